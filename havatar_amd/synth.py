@@ -1,0 +1,199 @@
+"""Deterministic synthetic inputs for the ray-march path (numpy only, no torch RNG).
+
+Everything here is a pure function of (shape, seed): a counter-based splitmix64 hash, so the
+same tensors can be regenerated bit-for-bit in the golden-fixture generator (which runs next to
+the reference), in the parity tests and in ``bench.py`` on the GPU box, without shipping the
+8 MB tri-plane / 2 MB skinning volume / 190 KB MLP as fixture files.
+
+The scene follows SURVEY.md section 8(d): pinhole camera at (0,0,5) looking at the origin
+(reference ray convention: dataloader/data_util.py:28-56), near/far = 5-1.6 / 5+1.0
+(dataloader/dataloader.py:174-177), white background, ``inv_head_T = [R^-1; -t]``
+(dataloader/dataloader.py:215-216).
+"""
+import math
+
+import numpy as np
+
+_MASK = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(x):
+    x = x.astype(np.uint64, copy=True)
+    with np.errstate(over="ignore"):
+        x += np.uint64(0x9E3779B97F4A7C15)
+        z = x
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def _counter(n, seed, stream):
+    base = np.uint64((seed * 0x100000001B3 + stream * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF)
+    with np.errstate(over="ignore"):
+        return np.arange(n, dtype=np.uint64) * np.uint64(2) + base
+
+
+def uniform(shape, seed, lo=0.0, hi=1.0):
+    """float32 U[lo,hi) with 24 random mantissa bits, element i depends only on (seed, i)."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    z = _splitmix64(_counter(n, seed, 1))
+    u = (z >> np.uint64(40)).astype(np.float64) * (1.0 / 16777216.0)
+    return (lo + (hi - lo) * u).astype(np.float32).reshape(shape)
+
+
+def normal(shape, seed, std=1.0):
+    """float32 N(0, std^2) by Box-Muller on two hash streams."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    z1 = _splitmix64(_counter(n, seed, 2))
+    z2 = _splitmix64(_counter(n, seed, 3))
+    u1 = ((z1 >> np.uint64(11)).astype(np.float64) + 1.0) * (1.0 / 9007199254740993.0)
+    u2 = (z2 >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+    g = np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * math.pi * u2)
+    return (std * g).astype(np.float32).reshape(shape)
+
+
+# ----------------------------------------------------------------------------------------------
+# Scene pieces
+# ----------------------------------------------------------------------------------------------
+XYZ_BOUNDING = [[-1.5, 1.5], [-1.6, 1.4], [-1.6, 1.2]]  # config/singleview_512_HD_base.yml:49
+
+
+def box_warp_param(xb, yb, zb):
+    """scale = 2/(max-min), trans = -scale*(max+min)/2  (utils/util.py:179-186)."""
+    out_s, out_t = [], []
+    for lo, hi in (xb, yb, zb):
+        f = 2.0 / (hi - lo)
+        c = f * (lo + hi) * 0.5
+        out_s.append(float(f))
+        out_t.append(float(-c))
+    return tuple(out_s), tuple(out_t)
+
+
+def nerf_box():
+    return box_warp_param(*XYZ_BOUNDING)
+
+
+def skin_box():
+    """Skin box = XYZ_bounding with Y_min := 0.3*Y_max (model/nerf_trainer.py:29-34)."""
+    yb = [0.3 * XYZ_BOUNDING[1][1], XYZ_BOUNDING[1][1]]
+    return box_warp_param(XYZ_BOUNDING[0], yb, XYZ_BOUNDING[2])
+
+
+def euler_deg_to_R(yaw, pitch, roll):
+    y, p, r = (math.radians(a) for a in (yaw, pitch, roll))
+    Ry = np.array([[math.cos(y), 0, math.sin(y)], [0, 1, 0], [-math.sin(y), 0, math.cos(y)]])
+    Rx = np.array([[1, 0, 0], [0, math.cos(p), -math.sin(p)], [0, math.sin(p), math.cos(p)]])
+    Rz = np.array([[math.cos(r), -math.sin(r), 0], [math.sin(r), math.cos(r), 0], [0, 0, 1]])
+    return (Rz @ Ry @ Rx).astype(np.float64)
+
+
+def inv_head_T(yaw=15.0, pitch=-8.0, roll=3.0, t=(0.02, -0.03, 0.01)):
+    """[4,3] = [R^-1 ; -t]  (dataloader/dataloader.py:215-216; right-multiplied row vectors)."""
+    R = euler_deg_to_R(yaw, pitch, roll)
+    return np.concatenate([np.linalg.inv(R), -np.asarray(t, np.float64)[None]], 0).astype(np.float32)
+
+
+def frame_pose(k, n=64):
+    """Head pose of frame k of an n-frame self-reenactment batch."""
+    return inv_head_T(yaw=20.0 * math.sin(2.0 * math.pi * k / n))
+
+
+def camera_rays(H, W, cam_dist=5.0, focal=1.7, near_off=-1.6, far_off=1.0, y0=0, y1=None):
+    """[rows*W, 8] = (o3, d3, near, far), row-major pixels, for image rows y0:y1.
+
+    Pinhole K = [[focal*W,0,0.5*W],[0,focal*H,0.5*H],[0,0,1]], dirs = K^-1 [i,j,1], camera looks
+    down +z in its own frame; c2w = diag(1,-1,-1) with origin (0,0,cam_dist); directions are
+    normalised (dataloader/data_util.py:28-56, normalize=True).
+    """
+    if y1 is None:
+        y1 = H
+    fx, fy, cx, cy = focal * W, focal * H, 0.5 * W, 0.5 * H
+    j, i = np.meshgrid(np.arange(y0, y1, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    dirs = np.stack([(i - cx) / fx, (j - cy) / fy, np.ones_like(i)], -1)
+    c2w = np.array([[1, 0, 0], [0, -1, 0], [0, 0, -1]], np.float64)
+    d = dirs @ c2w.T
+    d = d / np.linalg.norm(d, axis=-1, keepdims=True)
+    o = np.broadcast_to(np.array([0.0, 0.0, cam_dist]), d.shape)
+    near = np.full(d.shape[:-1] + (1,), cam_dist + near_off)
+    far = np.full(d.shape[:-1] + (1,), cam_dist + far_off)
+    return np.concatenate([o, d, near, far], -1).reshape(-1, 8).astype(np.float32)
+
+
+def triplane(B=1, C=64, res=128, seed=2, std=0.5, lowres=32):
+    """[2,B,C,res,res] NCHW like Trainer.model_coarse.triPlane_embeddings (model/nerf_model.py:85-86).
+
+    lowres=None: white noise (every texel independent: the worst case for the gather and for the
+    conditioning of the fine pass).  lowres=n: n x n noise upsampled bilinearly (align_corners) to
+    res x res and renormalised to `std` -- band-limited like the output of the StyleGAN encoders.
+    """
+    if lowres is None or lowres >= res:
+        return normal((2, B, C, res, res), seed, std)
+    lo = normal((2, B, C, lowres, lowres), seed, 1.0).astype(np.float64)
+    t = np.linspace(0.0, lowres - 1.0, res)
+    i0 = np.floor(t).astype(np.int64)
+    i1 = np.minimum(i0 + 1, lowres - 1)
+    f = t - i0
+    a = lo[..., i0, :] * (1.0 - f)[:, None] + lo[..., i1, :] * f[:, None]
+    b = a[..., i0] * (1.0 - f) + a[..., i1] * f
+    return (b / b.std() * std).astype(np.float32)
+
+
+def skin_volume(res=64, seed=3):
+    """[2,res,res,res] frozen skinning volume as fix_canonical_W leaves it (model/Skinning_Field.py:57-62).
+
+    x = sigmoid(2*N(0,1)); slab W1[:, 0, :] = 1; W1[:1, :res//8, :] = 1; W0 = 1 - W1.
+    """
+    g = normal((res, res, res), seed, 2.0).astype(np.float64)
+    w1 = (1.0 / (1.0 + np.exp(-g))).astype(np.float32)
+    w1[:, 0, :] = 1.0
+    w1[:1, : res // 8, :] = 1.0
+    return np.stack([1.0 - w1, w1], 0).astype(np.float32)
+
+
+def mlp_weights(seed=10, alpha_gain=5.0, alpha_bias=0.2, in_dim=176, hid=128, feat=64):
+    """Radiance-MLP parameters in the reference's nn.Linear layout (model/nerf_model.py:46-51).
+
+    U(-1/sqrt(fan_in), 1/sqrt(fan_in)) like torch's default Linear init, then the density head is
+    rescaled so that the accumulated opacity is not vacuous (primary recipe
+    gain 5 / bias 0.2, stress recipe gain 20 / bias -0.5).
+    """
+    def lin(o, i, s):
+        b = 1.0 / math.sqrt(i)
+        return uniform((o, i), s, -b, b), uniform((o,), s + 1000, -b, b)
+
+    W1, b1 = lin(hid, in_dim, seed)
+    W2, b2 = lin(hid, hid, seed + 1)
+    Wa, ba = lin(1, hid, seed + 2)
+    Wf, bf = lin(feat, hid, seed + 3)
+    Wc, bc = lin(3, feat, seed + 4)
+    Wa = (Wa * np.float32(alpha_gain)).astype(np.float32)
+    ba = np.full_like(ba, alpha_bias)
+    return dict(W1=W1, b1=b1, W2=W2, b2=b2, Wa=Wa, ba=ba, Wf=Wf, bf=bf, Wc=Wc, bc=bc)
+
+
+# recipe -> (density-head rescale, tri-plane smoothness).  Conditioning of the fine pass, measured as the
+# reference's own fp32-vs-fp64 L-inf on rgb_fine / depth_fine / acc_fine over a 16x16 frame:
+#   primary 8e-6 / 9e-5 / 2e-5   |   stress 2e-4 / 3e-3 / 4e-4   |   white 6e-5 / 6e-4 / 1e-4
+RECIPES = {
+    "primary": dict(mlp=dict(alpha_gain=5.0, alpha_bias=0.2), lowres=32),
+    "stress": dict(mlp=dict(alpha_gain=40.0, alpha_bias=0.0), lowres=16),
+    "white": dict(mlp=dict(alpha_gain=5.0, alpha_bias=0.2), lowres=None),
+}
+
+
+def scene(H, W, recipe="primary", y0=0, y1=None, B=1, pose=None):
+    """Everything one ray-march call needs, as numpy float32 (NCHW planes, reference layouts)."""
+    rays = camera_rays(H, W, y0=y0, y1=y1)
+    R = rays.shape[0]
+    ns, nt = nerf_box()
+    ss, st = skin_box()
+    return dict(
+        rays=np.broadcast_to(rays[None], (B, R, 8)).copy(),
+        bg=np.ones((B, R, 3), np.float32),
+        inv_T=np.broadcast_to((inv_head_T() if pose is None else pose)[None], (B, 4, 3)).copy(),
+        planes=triplane(B=B, lowres=RECIPES[recipe]["lowres"]),
+        vol=skin_volume(),
+        mlp=mlp_weights(**RECIPES[recipe]["mlp"]),
+        nerf_scale=ns, nerf_trans=nt, skin_scale=ss, skin_trans=st,
+    )

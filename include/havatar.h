@@ -1,0 +1,160 @@
+/*
+ * havatar.h -- C ABI of libhavatar_hip.so: the MI355X (gfx950) implementation of HAvatar's
+ * volumetric-rendering hot path and of its two StyleGAN2 custom ops.
+ *
+ * Every entry point takes plain device pointers + sizes + a HIP stream (void*, may be NULL for
+ * the default stream).  Nothing here allocates, frees or synchronises: the caller owns all
+ * memory and the launch is asynchronous on `stream` (reference convention: kernels go to
+ * at::cuda::getCurrentCUDAStream() with no sync and no post-launch check,
+ * model/op/fused_bias_act_kernel.cu:73,98; model/op/upfirdn2d_kernel.cu:215).
+ * Return value: 0 on success, a hipError_t (>0) from the launch, or a negative HAV_E* code for
+ * arguments this library refuses.
+ *
+ * Citations `path:line` are into the reference repository (XChenZ/havatar @ 2024_08_07).
+ */
+#ifndef HAVATAR_H
+#define HAVATAR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HAV_ABI_VERSION 1
+
+#define HAV_EINVAL   (-1) /* bad size / null pointer / inconsistent arguments            */
+#define HAV_EUNSUP   (-2) /* valid for the reference, not supported by this build        */
+
+/* element types of the op entry points (reference dispatch: AT_DISPATCH_FLOATING_TYPES_AND_HALF,
+ * fused_bias_act_kernel.cu:96, upfirdn2d_kernel.cu:311; bf16 is an addition) */
+#define HAV_F32  0
+#define HAV_F16  1
+#define HAV_BF16 2
+#define HAV_F64  3
+
+int hav_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * fused_bias_act -- replaces `fused.fused_bias_act(input, bias, refer, act, grad, alpha, scale)`
+ * (pybind: model/op/fused_bias_act.cpp:18-31; kernel: model/op/fused_bias_act_kernel.cu:18-105).
+ *   out[i] = scale * f(x[i] + b[(i / step_b) % size_b]),  i in [0, size_x)
+ *   act=1 linear, act=3 leaky-relu(alpha); grad=0 forward, grad=1 first derivative gated by the
+ *   sign of `ref`, grad=2 -> 0.  `b`/`ref` may be NULL (= the reference's empty tensors).
+ *   step_b = prod(x.shape[2:]), size_b = bias.numel().
+ * ------------------------------------------------------------------------------------------ */
+int hav_fused_bias_act(void* out, const void* x, const void* b, const void* ref,
+                       int dtype, int act, int grad, float alpha, float scale,
+                       int64_t size_x, int64_t step_b, int64_t size_b, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * upfirdn2d -- replaces `upfirdn2d.upfirdn2d(input[major,in_h,in_w,minor], kernel[kh,kw],
+ * up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1)`
+ * (pybind: model/op/upfirdn2d.cpp:17-31; kernels: model/op/upfirdn2d_kernel.cu:49-369).
+ *   zero-stuff by `up`, pad (negative pads crop), correlate with the FLIPPED FIR, decimate by
+ *   `down`.  out is [major,out_h,out_w,minor] with
+ *   out_h = (in_h*up_y + pad_y0 + pad_y1 - kh + down_y) / down_y   (upfirdn2d_kernel.cu:237-240).
+ *   The FIR is always float32 in this ABI (the reference casts it to the input dtype; taps are
+ *   accumulated in float32 either way, upfirdn2d_kernel.cu:115-116).
+ * ------------------------------------------------------------------------------------------ */
+int hav_upfirdn2d(void* out, const void* in, const float* kernel, int dtype,
+                  int64_t major, int in_h, int in_w, int minor, int kh, int kw,
+                  int up_x, int up_y, int down_x, int down_y,
+                  int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
+/* out_h/out_w for the arguments above (host-side helper, no device work) */
+int hav_upfirdn2d_out_size(int in_h, int in_w, int kh, int kw, int up_x, int up_y,
+                           int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0,
+                           int pad_y1, int* out_h, int* out_w);
+
+/* ------------------------------------------------------------------------------------------
+ * Ray march -- replaces Trainer.predict_and_render_radiance (model/nerf_trainer.py:120-201) and
+ * everything it calls: ray sampling (:129-141), Deformation_Field_new.forward
+ * (model/Skinning_Field.py:70-98), sample_pts_triplane_feat (model/nerf_model.py:88-99),
+ * Embedder.embed (model/network/embedder.py:32-61), the radiance MLP (model/nerf_model.py:101-117),
+ * volume_render_radiance_field / cumprod_exclusive (utils/nerf_util.py:4-73), sample_pdf
+ * (utils/nerf_util.py:76-117) and the sort/merge of the fine z list (model/nerf_trainer.py:170).
+ * One launch covers ALL rays of the call: the reference's 4096-ray chunk loop
+ * (model/nerf_trainer.py:66-71) only bounds activation memory and is not needed here.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct HavRenderParams {
+    int32_t B;            /* frames in this call (per-frame inv_T and tri-plane)               */
+    int32_t R;            /* rays per frame                                                    */
+    int32_t ray_stride;   /* floats per ray in `rays`; [0:3]=o [3:6]=d [6]=near [7]=far        */
+    int32_t S_c;          /* cfg.nerf.<mode>.num_coarse                                        */
+    int32_t S_f;          /* cfg.nerf.<mode>.num_fine (0: coarse pass only)                    */
+    int32_t perturb;      /* cfg.nerf.<mode>.perturb != 0                                      */
+    float   noise_std;    /* cfg.nerf.<mode>.radiance_field_noise_std                          */
+    int32_t plane_res;    /* tri-plane H = W (128)                                             */
+    int32_t plane_ch;     /* tri-plane channels per plane (64)                                 */
+    int32_t vol_res;      /* skinning volume D = H = W (64)                                    */
+    float   nerf_scale[3], nerf_trans[3];   /* UniformBoxWarp_new of the NeRF box (util.py:232) */
+    float   skin_scale[3], skin_trans[3];   /* ... of the skinning box (nerf_trainer.py:29-34)  */
+    uint64_t seed;        /* Philox key for on-device xi/zeta/eps when the rand pointers are NULL */
+    uint64_t rng_offset;  /* Philox counter base (advance per call)                            */
+} HavRenderParams;
+
+/* Radiance MLP parameters in nn.Linear layout (model/nerf_model.py:46-51), device pointers. */
+typedef struct HavMlpWeights {
+    const float* W1; const float* b1;   /* layers_xyz.0  [128,176],[128]   */
+    const float* W2; const float* b2;   /* layers_xyz.1  [128,128],[128]   */
+    const float* Wa; const float* ba;   /* fc_alpha      [1,128],[1]       */
+    const float* Wf; const float* bf;   /* fc_rgbFeat    [64,128],[64]     */
+    const float* Wc; const float* bc;   /* fc_rgb        [3,64],[3]        */
+} HavMlpWeights;
+
+/* Bytes of the packed, MFMA-fragment-ordered weight blob the ray march consumes. */
+int64_t hav_mlp_blob_bytes(void);
+/* Pack nn.Linear-layout weights into `blob` (device, hav_mlp_blob_bytes() bytes). Re-run whenever
+ * the weights change (training step / load_state_dict). */
+int hav_mlp_pack(void* blob, const HavMlpWeights* w, void* stream);
+
+/* NCHW [2,B,C,H,W] (Trainer.model_coarse.triPlane_embeddings, model/nerf_model.py:85-86)
+ * -> channels-last [2,B,H,W,C] so that one bilinear tap is one contiguous C*4-byte segment. */
+int hav_triplane_to_channels_last(float* dst, const float* src_nchw, int B, int C, int H, int W,
+                                  void* stream);
+
+typedef struct HavRenderOut {      /* all device pointers, float32; fine pointers unused if S_f==0 */
+    float* rgb_coarse;   /* [B,R,67]  rgb(3, sigmoid, + background) | feature(64)                 */
+    float* depth_coarse; /* [B,R]                                                                 */
+    float* acc_coarse;   /* [B,R]                                                                 */
+    float* weights_max;  /* [B,R]  max_i w_i of the LAST pass run (model/nerf_trainer.py:195,200) */
+    float* rgb_fine;     /* [B,R,67]                                                              */
+    float* depth_fine;   /* [B,R]                                                                 */
+    float* acc_fine;     /* [B,R]                                                                 */
+} HavRenderOut;
+
+/*
+ * rays      [B,R,ray_stride]                    (ray_batch; viewdirs, if present, are ignored:
+ *                                                the only consumer is dead code, nerf_trainer.py:146-150)
+ * bg        [B,R,3] or NULL                     (background_prior)
+ * inv_T     [B,4,3]                             (inv_head_T: rows 0-2 = M, row 3 = tau)
+ * planes_cl [2,B,H,W,C] channels-last           (hav_triplane_to_channels_last)
+ * skin_vol  [2,D,H,W]                           (canonical_W[0], shared by the batch)
+ * mlp_blob  hav_mlp_pack output
+ * t_rand    [B,R,S_c] or NULL                   (xi  = torch.rand at nerf_trainer.py:138)
+ * u_rand    [B*R,S_f] or NULL                   (zeta= torch.rand at utils/nerf_util.py:95)
+ * noise_c   [B*R,S_c] / noise_f [B*R,S_fp] or NULL (eps = torch.randn at utils/nerf_util.py:49-56,
+ *                                                UNSCALED standard normals; multiplied by noise_std here)
+ * With perturb!=0 and a NULL rand pointer the values come from an on-device Philox4x32-10 stream.
+ */
+int hav_render_rays(const HavRenderParams* p, const float* rays, const float* bg,
+                    const float* inv_T, const float* planes_cl, const float* skin_vol,
+                    const void* mlp_blob, const float* t_rand, const float* u_rand,
+                    const float* noise_c, const float* noise_f, const HavRenderOut* out,
+                    void* stream);
+
+/* Name of the ray-march kernel variant a call with these parameters would launch (for profiles). */
+const char* hav_render_variant(const HavRenderParams* p);
+
+/* ------------------------------------------------------------------------------------------
+ * get_rays on device (next-1; reference: dataloader/data_util.py:28-56 +
+ * dataloader/dataloader.py:174-177): rays[H*W,8] = (o3, d3 normalised, near, far) from
+ * intr=(fx,fy,cx/W,cy/H), c2w[3,4] row-major, for pixel rows [y0,y1).
+ * ------------------------------------------------------------------------------------------ */
+int hav_gen_rays(float* rays, int H, int W, const float intr[4], const float c2w[12],
+                 float near, float far, int y0, int y1, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HAVATAR_H */
