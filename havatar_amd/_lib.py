@@ -1,0 +1,87 @@
+"""ctypes binding of libhavatar_hip.so (the C ABI declared in include/havatar.h).
+
+Fails loudly: there is no CPU or PyTorch fallback behind these entry points.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhavatar_hip.so")
+
+HAV_F32, HAV_F16, HAV_BF16, HAV_F64 = 0, 1, 2, 3
+ABI_VERSION = 1
+
+
+class HavRenderParams(C.Structure):
+    _fields_ = [("B", C.c_int32), ("R", C.c_int32), ("ray_stride", C.c_int32), ("S_c", C.c_int32),
+                ("S_f", C.c_int32), ("perturb", C.c_int32), ("noise_std", C.c_float),
+                ("plane_res", C.c_int32), ("plane_ch", C.c_int32), ("vol_res", C.c_int32),
+                ("nerf_scale", C.c_float * 3), ("nerf_trans", C.c_float * 3),
+                ("skin_scale", C.c_float * 3), ("skin_trans", C.c_float * 3),
+                ("seed", C.c_uint64), ("rng_offset", C.c_uint64)]
+
+
+class HavMlpWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("W1", "b1", "W2", "b2", "Wa", "ba", "Wf", "bf", "Wc", "bc")]
+
+
+class HavRenderOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("rgb_coarse", "depth_coarse", "acc_coarse", "weights_max",
+                                          "rgb_fine", "depth_fine", "acc_fine")]
+
+
+class HavatarLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load the library (once). Raises HavatarLibraryError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HavatarLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -m havatar_amd.build` "
+            "(or __graft_entry__.build()). There is no fallback path.")
+    L = C.CDLL(LIB_PATH)
+    L.hav_abi_version.restype = C.c_int
+    if L.hav_abi_version() != ABI_VERSION:
+        raise HavatarLibraryError(f"ABI mismatch: library {L.hav_abi_version()} vs binding {ABI_VERSION}")
+    i64, i32, f32, vp = C.c_int64, C.c_int, C.c_float, C.c_void_p
+    L.hav_fused_bias_act.argtypes = [vp, vp, vp, vp, i32, i32, i32, f32, f32, i64, i64, i64, vp]
+    L.hav_fused_bias_act.restype = i32
+    L.hav_upfirdn2d.argtypes = [vp, vp, vp, i32, i64] + [i32] * 13 + [vp]
+    L.hav_upfirdn2d.restype = i32
+    L.hav_upfirdn2d_out_size.argtypes = [i32] * 12 + [C.POINTER(i32), C.POINTER(i32)]
+    L.hav_upfirdn2d_out_size.restype = i32
+    L.hav_mlp_blob_bytes.restype = i64
+    L.hav_mlp_pack.argtypes = [vp, C.POINTER(HavMlpWeights), vp]
+    L.hav_mlp_pack.restype = i32
+    L.hav_triplane_to_channels_last.argtypes = [vp, vp, i32, i32, i32, i32, vp]
+    L.hav_triplane_to_channels_last.restype = i32
+    L.hav_render_rays.argtypes = [C.POINTER(HavRenderParams)] + [vp] * 10 + [C.POINTER(HavRenderOut), vp]
+    L.hav_render_rays.restype = i32
+    L.hav_render_variant.argtypes = [C.POINTER(HavRenderParams)]
+    L.hav_render_variant.restype = C.c_char_p
+    L.hav_debug_set_zfine.argtypes = [vp]
+    L.hav_debug_set_zfine.restype = None
+    L.hav_gen_rays.argtypes = [vp, i32, i32, C.POINTER(f32), C.POINTER(f32), f32, f32, i32, i32, vp]
+    L.hav_gen_rays.restype = i32
+    _lib = L
+    return L
+
+
+_ERR = {-1: "HAV_EINVAL (bad size / null pointer / inconsistent arguments)",
+        -2: "HAV_EUNSUP (valid for the reference, not supported by this build)"}
+
+
+def check(rc, what):
+    """0 -> ok; negative -> library refusal; positive -> hipError_t from the launch."""
+    if rc == 0:
+        return
+    if rc < 0:
+        raise RuntimeError(f"{what}: {_ERR.get(rc, rc)}")
+    raise RuntimeError(f"{what}: HIP error {rc}")

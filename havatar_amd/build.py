@@ -1,0 +1,53 @@
+"""Build libhavatar_hip.so (gfx950) in-tree: `python -m havatar_amd.build`.
+
+One `hipcc --offload-arch=gfx950 -shared` per source set; hipcc cross-compiles without a GPU.  The .so is
+git-ignored but travels with the tree to the GPU box.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libhavatar_hip.so")
+SOURCES = ["hav_ops.hip", "hav_render.hip"]
+HEADERS = ["hav_common.h", os.path.join("..", "..", "include", "havatar.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 and link libhavatar_hip.so. Returns the library path."""
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        hipcc = "hipcc"
+    os.makedirs(LIBDIR, exist_ok=True)
+    objs = []
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(obj)
+    for cmd, pr in procs:
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode(errors="replace")))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

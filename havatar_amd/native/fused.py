@@ -1,0 +1,48 @@
+"""`fused` -- same call surface as the reference's pybind module (model/op/fused_bias_act.cpp:18-31),
+backed by hav_fused_bias_act in libhavatar_hip.so.  HIP tensors only; no CPU path (the reference's module has none
+either: CPU tensors never reach it, model/op/fused_act.py:108-119)."""
+import ctypes as C
+
+import torch
+
+from .. import _lib
+
+_DT = {torch.float32: _lib.HAV_F32, torch.float16: _lib.HAV_F16, torch.bfloat16: _lib.HAV_BF16,
+       torch.float64: _lib.HAV_F64}
+
+
+def _check_input(t, name):
+    # CHECK_CUDA / CHECK_CONTIGUOUS (fused_bias_act.cpp:10-16) -> RuntimeError like TORCH_CHECK
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+
+
+def fused_bias_act(input, bias, refer, act, grad, alpha, scale):
+    """out = scale * act'(input + bias[c]); `bias` / `refer` may be empty tensors (= absent)."""
+    _check_input(input, "input")
+    _check_input(bias, "bias")
+    if input.dtype not in _DT:
+        raise RuntimeError(f"fused_bias_act: unsupported dtype {input.dtype}")
+    x = input
+    b = bias.contiguous().to(x.dtype) if bias.numel() else None
+    ref = refer.contiguous().to(x.dtype) if refer.numel() else None
+    if ref is not None and ref.numel() != x.numel():
+        raise RuntimeError("fused_bias_act: refer must have as many elements as input")
+    step_b = 1
+    for d in x.shape[2:]:
+        step_b *= d                                   # fused_bias_act_kernel.cu:82-88
+    out = torch.empty_like(x)
+    if x.numel() == 0:
+        return out
+    with torch.cuda.device(x.device):                 # at::DeviceGuard (fused_bias_act.cpp:25)
+        rc = _lib.lib().hav_fused_bias_act(
+            C.c_void_p(out.data_ptr()), C.c_void_p(x.data_ptr()),
+            C.c_void_p(b.data_ptr()) if b is not None else None,
+            C.c_void_p(ref.data_ptr()) if ref is not None else None,
+            _DT[x.dtype], int(act), int(grad), float(alpha), float(scale),
+            x.numel(), step_b, b.numel() if b is not None else 0,
+            C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, "hav_fused_bias_act")
+    return out

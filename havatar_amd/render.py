@@ -1,0 +1,144 @@
+"""Torch-level host side of the fused ray march (one C-ABI call per set of rays).
+
+`RayMarcher` owns the device-resident, kernel-friendly copies of the per-model / per-frame constants:
+the MFMA-fragment-ordered weight blob (re-packed only when the weights change) and the channels-last
+tri-plane (re-laid-out once per frame), and launches `hav_render_rays` on torch's current HIP stream.
+"""
+import ctypes as C
+import os
+
+import torch
+
+from . import _lib
+
+_DEBUG_SYNC = os.environ.get("HAVATAR_DEBUG_SYNC", "0") == "1"
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk_f32_cuda(name, t, allow_none=False):
+    if t is None:
+        if allow_none:
+            return None
+        raise RuntimeError(f"{name} is required")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA/HIP tensor")     # TORCH_CHECK(is_cuda), fused_bias_act.cpp:10-16
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32")
+    return t.contiguous()
+
+
+class RayMarcher:
+    """Device state + launcher for `hav_render_rays`."""
+
+    def __init__(self, nerf_scale, nerf_trans, skin_scale, skin_trans, plane_res=128, plane_ch=64, vol_res=64):
+        self.nerf_scale, self.nerf_trans = tuple(map(float, nerf_scale)), tuple(map(float, nerf_trans))
+        self.skin_scale, self.skin_trans = tuple(map(float, skin_scale)), tuple(map(float, skin_trans))
+        self.plane_res, self.plane_ch, self.vol_res = plane_res, plane_ch, vol_res
+        self.blob = None
+        self._blob_key = None
+        self.planes_cl = None
+        self.rng_offset = 0
+        self.seed = 0x9E3779B97F4A7C15
+
+    # -- constants -----------------------------------------------------------------------------
+    def set_mlp(self, W1, b1, W2, b2, Wa, ba, Wf, bf, Wc, bc, force=False):
+        """Pack nn.Linear-layout weights (model/nerf_model.py:46-51) into the fragment-ordered blob."""
+        ts = [_chk_f32_cuda(n, t) for n, t in zip(("W1", "b1", "W2", "b2", "Wa", "ba", "Wf", "bf", "Wc", "bc"),
+                                                   (W1, b1, W2, b2, Wa, ba, Wf, bf, Wc, bc))]
+        key = tuple((t.data_ptr(), t._version) for t in ts)
+        if not force and key == self._blob_key and self.blob is not None:
+            return
+        L = _lib.lib()
+        if self.blob is None or self.blob.device != ts[0].device:
+            self.blob = torch.empty(int(L.hav_mlp_blob_bytes()) // 4, dtype=torch.float32, device=ts[0].device)
+        w = _lib.HavMlpWeights(*[t.data_ptr() for t in ts])
+        with torch.cuda.device(ts[0].device):
+            _lib.check(L.hav_mlp_pack(_ptr(self.blob), C.byref(w), _stream()), "hav_mlp_pack")
+        self._blob_key = key
+        self._keep = ts
+
+    def set_triplane(self, planes_nchw):
+        """[2,B,C,H,W] (Trainer.model_coarse.triPlane_embeddings) -> channels-last device copy."""
+        p = _chk_f32_cuda("triPlane_embeddings", planes_nchw)
+        two, B, Cc, H, W = p.shape
+        if two != 2 or Cc != self.plane_ch or H != W:
+            raise RuntimeError(f"unsupported tri-plane shape {tuple(p.shape)}")
+        self.plane_res = H
+        if self.planes_cl is None or self.planes_cl.shape != (2, B, H, W, Cc) or self.planes_cl.device != p.device:
+            self.planes_cl = torch.empty((2, B, H, W, Cc), dtype=torch.float32, device=p.device)
+        with torch.cuda.device(p.device):
+            _lib.check(_lib.lib().hav_triplane_to_channels_last(_ptr(self.planes_cl), _ptr(p), B, Cc, H, W, _stream()),
+                       "hav_triplane_to_channels_last")
+
+    # -- launch --------------------------------------------------------------------------------
+    def render(self, rays, bg, inv_T, skin_vol, S_c, S_f, perturb=False, noise_std=0.0,
+               t_rand=None, u_rand=None, noise_c=None, noise_f=None, dbg_zfine=False):
+        """rays [B,R,>=8], bg [B,R,3]|None, inv_T [B,4,3], skin_vol [2,D,H,W] or [1,2,D,H,W].
+
+        Returns the 7-tuple of predict_and_render_radiance (model/nerf_trainer.py:194-201):
+        rgb_coarse [B,R,67], depth_coarse [B,R,1], acc_coarse [B,R,1], weights_max [B,R,1],
+        rgb_fine, depth_fine, acc_fine (None x3 if S_f == 0)."""
+        if self.blob is None or self.planes_cl is None:
+            raise RuntimeError("set_mlp() and set_triplane() must be called before render()")
+        rays = _chk_f32_cuda("ray_batch", rays)
+        B, R, stride = rays.shape
+        bg = _chk_f32_cuda("background_prior", bg, allow_none=True)
+        inv_T = _chk_f32_cuda("inv_head_T", inv_T)
+        vol = _chk_f32_cuda("canonical_W", skin_vol)
+        if vol.dim() == 5:
+            vol = vol[0]
+        if self.planes_cl.shape[1] != B or inv_T.shape[0] != B:
+            raise RuntimeError("batch mismatch between rays, inv_head_T and the tri-plane")
+        dev = rays.device
+        S_fp = (S_c + 1) // 2 + S_f if S_f > 0 else 0
+        p = _lib.HavRenderParams()
+        p.B, p.R, p.ray_stride, p.S_c, p.S_f = B, R, stride, S_c, S_f
+        p.perturb, p.noise_std = int(bool(perturb)), float(noise_std)
+        p.plane_res, p.plane_ch, p.vol_res = self.plane_res, self.plane_ch, vol.shape[-1]
+        for i in range(3):
+            p.nerf_scale[i], p.nerf_trans[i] = self.nerf_scale[i], self.nerf_trans[i]
+            p.skin_scale[i], p.skin_trans[i] = self.skin_scale[i], self.skin_trans[i]
+        p.seed, p.rng_offset = self.seed, self.rng_offset
+        self.rng_offset += 1
+        t_rand = _chk_f32_cuda("t_rand", t_rand, True)
+        u_rand = _chk_f32_cuda("u_rand", u_rand, True)
+        noise_c = _chk_f32_cuda("noise_c", noise_c, True)
+        noise_f = _chk_f32_cuda("noise_f", noise_f, True)
+        for nm, t, n in (("t_rand", t_rand, B * R * S_c), ("u_rand", u_rand, B * R * S_f),
+                         ("noise_c", noise_c, B * R * S_c), ("noise_f", noise_f, B * R * S_fp)):
+            if t is not None and t.numel() != n:
+                raise RuntimeError(f"{nm} has {t.numel()} elements, expected {n}")
+        e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        rgb_c, d_c, a_c, wmax = e(B, R, 67), e(B, R, 1), e(B, R, 1), e(B, R, 1)
+        if S_f > 0:
+            rgb_f, d_f, a_f = e(B, R, 67), e(B, R, 1), e(B, R, 1)
+        else:
+            rgb_f = d_f = a_f = None
+        out = _lib.HavRenderOut(rgb_c.data_ptr(), d_c.data_ptr(), a_c.data_ptr(), wmax.data_ptr(),
+                                *(t.data_ptr() if t is not None else None for t in (rgb_f, d_f, a_f)))
+        L = _lib.lib()
+        zf = None
+        with torch.cuda.device(dev):
+            if dbg_zfine and S_fp > 0:
+                zf = e(B * R, S_fp)
+                L.hav_debug_set_zfine(_ptr(zf))
+            rc = L.hav_render_rays(C.byref(p), _ptr(rays), _ptr(bg), _ptr(inv_T), _ptr(self.planes_cl), _ptr(vol),
+                                   _ptr(self.blob), _ptr(t_rand), _ptr(u_rand), _ptr(noise_c), _ptr(noise_f),
+                                   C.byref(out), _stream())
+            _lib.check(rc, "hav_render_rays")
+            if _DEBUG_SYNC:
+                torch.cuda.synchronize()
+        res = (rgb_c, d_c, a_c, wmax, rgb_f, d_f, a_f)
+        return res + (zf,) if dbg_zfine else res
+
+    def variant(self, S_c, S_f, perturb=False, noise_std=0.0):
+        p = _lib.HavRenderParams()
+        p.S_c, p.S_f, p.perturb, p.noise_std = S_c, S_f, int(bool(perturb)), float(noise_std)
+        return _lib.lib().hav_render_variant(C.byref(p)).decode()

@@ -143,6 +143,10 @@ int hav_render_rays(const HavRenderParams* p, const float* rays, const float* bg
                     const float* noise_c, const float* noise_f, const HavRenderOut* out,
                     void* stream);
 
+/* Test hook: the NEXT hav_render_rays call additionally dumps the merged, sorted fine depths
+ * [B*R, S_fp] to `dev_ptr` (device memory); one-shot, cleared by that call. */
+void hav_debug_set_zfine(float* dev_ptr);
+
 /* Name of the ray-march kernel variant a call with these parameters would launch (for profiles). */
 const char* hav_render_variant(const HavRenderParams* p);
 

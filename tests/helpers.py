@@ -1,0 +1,56 @@
+"""Shared helpers for the parity tests (oracle side + HIP side)."""
+import os
+
+import numpy as np
+
+from havatar_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+OUT_KEYS = ("rgb_coarse", "depth_coarse", "acc_coarse", "weights_max", "rgb_fine", "depth_fine", "acc_fine")
+
+
+def checksum(a):
+    a = np.asarray(a, np.float64).ravel()
+    return np.array([a.sum(), np.abs(a).sum(), (a * np.arange(1, a.size + 1) % 7.0).sum()])
+
+
+def load_render_fixture(name):
+    """-> (fixture npz, scene dict with regenerated planes/vol/mlp, kwargs for the random inputs)."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    H, W, recipe = int(g["meta_H"]), int(g["meta_W"]), str(g["meta_recipe"])
+    B = g["rays"].shape[0]
+    sc = synth.scene(H, W, recipe, B=B)
+    sc["rays"], sc["bg"], sc["inv_T"] = g["rays"], g["bg"], g["inv_T"]
+    # the regenerated seed tensors must be the ones the reference was run on
+    np.testing.assert_allclose(checksum(sc["planes"]), g["cks_planes"], rtol=1e-12)
+    np.testing.assert_allclose(checksum(sc["vol"]), g["cks_vol"], rtol=1e-12)
+    ck = np.stack([checksum(sc["mlp"][k]) for k in ("W1", "b1", "W2", "b2", "Wa", "ba", "Wf", "bf", "Wc", "bc")])
+    np.testing.assert_allclose(ck, g["cks_mlp"], rtol=1e-12)
+    kw = {k: g[k] for k in ("t_rand", "u_rand", "noise_c", "noise_f") if k in g.files}
+    cfg = dict(S_c=int(g["S_c"]), S_f=int(g["S_f"]), perturb=bool(g["perturb"]), noise_std=float(g["noise_std"]))
+    return g, sc, cfg, kw
+
+
+def hip_render(sc, S_c, S_f, perturb=False, noise_std=0.0, t_rand=None, u_rand=None, noise_c=None, noise_f=None,
+               dbg_zfine=False):
+    """Run the HIP ray march (through the C ABI) on a synth-style scene; returns numpy outputs keyed like OUT_KEYS."""
+    import torch
+    from havatar_amd.render import RayMarcher
+    dev = torch.device("cuda:0")
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+    rm = RayMarcher(sc["nerf_scale"], sc["nerf_trans"], sc["skin_scale"], sc["skin_trans"])
+    m = sc["mlp"]
+    rm.set_mlp(*[t(m[k]) for k in ("W1", "b1", "W2", "b2", "Wa", "ba", "Wf", "bf", "Wc", "bc")])
+    rm.set_triplane(t(sc["planes"]))
+    res = rm.render(t(sc["rays"]), t(sc["bg"]), t(sc["inv_T"]), t(sc["vol"]), S_c, S_f, perturb=perturb,
+                    noise_std=noise_std, t_rand=t(t_rand), u_rand=t(u_rand), noise_c=t(noise_c), noise_f=t(noise_f),
+                    dbg_zfine=dbg_zfine)
+    torch.cuda.synchronize()
+    out = {k: (None if v is None else v.cpu().numpy().reshape(v.shape[0], v.shape[1], -1)) for k, v in zip(OUT_KEYS, res)}
+    if dbg_zfine:
+        out["z_fine"] = res[7].cpu().numpy()
+    return out
+
+
+def linf(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64).reshape(np.shape(a))).max())

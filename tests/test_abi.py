@@ -1,0 +1,78 @@
+"""CPU: libhavatar_hip.so loads and exports every symbol include/havatar.h declares (no compute without a GPU),
+and the product package never touches the oracle."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "havatar.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(hav_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_all_declared_symbols():
+    from havatar_amd import _lib, build
+    build.build()
+    names = _declared()
+    assert len(names) >= 10
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/havatar.h but not exported"
+    L = _lib.lib()
+    assert L.hav_abi_version() == _lib.ABI_VERSION
+    assert L.hav_mlp_blob_bytes() > 4 * (176 * 128 + 128 * 128 + 68 * 128)
+
+
+def test_out_size_helper_matches_reference_formula():
+    from havatar_amd import _lib
+    L = _lib.lib()
+    oh, ow = ctypes.c_int(), ctypes.c_int()
+    for (h, w, kh, kw, ux, uy, dx, dy, p) in [(128, 128, 4, 4, 1, 1, 1, 1, (2, 2, 2, 2)), (64, 48, 4, 4, 2, 2, 1, 1, (2, 1, 2, 1)),
+                                               (513, 513, 4, 4, 1, 1, 2, 2, (1, 1, 1, 1)), (10, 13, 5, 3, 3, 2, 2, 3, (2, 3, 1, 4))]:
+        assert L.hav_upfirdn2d_out_size(h, w, kh, kw, ux, uy, dx, dy, *p, ctypes.byref(oh), ctypes.byref(ow)) == 0
+        assert oh.value == (h * uy + p[2] + p[3] - kh + dy) // dy
+        assert ow.value == (w * ux + p[0] + p[1] - kw + dx) // dx
+    assert L.hav_upfirdn2d_out_size(4, 4, 9, 9, 1, 1, 1, 1, 0, 0, 0, 0, ctypes.byref(oh), ctypes.byref(ow)) == -1
+
+
+def test_struct_layouts_match_header():
+    from havatar_amd import _lib
+    from oracle import oracle
+    assert ctypes.sizeof(_lib.HavRenderParams) == 104 == ctypes.sizeof(oracle.HavRenderParams)
+    assert ctypes.sizeof(_lib.HavMlpWeights) == 80
+    assert ctypes.sizeof(_lib.HavRenderOut) == 56
+
+
+def test_product_never_imports_oracle():
+    """havatar_amd/ must not reference oracle/ (a product path through the oracle voids every parity claim)."""
+    bad = []
+    for dp, _, fs in os.walk(os.path.join(ROOT, "havatar_amd")):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f), errors="replace").read()
+                if re.search(r"(from|import)\s+oracle|hav_oracle|libhav_oracle|orc_", txt):
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from havatar_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libhavatar_hip.so")
+    with pytest.raises(_lib.HavatarLibraryError):
+        _lib.lib()
+
+
+def test_cpu_tensors_are_refused_by_native_modules():
+    import torch
+    from havatar_amd.native import fused, upfirdn2d
+    x = torch.zeros(1, 2, 4, 4)
+    with pytest.raises(RuntimeError):
+        fused.fused_bias_act(x, x.new_empty(0), x.new_empty(0), 3, 0, 0.2, 1.0)
+    with pytest.raises(RuntimeError):
+        upfirdn2d.upfirdn2d(x.reshape(2, 4, 4, 1), torch.ones(2, 2), 1, 1, 1, 1, 0, 0, 0, 0)

@@ -1,0 +1,181 @@
+"""GPU: fused_bias_act / upfirdn2d HIP kernels (through the C ABI and the reference-shaped Python surface)
+against the oracle and the reference's CPU vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, linf
+from havatar_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+S2 = 2 ** 0.5
+
+
+def _t(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    return t if dtype is None else t.to(dtype)
+
+
+@pytest.mark.parametrize("shape,cb", [((2, 5, 7, 9), 5), ((3, 6), 6), ((1, 64, 32, 32), 64), ((2, 3, 5, 5), 3), ((1, 1, 1, 1), 1),
+                                      ((4, 8, 3, 1), 8)])
+@pytest.mark.parametrize("act,grad", [(3, 0), (3, 1), (3, 2), (1, 0), (1, 1), (1, 2)])
+def test_fused_bias_act_f32_bit_exact(shape, cb, act, grad):
+    from oracle import oracle
+    from havatar_amd.native import fused
+    x, b, ref = synth.normal(shape, 1), synth.normal((cb,), 2), synth.normal(shape, 3)
+    for bias in (b, None):
+        for rf in (ref, None):
+            y = fused.fused_bias_act(_t(x), _t(bias) if bias is not None else _t(x).new_empty(0),
+                                     _t(rf) if rf is not None else _t(x).new_empty(0), act, grad, 0.2, S2)
+            yo = oracle.fused_bias_act(x, bias, rf, act, grad, 0.2, S2)
+            assert np.array_equal(y.cpu().numpy(), yo), (shape, act, grad, bias is None, rf is None)
+
+
+def test_fused_bias_act_dtypes_and_unaligned():
+    from oracle import oracle
+    from havatar_amd.native import fused
+    x, b = synth.normal((2, 6, 5, 3), 4), synth.normal((6,), 5)       # step_b = 15: not a multiple of any vector width
+    yo = oracle.fused_bias_act(x, b, None, 3, 0, 0.2, S2)
+    assert np.array_equal(fused.fused_bias_act(_t(x), _t(b), _t(x).new_empty(0), 3, 0, 0.2, S2).cpu().numpy(), yo)
+    y64 = fused.fused_bias_act(_t(x, torch.float64), _t(b, torch.float64), _t(x, torch.float64).new_empty(0), 3, 0, 0.2, S2)
+    assert np.array_equal(y64.cpu().numpy(), oracle.fused_bias_act(x.astype(np.float64), b.astype(np.float64), None, 3, 0, 0.2, S2))
+    for dt, tol in ((torch.float16, 2e-3), (torch.bfloat16, 2e-2)):
+        xs = _t(synth.normal((1, 16, 8, 8), 6), dt)
+        bs = _t(synth.normal((16,), 7), dt)
+        y = fused.fused_bias_act(xs, bs, xs.new_empty(0), 3, 0, 0.2, S2)
+        yo = oracle.fused_bias_act(xs.float().cpu().numpy(), bs.float().cpu().numpy(), None, 3, 0, 0.2, S2)
+        assert y.dtype == dt and linf(y.float().cpu().numpy(), yo) <= tol * max(1.0, np.abs(yo).max())
+    # a view with a storage offset: data pointer not 16-byte aligned -> scalar kernel
+    base = _t(synth.normal((1, 4, 9, 9), 8).ravel())
+    xo = base[1:1 + 4 * 80].view(1, 4, 8, 10)
+    yo = oracle.fused_bias_act(xo.cpu().numpy(), b[:4], None, 3, 0, 0.2, S2)
+    assert np.array_equal(fused.fused_bias_act(xo, _t(b[:4]), xo.new_empty(0), 3, 0, 0.2, S2).cpu().numpy(), yo)
+    with pytest.raises(RuntimeError):
+        fused.fused_bias_act(_t(x).transpose(2, 3), _t(b), _t(x).new_empty(0), 3, 0, 0.2, S2)   # non-contiguous
+
+
+def test_fused_leaky_relu_module_matches_reference_and_grads():
+    from havatar_amd.model.op import FusedLeakyReLU, fused_leaky_relu
+    g = np.load(os.path.join(GOLDEN, "ops_reference_cpu.npz"))
+    x, b = _t(g["fba_x"]), _t(g["fba_b"])
+    assert linf(fused_leaky_relu(x, b).cpu().numpy(), g["fba_y"]) <= 1e-6
+    assert linf(fused_leaky_relu(x).cpu().numpy(), g["fba_y_nobias"]) <= 1e-6
+    assert linf(fused_leaky_relu(_t(g["fba_x2"]), _t(g["fba_b2"])).cpu().numpy(), g["fba_y2"]) <= 1e-6
+    m = FusedLeakyReLU(5).to(DEV)
+    with torch.no_grad():
+        m.bias.copy_(b)
+    xr = x.clone().requires_grad_(True)
+    gx, gb = torch.autograd.grad(m(xr), (xr, m.bias), _t(g["fba_go"]))
+    assert linf(gx.cpu().numpy(), g["fba_gx"]) <= 1e-6 and linf(gb.cpu().numpy(), g["fba_gb"]) <= 1e-4
+    # the HIP path honours negative_slope (kernel.cu:53) while the CPU branch hard-codes 0.2 (SURVEY B-4)
+    y7 = fused_leaky_relu(x, b, 0.7)
+    assert linf(y7.cpu().numpy(), np.where(g["fba_x"] + g["fba_b"][None, :, None, None] > 0, 1.0, 0.7) *
+                (g["fba_x"] + g["fba_b"][None, :, None, None]) * S2) <= 1e-6
+    # first and second order through the custom Functions, in float64
+    xd = _t(synth.normal((2, 3, 4, 5), 9), torch.float64).requires_grad_(True)
+    bd = _t(synth.normal((3,), 10), torch.float64).requires_grad_(True)
+    f = lambda a, c: fused_leaky_relu(a, c, 0.2, S2)
+    assert torch.autograd.gradcheck(f, (xd, bd), eps=1e-6, atol=1e-6)
+    assert torch.autograd.gradgradcheck(f, (xd, bd), eps=1e-6, atol=1e-6)
+
+
+def _ufd_cases():
+    g = np.load(os.path.join(GOLDEN, "ops_reference_cpu.npz"))
+    return g, sorted({k[4:-2] for k in g.files if k.startswith("ufd_") and k.endswith("_k")})
+
+
+def test_upfirdn2d_matches_reference_vectors_and_grads():
+    from havatar_amd.model.op import upfirdn2d
+    g, names = _ufd_cases()
+    x = _t(g["ufd_x"])
+    for n in names:
+        k = _t(g[f"ufd_{n}_k"])
+        ux, uy, dx, dy, px0, px1, py0, py1 = [int(v) for v in g[f"ufd_{n}_args"]]
+        xr = x.clone().requires_grad_(True)
+        y = upfirdn2d(xr, k, up=(ux, uy), down=(dx, dy), pad=(px0, px1, py0, py1))
+        assert linf(y.detach().cpu().numpy(), g[f"ufd_{n}_y"]) <= 2e-6, n
+        gi, = torch.autograd.grad(y, xr, _t(g[f"ufd_{n}_go"]))
+        assert linf(gi.cpu().numpy(), g[f"ufd_{n}_gx"]) <= 5e-6, n
+
+
+@pytest.mark.parametrize("case", [
+    # (major, H, W, minor, kh, kw, up, down, pad)   -- tiled fast paths at sizes that are not tile multiples
+    (3, 70, 131, 1, 4, 4, (1, 1), (1, 1), (2, 2, 2, 2)), (5, 33, 65, 1, 4, 4, (1, 1), (1, 1), (1, 1, 1, 1)),
+    (2, 64, 64, 1, 3, 3, (1, 1), (1, 1), (1, 1, 1, 1)), (4, 17, 40, 1, 4, 4, (2, 2), (1, 1), (2, 1, 2, 1)),
+    (3, 31, 33, 1, 2, 2, (2, 2), (1, 1), (1, 0, 1, 0)), (2, 129, 67, 1, 4, 4, (1, 1), (2, 2), (1, 1, 1, 1)),
+    (6, 64, 66, 1, 2, 2, (1, 1), (2, 2), (0, 0, 0, 0)), (2, 16, 16, 1, 1, 1, (1, 1), (1, 1), (0, 0, 0, 0)),
+    (2, 40, 40, 1, 4, 2, (1, 1), (1, 1), (3, 0, 1, 2)), (2, 40, 41, 1, 2, 4, (2, 2), (1, 1), (0, 3, 2, 1)),
+    # generic kernel: minor > 1, anisotropic factors, large FIR, negative pads
+    (2, 12, 9, 3, 5, 3, (3, 2), (2, 3), (2, 3, 1, 4)), (3, 20, 22, 1, 7, 7, (1, 1), (1, 1), (3, 3, 3, 3)),
+    (2, 14, 15, 2, 4, 4, (1, 1), (1, 1), (-1, 2, -2, 3)), (1, 9, 9, 1, 3, 3, (2, 2), (2, 2), (1, 1, 1, 1)),
+    (2, 30, 30, 1, 4, 4, (1, 2), (2, 1), (1, 2, 2, 1)),
+])
+def test_upfirdn2d_native_vs_oracle(case):
+    from oracle import oracle
+    from havatar_amd.native import upfirdn2d as op
+    major, H, W, minor, kh, kw, up, dn, pad = case
+    x, k = synth.normal((major, H, W, minor), 11), synth.normal((kh, kw), 12)
+    y = op.upfirdn2d(_t(x), _t(k), up[0], up[1], dn[0], dn[1], *pad)
+    yo = oracle.upfirdn2d(x, k, up[0], up[1], dn[0], dn[1], *pad)
+    assert tuple(y.shape) == yo.shape
+    assert linf(y.cpu().numpy(), yo) <= 1e-5 * max(1.0, float(np.abs(yo).max()))
+    y64 = op.upfirdn2d(_t(x, torch.float64), _t(k), up[0], up[1], dn[0], dn[1], *pad)
+    assert linf(y64.cpu().numpy(), oracle.upfirdn2d(x.astype(np.float64), k, up[0], up[1], dn[0], dn[1], *pad)) <= 1e-12
+
+
+def test_upfirdn2d_half_precisions_and_errors():
+    from oracle import oracle
+    from havatar_amd.native import upfirdn2d as op
+    k1 = np.array([1., 3., 3., 1.], np.float32)
+    k = np.outer(k1, k1) / 64
+    for dt, tol in ((torch.float16, 2e-3), (torch.bfloat16, 1.5e-2)):
+        x = _t(synth.normal((4, 40, 72, 1), 13), dt)
+        y = op.upfirdn2d(x, _t(k), 1, 1, 2, 2, 1, 1, 1, 1)
+        yo = oracle.upfirdn2d(x.float().cpu().numpy(), k, 1, 1, 2, 2, 1, 1, 1, 1)
+        assert y.dtype == dt and linf(y.float().cpu().numpy(), yo) <= tol
+    with pytest.raises(RuntimeError):
+        op.upfirdn2d(_t(synth.normal((2, 4, 4, 1), 1)), _t(np.ones((9, 9), np.float32)), 1, 1, 1, 1, 0, 0, 0, 0)   # empty output
+    with pytest.raises(RuntimeError):
+        op.upfirdn2d(torch.zeros(2, 4, 4, 1), torch.ones(2, 2), 1, 1, 1, 1, 0, 0, 0, 0)     # CPU tensors
+
+
+def test_upfirdn2d_autograd_first_and_second_order():
+    from havatar_amd.model.op import upfirdn2d
+    k = _t(np.outer([1., 3., 3., 1.], [1., 3., 3., 1.]) / 16.0, torch.float64)
+    for up, dn, pad in ((1, 1, (2, 1)), (2, 1, (2, 1)), (1, 2, (1, 1))):
+        x = _t(synth.normal((1, 2, 6, 7), 14), torch.float64).requires_grad_(True)
+        f = lambda a: upfirdn2d(a, k, up=up, down=dn, pad=pad)
+        assert torch.autograd.gradcheck(f, (x,), eps=1e-6, atol=1e-7)
+        assert torch.autograd.gradgradcheck(f, (x,), eps=1e-6, atol=1e-7)
+
+
+def test_ops_full_size_properties():
+    """BASELINE config-4 sizes ([1,64,513,513] blur, [1,64,512,512] bias-act): size-independent properties.
+    upfirdn2d is linear and, for a normalised FIR with up=down=1 and enough padding, preserves the plane sum;
+    fused_bias_act(grad=1) applied to the forward output with unit gradients reproduces the gate."""
+    from havatar_amd.model.op import upfirdn2d, fused_leaky_relu
+    from havatar_amd.native import fused
+    k1 = torch.tensor([1., 3., 3., 1.], device=DEV)
+    k = k1[None] * k1[:, None]
+    k = k / k.sum()
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x = torch.randn(1, 64, 513, 513, device=DEV, generator=g)
+    z = torch.randn(1, 64, 513, 513, device=DEV, generator=g)
+    fx, fz = upfirdn2d(x, k, pad=(2, 1)), upfirdn2d(z, k, pad=(2, 1))
+    assert fx.shape == (1, 64, 513, 513)
+    lin = upfirdn2d(1.5 * x - 0.25 * z, k, pad=(2, 1))
+    assert (lin - (1.5 * fx - 0.25 * fz)).abs().max().item() <= 2e-5
+    full = upfirdn2d(x, k, pad=(3, 3))           # every input sample meets every tap -> sums agree
+    assert torch.allclose(full.double().sum((2, 3)), x.double().sum((2, 3)), rtol=0, atol=2e-2)
+    dn = upfirdn2d(x, k, down=2, pad=(1, 1))
+    assert dn.shape == (1, 64, 256, 256) and torch.equal(dn, upfirdn2d(x, k, pad=(1, 1))[:, :, ::2, ::2][:, :, :256, :256])
+    a = torch.randn(1, 64, 512, 512, device=DEV, generator=g)
+    b = torch.randn(64, device=DEV, generator=g)
+    y = fused_leaky_relu(a, b)
+    t = (a + b.view(1, -1, 1, 1))
+    assert torch.equal(y, torch.where(t > 0, t, t * 0.2) * S2)
+    gate = fused.fused_bias_act(torch.ones_like(a), a.new_empty(0), y, 3, 1, 0.2, S2)
+    assert torch.equal(gate, torch.where(t > 0, torch.full_like(t, S2), torch.full_like(t, 0.2 * S2)))
