@@ -578,9 +578,11 @@ __global__ void __launch_bounds__(MARCH_THREADS, 2) hav_march_f32_kernel(const M
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        float v = row16_sum(acc3[m][r] * wgt);
-                        if (same) v += __shfl_xor(v, 16, 64);
-                        if (writer) racc[3 + acc_row(m, r, h)] += v;
+                        // rows are always added in increasing row order, one at a time, so a ray's sums do not depend
+                        // on which slot of the pair (or which call) it was rendered in: results are bit-reproducible
+                        const float v = row16_sum(acc3[m][r] * wgt);
+                        const float vo = same ? __shfl_xor(v, 16, 64) : 0.f;
+                        if (writer) racc[3 + acc_row(m, r, h)] = (racc[3 + acc_row(m, r, h)] + v) + vo;
                     }
                 {
                     float e0, e1, e2, e3, e4;
@@ -590,14 +592,17 @@ __global__ void __launch_bounds__(MARCH_THREADS, 2) hav_march_f32_kernel(const M
                         e2 = 1.0f / (1.0f + expf(-acc3[2][2]));
                         e3 = z; e4 = 1.0f;
                     } else { e0 = e1 = e2 = e3 = e4 = 0.f; }
-                    float v0 = row16_sum(e0 * wgt), v1 = row16_sum(e1 * wgt), v2 = row16_sum(e2 * wgt);
-                    float v3 = row16_sum(e3 * wgt), v4 = row16_sum(e4 * wgt), v5 = row16_max(wgt);
+                    const float v0 = row16_sum(e0 * wgt), v1 = row16_sum(e1 * wgt), v2 = row16_sum(e2 * wgt);
+                    const float v3 = row16_sum(e3 * wgt), v4 = row16_sum(e4 * wgt);
+                    float v5 = row16_max(wgt);
+                    float u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f, u4 = 0.f;
                     if (same) {
-                        v0 += __shfl_xor(v0, 16, 64); v1 += __shfl_xor(v1, 16, 64); v2 += __shfl_xor(v2, 16, 64);
-                        v3 += __shfl_xor(v3, 16, 64); v4 += __shfl_xor(v4, 16, 64); v5 = fmaxf(v5, __shfl_xor(v5, 16, 64));
+                        u0 = __shfl_xor(v0, 16, 64); u1 = __shfl_xor(v1, 16, 64); u2 = __shfl_xor(v2, 16, 64);
+                        u3 = __shfl_xor(v3, 16, 64); u4 = __shfl_xor(v4, 16, 64); v5 = fmaxf(v5, __shfl_xor(v5, 16, 64));
                     }
                     if (writer && h == 0) {
-                        racc[0] += v0; racc[1] += v1; racc[2] += v2; racc[67] += v3; racc[68] += v4;
+                        racc[0] = (racc[0] + v0) + u0; racc[1] = (racc[1] + v1) + u1; racc[2] = (racc[2] + v2) + u2;
+                        racc[67] = (racc[67] + v3) + u3; racc[68] = (racc[68] + v4) + u4;
                         racc[69] = fmaxf(racc[69], v5);
                     }
                 }

@@ -125,6 +125,9 @@ def fused_bias_act(x, b, ref, act, grad, alpha, scale):
     ref = None if ref is None or ref.size == 0 else np.ascontiguousarray(ref, dt)
     step_b = int(np.prod(x.shape[2:])) if x.ndim > 2 else 1
     size_b = 0 if b is None else b.size
+    # the reference op takes `float alpha, float scale` and casts them to scalar_t inside the kernel
+    # (model/op/fused_bias_act_kernel.cu:67-70,98-101): also for float64 inputs they carry float32 precision
+    alpha, scale = float(np.float32(alpha)), float(np.float32(scale))
     if dt == np.float64:
         fn, ct = lib().orc_fused_bias_act_f64, C.c_double
     else:
