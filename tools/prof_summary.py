@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (kernel trace + PMC passes) into the text summary committed under profiles/."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+print("# rocprofv3 summary for", out)
+try:
+    print("# bench line:", open(os.path.join(out, "bench_line.json")).read().strip()[:2000])
+except OSError:
+    pass
+for f in glob.glob(os.path.join(out, "kt", "**", "*kernel_stats.csv"), recursive=True):
+    print("\n## kernel stats (", os.path.relpath(f, out), ")")
+    rows = list(csv.DictReader(open(f)))
+    for r in rows[:12]:
+        print("  %-70s calls=%-6s total_ns=%-14s avg_ns=%-12s pct=%s" % (r.get("Name", "")[:70], r.get("Calls"), r.get("TotalDurationNs"),
+                                                                      r.get("AverageNs"), r.get("Percentage")))
+for f in glob.glob(os.path.join(out, "kt", "**", "*kernel_trace.csv"), recursive=True):
+    rows = list(csv.DictReader(open(f)))
+    byk = defaultdict(list)
+    for r in rows:
+        byk[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r))
+    print("\n## kernel trace: per-kernel durations and resources")
+    for k, v in sorted(byk.items(), key=lambda kv: -sum(d for d, _ in kv[1]))[:8]:
+        d = sorted(x for x, _ in v)
+        r = v[0][1]
+        print("  %-60s n=%-4d med_us=%-10.1f min_us=%-10.1f VGPR=%s AGPR=%s SGPR=%s LDS=%s scratch=%s grid=%s wg=%s" % (
+            k[:60], len(d), d[len(d) // 2] / 1e3, d[0] / 1e3, r.get("VGPR_Count"), r.get("Accum_VGPR_Count"), r.get("SGPR_Count"),
+            r.get("LDS_Block_Size"), r.get("Scratch_Size"), r.get("Grid_Size"), r.get("Workgroup_Size")))
+print("\n## PMC (per-dispatch mean over the dispatches of each kernel)")
+for f in sorted(glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
+    rows = list(csv.DictReader(open(f)))
+    acc = defaultdict(lambda: defaultdict(list))
+    for r in rows:
+        acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, cs in acc.items():
+        if "march" not in k and "fba" not in k and "ufd" not in k:
+            continue
+        print("  %s" % k[:80])
+        for c, vals in sorted(cs.items()):
+            print("      %-32s mean=%.6g  (n=%d)" % (c, sum(vals) / len(vals), len(vals)))

@@ -1,0 +1,20 @@
+#!/bin/bash
+# rocprofv3 recipe (run on the GPU box through gpurun): kernel trace + stats, then separate PMC passes.
+# usage: tools/profile.sh <tag> [bench args...]   -> gpurun_out/prof_<tag>/...
+set -u
+cd /tmp && export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+TAG=${1:-run}; shift || true
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+BENCH="python bench.py --steps 8 --warmup 2 --no-cpu-baseline $*"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $BENCH > $OUT/bench_kt.log 2>&1
+tail -1 $OUT/bench_kt.log > $OUT/bench_line.json
+for pass in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" \
+            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU" \
+            "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
+  n=$(echo $pass | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/pmc_$n -o pmc -- $BENCH > $OUT/pmc_$n.log 2>&1
+done
+python tools/prof_summary.py $OUT > $OUT/summary.txt 2>&1
+cat $OUT/summary.txt
