@@ -60,8 +60,10 @@ def lib():
     L.hav_mlp_blob_bytes.restype = i64
     L.hav_mlp_pack.argtypes = [vp, C.POINTER(HavMlpWeights), vp]
     L.hav_mlp_pack.restype = i32
-    L.hav_triplane_to_channels_last.argtypes = [vp, vp, i32, i32, i32, i32, vp]
-    L.hav_triplane_to_channels_last.restype = i32
+    L.hav_triplane_prepare.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
+    L.hav_triplane_prepare.restype = i32
+    L.hav_triplane_prepared_bytes.argtypes = [i32, i32, i32]
+    L.hav_triplane_prepared_bytes.restype = i64
     L.hav_render_rays.argtypes = [C.POINTER(HavRenderParams)] + [vp] * 10 + [C.POINTER(HavRenderOut), vp]
     L.hav_render_rays.restype = i32
     L.hav_render_variant.argtypes = [C.POINTER(HavRenderParams)]

@@ -4,49 +4,62 @@
 // composited outputs touching HBM.
 //
 // Replaces Trainer.predict_and_render_radiance and its callees (reference file:line in include/havatar.h
-// and next to each step below).  Design notes (DESIGN.md has the long form):
+// and next to each step below).  Design (DESIGN.md has the long form and the measurements behind each choice):
 //
 //  * Work unit = a PAIR of rays per wave64.  A wave evaluates 32 samples per MLP pass ("tile"): lanes
-//    j = lane&31 are the samples, the two half-waves h = lane>>5 split each sample's 176 MLP inputs
-//    (plane h's 64 channels + PE octaves 4h..4h+3), its hidden units and its gather work.
+//    j = lane&31 are the samples, the two half-waves h = lane>>5 split each sample's hidden units, its tri-plane
+//    gather (64 of the 128 projected channels each), its PE octaves (4h..4h+3) and its two skinning bones.
 //    Rows of 16 lanes (= one DPP row) always belong to one ray, so the transmittance product is a
 //    DPP row scan + a scalar carry; 64 coarse samples = 4 rows, 48 fine samples = 3 rows, and the odd
 //    fine row of ray A shares a tile with the first row of ray B: no matrix-core slot is wasted.
-//  * MLP in "transposed" form  H^T[feature][sample] = W[feature][k] . X^T[k][sample]  on
-//    v_mfma_f32_32x32x2_f32 (exact fp32).  With this orientation the accumulator registers of layer
-//    l ARE the B operands of layer l+1 (lane holds column = its sample; register r of a 32-row tile
-//    holds rows (r&3)+8(r>>2)+4h, i.e. exactly the k-pair an MFMA step consumes from the two
-//    half-waves), so activations never leave registers and never cross lanes between layers.  Only the
-//    weights move: they are pre-permuted once into that k order ("fragment order", hav_mlp_pack) so
-//    every A operand is one conflict-free 256-byte ds_read_b32 / global_load_dword per wave.
-//  * fc_rgb o fc_rgbFeat has no activation in between (model/nerf_model.py:110-111), so the 3 rgb rows
-//    are folded into the head: one 128 -> {64 feat, 3 rgb, 1 alpha} layer.
-//  * Layer-1 weights (88 KB) are LDS-resident per workgroup; layer-2/head fragments stream from L2
-//    (coalesced, 8.75 B/clk/CU).  One persistent workgroup (8 waves) per CU; XCD-aware ray assignment
-//    keeps each XCD's L2 on one horizontal band of the image / tri-planes.
+//  * MLP in "transposed" form  H^T[unit][sample] = W[unit][k] . X^T[k][sample]  on v_mfma_f32_32x32x2_f32
+//    (exact fp32).  With this orientation the accumulator registers of layer l ARE the B operands of layer l+1
+//    (lane = its sample's column; register r of a 32-row tile holds rows (r&3)+8(r>>2)+4h, exactly the k-pair an MFMA
+//    step consumes from the two half-waves), so activations never leave registers and never cross lanes between
+//    layers.  Only weights move: pre-permuted once into that k order ("fragment order", hav_mlp_pack) so every A
+//    operand is one conflict-free 256-byte ds_read_b32 per wave.  ALL weights are LDS-resident (122 KB).
+//  * Measured on gfx950: v_mfma_f32_32x32x2_f32 does not overlap with VALU work -- neither from the same wave (each
+//    filler v_fma adds its ~2-4 cycles to the 64-cycle MFMA) nor from the other wave of the SIMD (a wave issuing
+//    back-to-back MFMAs starves its partner's VALU completely; tools/ubench).  Kernel time = MFMA cycles + VALU issue
+//    cycles, so the design minimises BOTH, algebraically:
+//      - Layer 1's 128 tri-plane columns are folded into the planes once per frame: bilinear interpolation is linear,
+//        W1f (sum_tap w_tap texel_tap) = sum_tap w_tap (W1f texel_tap).  hav_triplane_prepare projects every texel
+//        through W1f (a 128x64 GEMM over 32768 texels = 0.5 GFLOP per frame, vs 2.8 TFLOP for the march) into
+//        128-channel planes stored in accumulator order; the kernel then accumulates 8 taps straight into the layer-1
+//        accumulators (packed FMAs) and only the 48 PE columns go through the matrix cores: 96 MFMAs instead of 352.
+//      - fc_rgb o fc_rgbFeat has no activation in between (model/nerf_model.py:110-111): the 3 rgb rows fold into 3
+//        rows over the 128 hidden units; with alpha that is 4 dot products per sample on the VALU.
+//      - the 64 feature channels are LINEAR in h2 and only consumed through the compositing sum:
+//        sum_s w_s (Wf h2_s + bf) = Wf (sum_s w_s h2_s) + bf sum_s w_s.  The kernel composites the 128 hidden units
+//        (reduce-scatter over DPP rows) and applies fc_rgbFeat once per RAY.
+//    Per 32-sample tile that leaves 96 + 256 = 352 MFMAs instead of 736 for the literal network.
+//  * One persistent workgroup (8 waves, 2 per SIMD) per CU; XCD-aware ray assignment keeps each XCD's L2 on one
+//    horizontal band of the image / projected planes.
 #include "hav_common.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------------
-// packed weight blob (float offsets)
+// packed weight blob (float offsets).  [0, LDS_FLOATS) is copied verbatim into LDS by every workgroup.
 // ------------------------------------------------------------------------------------------------
 #define HAV_HID 128
 #define HAV_PC 64                      // channels per plane
 #define HAV_IN (2 * HAV_PC + 48)       // 176
-#define K1_STEPS (HAV_IN / 2)          // 88 MFMA k-steps in layer 1
+#define KPE_STEPS 24                   // MFMA k-steps of the PE part of layer 1 (48 columns)
 #define K2_STEPS (HAV_HID / 2)         // 64
-#define HEAD_TILES 3                   // 96 rows: 64 feat | 3 rgb | alpha | 28 zero rows
-#define OFF_W1 0
-#define OFF_W2 (OFF_W1 + K1_STEPS * 4 * 64)
-#define OFF_WH (OFF_W2 + K2_STEPS * 4 * 64)
-#define OFF_B1 (OFF_WH + K2_STEPS * HEAD_TILES * 64)
-#define OFF_B2 (OFF_B1 + 128)
-#define OFF_BH (OFF_B2 + 128)
-#define BLOB_FLOATS (OFF_BH + 32 * HEAD_TILES)
+#define OFF_W1PE 0                                  // [24][4][64]  layer-1 PE columns, fragment order
+#define OFF_W2 (OFF_W1PE + KPE_STEPS * 4 * 64)      // [64][4][64]  layer 2, fragment order
+#define OFF_W4 (OFF_W2 + K2_STEPS * 4 * 64)         // [64][2][4]   head rows rgb0 rgb1 rgb2 alpha per (k-step, half-wave)
+#define OFF_WFT (OFF_W4 + K2_STEPS * 2 * 4)         // [128][64]    fc_rgbFeat weight transposed
+#define LDS_FLOATS (OFF_WFT + HAV_HID * 64)         // 31232 floats = 122 KB
+#define OFF_B1 LDS_FLOATS                           // [128]
+#define OFF_B2 (OFF_B1 + 128)                       // [128]
+#define OFF_B4 (OFF_B2 + 128)                       // [4]  folded rgb biases, alpha bias
+#define OFF_BF (OFF_B4 + 4)                         // [64] fc_rgbFeat bias
+#define OFF_W1F (OFF_BF + 64)                       // [2][128][64] layer-1 plane columns per plane, rows in accumulator order
+#define BLOB_FLOATS (OFF_W1F + 2 * 128 * 64)
 
 extern "C" int64_t hav_mlp_blob_bytes(void) { return (int64_t)BLOB_FLOATS * 4; }
 
-// input column consumed by half-wave h at layer-1 k-step t
-__host__ __device__ inline int k1_col(int t, int h) { return t < HAV_PC ? 2 * t + h : 2 * HAV_PC + 24 * h + (t - HAV_PC); }
 // hidden unit held by half-wave h in accumulator register r of row-tile mp
 __host__ __device__ inline int acc_row(int mp, int r, int h) { return 32 * mp + (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -55,33 +68,40 @@ __global__ void __launch_bounds__(256) mlp_pack_kernel(float* __restrict__ blob,
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= BLOB_FLOATS) return;
     float v = 0.f;
-    if (e < OFF_W2) {
+    if (e < OFF_W2) {                   // PE column consumed by half-wave h at k-step t: 128 + 24h + t
         const int l = e & 63, m = (e >> 6) & 3, t = e >> 8;
-        v = w.W1[(32 * m + (l & 31)) * HAV_IN + k1_col(t, l >> 5)];
-    } else if (e < OFF_WH) {
+        v = w.W1[(32 * m + (l & 31)) * HAV_IN + 2 * HAV_PC + 24 * (l >> 5) + t];
+    } else if (e < OFF_W4) {
         const int q = e - OFF_W2;
         const int l = q & 63, m = (q >> 6) & 3, ks = q >> 8;
         v = w.W2[(32 * m + (l & 31)) * HAV_HID + acc_row(ks >> 4, ks & 15, l >> 5)];
-    } else if (e < OFF_B1) {
-        const int q = e - OFF_WH;
-        const int l = q & 63, m = (q >> 6) % HEAD_TILES, ks = (q >> 6) / HEAD_TILES;
-        const int row = 32 * m + (l & 31), col = acc_row(ks >> 4, ks & 15, l >> 5);
-        if (row < 64) v = w.Wf[row * HAV_HID + col];
-        else if (row < 67) {       // fc_rgb o fc_rgbFeat folded: (Wc Wf)[c][col]
+    } else if (e < OFF_WFT) {
+        const int q = e - OFF_W4;
+        const int c = q & 3, hh = (q >> 2) & 1, ks = q >> 3;
+        const int col = acc_row(ks >> 4, ks & 15, hh);
+        if (c < 3) {               // fc_rgb o fc_rgbFeat folded (no activation in between): (Wc Wf)[c][col]
             double s = 0.0;
-            for (int k = 0; k < 64; ++k) s += (double)w.Wc[(row - 64) * 64 + k] * (double)w.Wf[k * HAV_HID + col];
+            for (int k = 0; k < 64; ++k) s += (double)w.Wc[c * 64 + k] * (double)w.Wf[k * HAV_HID + col];
             v = (float)s;
-        } else if (row == 67) v = w.Wa[col];
+        } else v = w.Wa[col];
+    } else if (e < OFF_B1) {
+        const int q = e - OFF_WFT;
+        v = w.Wf[(q & 63) * HAV_HID + (q >> 6)];
     } else if (e < OFF_B2) v = w.b1[e - OFF_B1];
-    else if (e < OFF_BH) v = w.b2[e - OFF_B2];
-    else {
-        const int row = e - OFF_BH;
-        if (row < 64) v = w.bf[row];
-        else if (row < 67) {
-            double s = (double)w.bc[row - 64];
-            for (int k = 0; k < 64; ++k) s += (double)w.Wc[(row - 64) * 64 + k] * (double)w.bf[k];
+    else if (e < OFF_B4) v = w.b2[e - OFF_B2];
+    else if (e < OFF_BF) {
+        const int c = e - OFF_B4;
+        if (c < 3) {
+            double s = (double)w.bc[c];
+            for (int k = 0; k < 64; ++k) s += (double)w.Wc[c * 64 + k] * (double)w.bf[k];
             v = (float)s;
-        } else if (row == 67) v = w.ba[0];
+        } else v = w.ba[0];
+    } else if (e < OFF_W1F) v = w.bf[e - OFF_BF];
+    else {                              // W1F[p][hu][c] = W1[unit(hu)][2c + p]; hu = h*64 + (m*16 + r)
+        const int q = e - OFF_W1F;
+        const int c = q & 63, hu = (q >> 6) & 127, p = q >> 13;
+        const int u = hu & 63;
+        v = w.W1[acc_row(u >> 4, u & 15, hu >> 6) * HAV_IN + 2 * c + p];    // feature index = 2*channel + plane (nerf_model.py:99)
     }
     blob[e] = v;
 }
@@ -96,31 +116,63 @@ extern "C" int hav_mlp_pack(void* blob, const HavMlpWeights* w, void* stream)
 }
 
 // ------------------------------------------------------------------------------------------------
-// NCHW -> channels-last tri-plane: dst[(n*H*W + p)*C + c] = src[(n*C + c)*H*W + p]; LDS transpose tile
+// Per-frame plane preparation: P[p][b][texel][hu] = sum_c W1F[p][hu][c] * plane[p][b][c][texel]
+// (NCHW in, channels-last 128-wide out, channel order = accumulator order of the march kernel).
+// One workgroup = 64 texels x 128 outputs; plane tile, weights and the output tile go through LDS so that both the
+// NCHW reads and the channels-last writes are coalesced.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(float* __restrict__ dst, const float* __restrict__ src, int C,
-                                                           int HW)
+__global__ void __launch_bounds__(256) plane_project_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                            const float* __restrict__ blob, int HW)
 {
-    __shared__ float tile[64][65];
-    const int n = blockIdx.z, p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int i = ty; i < 64; i += 4) {
-        const int c = c0 + i, p = p0 + tx;
-        tile[i][tx] = (c < C && p < HW) ? src[((size_t)n * C + c) * HW + p] : 0.f;
-    }
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* sX = sm;                 // [64 c][64 texels]
+    float* sW = sm + 64 * 64;       // [128 hu][65]
+    float* sO = sW + 128 * 65;      // [64 texels][129]
+    const int pb = blockIdx.y;      // p * B + b
+    const int p = pb / (gridDim.y / 2);
+    const int t0 = blockIdx.x * 64;
+    const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+    const float* plane = src + (size_t)pb * HAV_PC * HW;
+    for (int c = ty; c < HAV_PC; c += 4) sX[c * 64 + tx] = (t0 + tx < HW) ? plane[(size_t)c * HW + t0 + tx] : 0.f;
+    const float* wsrc = blob + OFF_W1F + (size_t)p * 128 * 64;
+    for (int i = tid; i < 128 * 64; i += 256) sW[(i >> 6) * 65 + (i & 63)] = wsrc[i];
     __syncthreads();
-    for (int i = ty; i < 64; i += 4) {
-        const int p = p0 + i, c = c0 + tx;
-        if (c < C && p < HW) dst[((size_t)n * HW + p) * C + c] = tile[tx][i];
+    // thread: texel tx, 32 outputs hu = ty*32 .. +31 (weights broadcast across the wave, texel column conflict-free)
+    float acc[32];
+#pragma unroll
+    for (int o = 0; o < 32; ++o) acc[o] = 0.f;
+    for (int c = 0; c < HAV_PC; ++c) {
+        const float xv = sX[c * 64 + tx];
+#pragma unroll
+        for (int o = 0; o < 32; ++o) acc[o] = fmaf(sW[(ty * 32 + o) * 65 + c], xv, acc[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < 32; ++o) sO[tx * 129 + ty * 32 + o] = acc[o];
+    __syncthreads();
+    float* out = dst + ((size_t)pb * HW + t0) * 128;
+    for (int i = tid; i < 64 * 128; i += 256) {
+        const int t = i >> 7, hu = i & 127;
+        if (t0 + t < HW) out[(size_t)t * 128 + hu] = sO[t * 129 + hu];
     }
 }
 
-extern "C" int hav_triplane_to_channels_last(float* dst, const float* src, int B, int C, int H, int W, void* stream)
+extern "C" int64_t hav_triplane_prepared_bytes(int B, int H, int W) { return (int64_t)2 * B * H * W * 128 * 4; }
+
+extern "C" int hav_triplane_prepare(float* dst, const float* src_nchw, const void* mlp_blob, int B, int C, int H, int W,
+                                    void* stream)
 {
-    if (!dst || !src || B < 1 || C < 1 || H < 1 || W < 1) return HAV_EINVAL;
+    if (!dst || !src_nchw || !mlp_blob || B < 1 || H < 1 || W < 1) return HAV_EINVAL;
+    if (C != HAV_PC) return HAV_EUNSUP;
     const int HW = H * W;
-    dim3 grid((HW + 63) / 64, (C + 63) / 64, 2 * B);
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, dst, src, C, HW);
+    const size_t lds = (64 * 64 + 128 * 65 + 64 * 129) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)plane_project_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(plane_project_kernel, dim3((HW + 63) / 64, 2 * B), dim3(256), lds, (hipStream_t)stream, dst, src_nchw,
+                       (const float*)mlp_blob, HW);
     HAV_LAUNCH_CHECK();
     return 0;
 }
@@ -186,11 +238,14 @@ __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// sin for the positional encoding: branch-free Cody-Waite reduction by pi/2 (3 FMA terms) + degree-9/8 minimax
-// polynomials, max abs error 9.3e-8 (<= 1.6 ulp) for |x| <= 260, i.e. |p| <= 2 at the top octave 2^7 (the NeRF box is
-// +-1.6); accuracy degrades gracefully (not catastrophically) up to |x| ~ 1e5.  The libm-style sinf carries a
-// Payne-Hanek slow path whose control flow costs registers in a kernel that has none to spare.
-__device__ __forceinline__ float pe_sin(float x)
+// Positional encoding pair for one angle x = p * 2^k (model/network/embedder.py:42-56): the reference evaluates
+// sin(x) and sin(fl(x + pi/2)) in fp32.  One branch-free Cody-Waite reduction by pi/2 (3 FMA terms) + degree-9/8
+// minimax polynomials gives sin x and cos x (max abs error 9.3e-8 for |x| <= 260, i.e. |p| <= 2 at the top octave; the
+// box is +-1.6; accuracy degrades gracefully up to |x| ~ 1e5).  The reference's second value is NOT cos x: the fp32
+// rounding of x + pi/2 moves the angle by up to half an ulp of x (1e-5 at the top octave).  TwoSum recovers that
+// rounding error exactly, and sin(fl(x+pi/2)) = cos(x + eps) = cos x - eps sin x reproduces the reference's value to
+// 1.2e-7 (validated against float64 in DESIGN.md) while sharing the range reduction between the two outputs.
+__device__ __forceinline__ void pe_pair(float x, float& s_out, float& c_out)
 {
     const float n = rintf(x * 0.63661977236758134f);
     float r = fmaf(-n, 1.5707964f, x);
@@ -206,8 +261,16 @@ __device__ __forceinline__ float pe_sin(float x)
     q = fmaf(s, q, 0.0416666679084301f);
     const float cs = fmaf(s * s, q, fmaf(s, -0.5f, 1.0f));
     const int k = (int)n;
-    const float v = (k & 1) ? cs : sn;
-    return (k & 2) ? -v : v;
+    const float a = (k & 1) ? cs : sn, b = (k & 1) ? sn : cs;
+    const float sinx = (k & 2) ? -a : a;
+    const float cosx = ((k + 1) & 2) ? -b : b;
+    const float hp = 1.57079632679489661923f;
+    const float t = x + hp;                       // the reference's fp32 angle
+    const float bb = t - x;
+    const float err = (x - (t - bb)) + (hp - bb); // x + hp == t + err exactly (TwoSum)
+    const float eps = 4.371139e-08f - err;        // t == x + pi/2 + eps   (hp - pi/2 = +4.371139e-8)
+    s_out = sinx;
+    c_out = fmaf(-eps, sinx, cosx);
 }
 
 struct MarchArgs {
@@ -215,11 +278,13 @@ struct MarchArgs {
     const float* rays; const float* bg; const float* inv_T; const float* planes; const float* vol; const float* blob;
     const float* t_rand; const float* u_rand; const float* noise_c; const float* noise_f;
     HavRenderOut out;
+    int ablate;             // HAV_ABLATE bit mask (timing experiments only; results are wrong when set)
     float* dbg_zfine;       // optional [B*R, S_fp] dump of the merged fine depths (tests)
     long long NR;           // B*R
     int S_fp;               // ceil(S_c/2) + S_f, 0 if no fine pass
     int scr_floats;         // per-wave LDS scratch
     int o_w, o_cdf, o_cand, o_zf, o_racc, s_pad_c, s_pad_f;
+    const float* pplanes;   // projected tri-planes [2,B,H,W,128] (hav_triplane_prepare)
 };
 
 enum { STREAM_XI = 0, STREAM_ZETA = 1, STREAM_EPS_C = 2, STREAM_EPS_F = 3 };
@@ -266,7 +331,21 @@ __device__ __forceinline__ float z_coarse(const MarchArgs& a, long long gr, int 
 // ------------------------------------------------------------------------------------------------
 #define MARCH_THREADS 512
 #define MARCH_WAVES (MARCH_THREADS / 64)
-#define RACC_N 72   // 67 colour/feature sums | 67 depth | 68 acc | 69 wmax
+#define RACC_N 136  // 0..127 composited hidden units | 128..130 rgb | 131 depth | 132 acc | 133 wmax
+#define R_RGB 128
+#define R_DEPTH 131
+#define R_ACC 132
+#define R_WMAX 133
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// exchange with lane^4 inside a DPP row: banks {0,2} read from lane+4, banks {1,3} from lane-4
+__device__ __forceinline__ float dpp_xor4(float v)
+{
+    int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x104 /*row_shl:4*/, 0xf, 0x5, false);
+    r = __builtin_amdgcn_update_dpp(r, __float_as_int(v), 0x114 /*row_shr:4*/, 0xf, 0xA, false);
+    return __int_as_float(r);
+}
 
 // RANDOM=false: perturb == 0 and noise_std == 0 (deterministic rendering, the parity configuration); the random-number
 // paths (injected tensors or Philox) are compiled out.
@@ -274,30 +353,30 @@ template <bool RANDOM>
 __global__ void __launch_bounds__(MARCH_THREADS, 2) hav_march_f32_kernel(const MarchArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sW1 = smem;
+    const float* sW1 = smem + OFF_W1PE;
+    const float* sW2 = smem + OFF_W2;
+    const float4* sW4 = reinterpret_cast<const float4*>(smem + OFF_W4);
+    const float* sWFT = smem + OFF_WFT;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* scr = smem + K1_STEPS * 4 * 64 + wave * a.scr_floats;
+    float* scr = smem + LDS_FLOATS + wave * a.scr_floats;
     float* s_w = scr + a.o_w;       // [2][s_pad_c]  coarse weights
     float* s_cdf = scr + a.o_cdf;   // [2][s_pad_c]
     float* s_cand = scr + a.o_cand; // [2][s_pad_f]  unsorted fine depths
     float* s_zf = scr + a.o_zf;     // [2][s_pad_f]  sorted fine depths
     float* s_racc = scr + a.o_racc; // [2][RACC_N]
 
-    {   // stage the layer-1 fragments (already in fragment order) into LDS once per workgroup
-        const float4* src = reinterpret_cast<const float4*>(a.blob + OFF_W1);
-        float4* dst = reinterpret_cast<float4*>(sW1);
-        for (int i = tid; i < K1_STEPS * 4 * 64 / 4; i += MARCH_THREADS) dst[i] = src[i];
+    {   // every weight the tile loop touches becomes LDS-resident (fragment order, straight copy)
+        const float4* src = reinterpret_cast<const float4*>(a.blob);
+        float4* dst = reinterpret_cast<float4*>(smem);
+        for (int i = tid; i < LDS_FLOATS / 4; i += MARCH_THREADS) dst[i] = src[i];
     }
     __syncthreads();
 
     const int j = lane & 31, h = lane >> 5, col = lane & 15, rowt = (lane >> 4) & 1;
-    // streamed weights/biases go through ONE buffer descriptor: per-load address = SGPR constant + lane*4, so the
-    // compiler has no 64-bit per-load pointers to hoist out of the loops (it spilled ~900 of them otherwise)
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.blob), 0, BLOB_FLOATS * 4, 0x00020000);
-    const int voff = lane * 4, hoff = h * 16;
-#define LDW(off_floats) __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrs, voff, (off_floats) * 4, 0))
+    const int hoff = h * 16;
 #define LDB4(off_floats) __builtin_amdgcn_raw_buffer_load_b128(wrs, hoff, (off_floats) * 4, 0)
 
     const int S_c = a.p.S_c, S_fp = a.S_fp;
@@ -359,19 +438,18 @@ __global__ void __launch_bounds__(MARCH_THREADS, 2) hav_march_f32_kernel(const M
                 }
                 const float dist = (s + 1 < S) ? (znb - z) : (z - znb);
 
-                // ---- pts = o + d z; skinning field (model/Skinning_Field.py:77-95) -----------------------
+                // ---- pts = o + d z; skinning field (model/Skinning_Field.py:77-95): half-wave h evaluates bone h ---------
                 const float px = ox + dx * z, py = oy + dy * z, pz = oz + dz * z;
                 const float* iT = a.inv_T + (size_t)b * 12;
                 const float tx_ = px + iT[9], ty_ = py + iT[10], tz_ = pz + iT[11];
                 const float p1x = tx_ * iT[0] + ty_ * iT[3] + tz_ * iT[6];
                 const float p1y = tx_ * iT[1] + ty_ * iT[4] + tz_ * iT[7];
                 const float p1z = tx_ * iT[2] + ty_ * iT[5] + tz_ * iT[8];
-                float wsk[2];
-#pragma unroll
-                for (int bone = 0; bone < 2; ++bone) {
-                    const float gx = (bone ? p1x : px) * a.p.skin_scale[0] + a.p.skin_trans[0];
-                    const float gy = (bone ? p1y : py) * a.p.skin_scale[1] + a.p.skin_trans[1];
-                    const float gz = (bone ? p1z : pz) * a.p.skin_scale[2] + a.p.skin_trans[2];
+                float wmine;
+                {
+                    const float gx = (h ? p1x : px) * a.p.skin_scale[0] + a.p.skin_trans[0];
+                    const float gy = (h ? p1y : py) * a.p.skin_scale[1] + a.p.skin_trans[1];
+                    const float gz = (h ? p1z : pz) * a.p.skin_scale[2] + a.p.skin_trans[2];
                     // grid_sample 3-D, border padding, align_corners=True (utils/util.py:409-418)
                     const float lim = (float)(VR - 1);
                     float ix = ((gx + 1.0f) * 0.5f) * lim, iy = ((gy + 1.0f) * 0.5f) * lim, iz = ((gz + 1.0f) * 0.5f) * lim;
@@ -380,7 +458,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, 2) hav_march_f32_kernel(const M
                     const float fx = ix - x0f, fy = iy - y0f, fz = iz - z0f;
                     const int x0 = (int)x0f, y0 = (int)y0f, z0 = (int)z0f;
                     const int x1 = min(x0 + 1, VR - 1), y1 = min(y0 + 1, VR - 1), z1 = min(z0 + 1, VR - 1);  // weight is 0 when clamped
-                    const float* v = a.vol + (size_t)bone * VR * VR * VR;
+                    const float* v = a.vol + (size_t)h * VR * VR * VR;
                     float acc = 0.f;
 #pragma unroll
                     for (int cz = 0; cz < 2; ++cz)
@@ -391,68 +469,15 @@ __global__ void __launch_bounds__(MARCH_THREADS, 2) hav_march_f32_kernel(const M
                                 const float wgt = (cx ? fx : 1.0f - fx) * (cy ? fy : 1.0f - fy) * (cz ? fz : 1.0f - fz);
                                 acc += v[((size_t)(cz ? z1 : z0) * VR + (cy ? y1 : y0)) * VR + (cx ? x1 : x0)] * wgt;
                             }
-                    wsk[bone] = acc;
+                    wmine = acc;
                 }
-                const float den = (wsk[0] + wsk[1]) + 1e-8f;
-                const float n0 = wsk[0] / den, n1 = wsk[1] / den;
+                const float wother = __shfl_xor(wmine, 32, 64);
+                const float w0 = h ? wother : wmine, w1 = h ? wmine : wother;
+                const float den = (w0 + w1) + 1e-8f;
+                const float n0 = w0 / den, n1 = w1 / den;
                 const float qx_ = n0 * px + n1 * p1x, qy_ = n0 * py + n1 * p1y, qz_ = n0 * pz + n1 * p1z;   // p'
 
-                __builtin_amdgcn_sched_barrier(0);
-                // ---- MLP inputs of this half-wave: plane h (64 ch) + PE octaves 4h..4h+3 (24) ----------
-                float x[K1_STEPS];
-                {
-                    // Embedder.embed (model/network/embedder.py:32-61): sin(p f), sin(p f + pi/2), f = 2^k
-                    const float halfpi = 1.57079632679489661923f;
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        const float f = h ? (float)(16 << kk) : (float)(1 << kk);
-                        const float ax = qx_ * f, ay = qy_ * f, az = qz_ * f;
-                        x[HAV_PC + 6 * kk + 0] = pe_sin(ax);
-                        x[HAV_PC + 6 * kk + 1] = pe_sin(ay);
-                        x[HAV_PC + 6 * kk + 2] = pe_sin(az);
-                        x[HAV_PC + 6 * kk + 3] = pe_sin(ax + halfpi);
-                        x[HAV_PC + 6 * kk + 4] = pe_sin(ay + halfpi);
-                        x[HAV_PC + 6 * kk + 5] = pe_sin(az + halfpi);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    // sample_from_triplane_new (utils/util.py:359-392): plane0 at (x,y), plane1 at (z,y); zeros padding
-                    const float gx = (h ? qz_ * a.p.nerf_scale[2] + a.p.nerf_trans[2] : qx_ * a.p.nerf_scale[0] + a.p.nerf_trans[0]);
-                    const float gy = qy_ * a.p.nerf_scale[1] + a.p.nerf_trans[1];
-                    const float lim = (float)(PR - 1);
-                    const float ix = ((gx + 1.0f) * 0.5f) * lim, iy = ((gy + 1.0f) * 0.5f) * lim;
-                    float x0f = floorf(ix), y0f = floorf(iy);
-                    const float wx1 = ix - x0f, wx0 = 1.0f - wx1, wy1 = iy - y0f, wy0 = 1.0f - wy1;
-                    x0f = fminf(fmaxf(x0f, -2.f), lim + 2.f); y0f = fminf(fmaxf(y0f, -2.f), lim + 2.f);
-                    const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
-                    const bool vx0 = x0 >= 0 && x0 < PR, vx1 = x1 >= 0 && x1 < PR, vy0 = y0 >= 0 && y0 < PR, vy1 = y1 >= 0 && y1 < PR;
-                    const float w00 = (vx0 && vy0) ? wx0 * wy0 : 0.f, w01 = (vx1 && vy0) ? wx1 * wy0 : 0.f;
-                    const float w10 = (vx0 && vy1) ? wx0 * wy1 : 0.f, w11 = (vx1 && vy1) ? wx1 * wy1 : 0.f;
-                    const int cx0 = min(max(x0, 0), PR - 1), cx1 = min(max(x1, 0), PR - 1);
-                    const int cy0 = min(max(y0, 0), PR - 1), cy1 = min(max(y1, 0), PR - 1);
-                    const float* pl = a.planes + ((size_t)h * a.p.B + b) * PR * PR * HAV_PC;
-                    const float4* t00 = reinterpret_cast<const float4*>(pl + ((size_t)cy0 * PR + cx0) * HAV_PC);
-                    const float4* t01 = reinterpret_cast<const float4*>(pl + ((size_t)cy0 * PR + cx1) * HAV_PC);
-                    const float4* t10 = reinterpret_cast<const float4*>(pl + ((size_t)cy1 * PR + cx0) * HAV_PC);
-                    const float4* t11 = reinterpret_cast<const float4*>(pl + ((size_t)cy1 * PR + cx1) * HAV_PC);
-                    // 4 x 256 B per lane; issued 16 loads (4 channel quads x 4 taps) at a time to bound live registers
-#pragma unroll
-                    for (int cg = 0; cg < HAV_PC / 16; ++cg) {
-                        float4 v00[4], v01[4], v10[4], v11[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) { v00[u] = t00[4 * cg + u]; v01[u] = t01[4 * cg + u]; v10[u] = t10[4 * cg + u]; v11[u] = t11[4 * cg + u]; }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int c4 = 4 * cg + u;
-                            x[4 * c4 + 0] = v00[u].x * w00 + v01[u].x * w01 + v10[u].x * w10 + v11[u].x * w11;
-                            x[4 * c4 + 1] = v00[u].y * w00 + v01[u].y * w01 + v10[u].y * w10 + v11[u].y * w11;
-                            x[4 * c4 + 2] = v00[u].z * w00 + v01[u].z * w01 + v10[u].z * w10 + v11[u].z * w11;
-                            x[4 * c4 + 3] = v00[u].w * w00 + v01[u].w * w01 + v10[u].w * w10 + v11[u].w * w11;
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-
-                // ---- layer 1: 176 -> 128, relu (model/nerf_model.py:104-108) ---------------------------
+                // ---- layer 1 (model/nerf_model.py:104-108): bias + 8 projected tri-plane taps + PE columns on the MFMA ----
                 f32x16 acc1[4];
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
@@ -462,12 +487,78 @@ __global__ void __launch_bounds__(MARCH_THREADS, 2) hav_march_f32_kernel(const M
                         acc1[m][4 * q + 0] = __uint_as_float(bb[0]); acc1[m][4 * q + 1] = __uint_as_float(bb[1]);
                         acc1[m][4 * q + 2] = __uint_as_float(bb[2]); acc1[m][4 * q + 3] = __uint_as_float(bb[3]);
                     }
-                __builtin_amdgcn_sched_barrier(0);
+                if (!(a.ablate & 1)) {
+                    // sample_from_triplane_new (utils/util.py:359-392): plane0 at (x,y), plane1 at (z,y); zeros padding.
+                    // Each texel of the prepared planes already carries W1f . texel for this half-wave's 64 hidden units.
+                    const float lim = (float)(PR - 1);
+                    const float gy = qy_ * a.p.nerf_scale[1] + a.p.nerf_trans[1];
+                    const float iy = ((gy + 1.0f) * 0.5f) * lim;
+                    float y0f = floorf(iy);
+                    const float wy1 = iy - y0f, wy0 = 1.0f - wy1;
+                    y0f = fminf(fmaxf(y0f, -2.f), lim + 2.f);
+                    const int y0 = (int)y0f, y1 = y0 + 1;
+                    const bool vy0 = y0 >= 0 && y0 < PR, vy1 = y1 >= 0 && y1 < PR;
+                    const int cy0 = min(max(y0, 0), PR - 1), cy1 = min(max(y1, 0), PR - 1);
+                    float tw[8];
+                    const float4* tp[8];
 #pragma unroll
-                for (int t = 0; t < K1_STEPS; ++t) {
+                    for (int pl = 0; pl < 2; ++pl) {
+                        const float gx = pl ? qz_ * a.p.nerf_scale[2] + a.p.nerf_trans[2] : qx_ * a.p.nerf_scale[0] + a.p.nerf_trans[0];
+                        const float ix = ((gx + 1.0f) * 0.5f) * lim;
+                        float x0f = floorf(ix);
+                        const float wx1 = ix - x0f, wx0 = 1.0f - wx1;
+                        x0f = fminf(fmaxf(x0f, -2.f), lim + 2.f);
+                        const int x0 = (int)x0f, x1 = x0 + 1;
+                        const bool vx0 = x0 >= 0 && x0 < PR, vx1 = x1 >= 0 && x1 < PR;
+                        const int cx0 = min(max(x0, 0), PR - 1), cx1 = min(max(x1, 0), PR - 1);
+                        tw[4 * pl + 0] = (vx0 && vy0) ? wx0 * wy0 : 0.f; tw[4 * pl + 1] = (vx1 && vy0) ? wx1 * wy0 : 0.f;
+                        tw[4 * pl + 2] = (vx0 && vy1) ? wx0 * wy1 : 0.f; tw[4 * pl + 3] = (vx1 && vy1) ? wx1 * wy1 : 0.f;
+                        const float* plb = a.pplanes + ((size_t)pl * a.p.B + b) * PR * PR * 128 + h * 64;
+                        tp[4 * pl + 0] = reinterpret_cast<const float4*>(plb + ((size_t)cy0 * PR + cx0) * 128);
+                        tp[4 * pl + 1] = reinterpret_cast<const float4*>(plb + ((size_t)cy0 * PR + cx1) * 128);
+                        tp[4 * pl + 2] = reinterpret_cast<const float4*>(plb + ((size_t)cy1 * PR + cx0) * 128);
+                        tp[4 * pl + 3] = reinterpret_cast<const float4*>(plb + ((size_t)cy1 * PR + cx1) * 128);
+                    }
+                    // 8 taps x 256 B per lane, two taps (32 x 16 B) in flight.  The empty asm pins each tap's FMAs before the
+                    // loads that recycle its registers: left alone, the compiler hoists all 128 loads and spills them.
+                    float4 tv[2][16];
+#pragma unroll
+                    for (int c4 = 0; c4 < 16; ++c4) { tv[0][c4] = tp[0][c4]; tv[1][c4] = tp[1][c4]; }
+#pragma unroll
+                    for (int tap = 0; tap < 8; ++tap) {
+                        const float wt = tw[tap];
+#pragma unroll
+                        for (int c4 = 0; c4 < 16; ++c4) {     // slot u = 4*c4+e  <->  accumulator (m = u>>4, r = u&15)
+                            const float4 t4 = tv[tap & 1][c4];
+                            acc1[c4 >> 2][4 * (c4 & 3) + 0] = fmaf(t4.x, wt, acc1[c4 >> 2][4 * (c4 & 3) + 0]);
+                            acc1[c4 >> 2][4 * (c4 & 3) + 1] = fmaf(t4.y, wt, acc1[c4 >> 2][4 * (c4 & 3) + 1]);
+                            acc1[c4 >> 2][4 * (c4 & 3) + 2] = fmaf(t4.z, wt, acc1[c4 >> 2][4 * (c4 & 3) + 2]);
+                            acc1[c4 >> 2][4 * (c4 & 3) + 3] = fmaf(t4.w, wt, acc1[c4 >> 2][4 * (c4 & 3) + 3]);
+                        }
+                        asm volatile("" : "+v"(acc1[0]), "+v"(acc1[1]), "+v"(acc1[2]), "+v"(acc1[3]) : : "memory");
+                        if (tap + 2 < 8) {
+#pragma unroll
+                            for (int c4 = 0; c4 < 16; ++c4) tv[tap & 1][c4] = tp[tap + 2][c4];
+                        }
+                    }
+                }
+                // ---- PE octaves 4h..4h+3 of this half-wave (model/network/embedder.py:32-61) ---------------------
+                float pe[KPE_STEPS];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const float f = h ? (float)(16 << kk) : (float)(1 << kk);
+                    pe_pair(qx_ * f, pe[6 * kk + 0], pe[6 * kk + 3]);
+                    pe_pair(qy_ * f, pe[6 * kk + 1], pe[6 * kk + 4]);
+                    pe_pair(qz_ * f, pe[6 * kk + 2], pe[6 * kk + 5]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+
+                if (!(a.ablate & 16))
+#pragma unroll
+                for (int t = 0; t < KPE_STEPS; ++t) {
 #pragma unroll
                     for (int m = 0; m < 4; ++m)
-                        acc1[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(sW1[(t * 4 + m) * 64 + lane], x[t], acc1[m], 0, 0, 0);
+                        acc1[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(sW1[(t * 4 + m) * 64 + lane], pe[t], acc1[m], 0, 0, 0);
                     if ((t & 7) == 7) __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
@@ -476,7 +567,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, 2) hav_march_f32_kernel(const M
                     for (int r = 0; r < 16; ++r) acc1[m][r] = fmaxf(acc1[m][r], 0.f);
 
                 __builtin_amdgcn_sched_barrier(0);
-                // ---- layer 2: 128 -> 128, relu; B operands are layer-1 accumulator registers ----------
+                // ---- layer 2: 128 -> 128, relu; B operands are layer-1 accumulator registers, A fragments from LDS ------
                 f32x16 acc2[4];
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
@@ -486,26 +577,13 @@ __global__ void __launch_bounds__(MARCH_THREADS, 2) hav_march_f32_kernel(const M
                         acc2[m][4 * q + 0] = __uint_as_float(bb[0]); acc2[m][4 * q + 1] = __uint_as_float(bb[1]);
                         acc2[m][4 * q + 2] = __uint_as_float(bb[2]); acc2[m][4 * q + 3] = __uint_as_float(bb[3]);
                     }
-                {   // weights stream from L2: 4 k-steps (16 fragments) are in flight while the previous 16 MFMAs run
-                    float af[2][16];
+                if (!(a.ablate & 32))
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) af[0][u] = LDW(OFF_W2 + u * 64);
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int ks = 0; ks < K2_STEPS; ++ks) {
 #pragma unroll
-                    for (int g = 0; g < 16; ++g) {
-                        if (g + 1 < 16) {
-#pragma unroll
-                            for (int u = 0; u < 16; ++u) af[(g + 1) & 1][u] = LDW(OFF_W2 + ((g + 1) * 16 + u) * 64);
-                        }
-#pragma unroll
-                        for (int kq = 0; kq < 4; ++kq) {
-                            const int ks = g * 4 + kq;
-#pragma unroll
-                            for (int m = 0; m < 4; ++m)
-                                acc2[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][kq * 4 + m], acc1[ks >> 4][ks & 15], acc2[m], 0, 0, 0);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
+                    for (int m = 0; m < 4; ++m)
+                        acc2[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(sW2[(ks * 4 + m) * 64 + lane], acc1[ks >> 4][ks & 15], acc2[m], 0, 0, 0);
+                    if ((ks & 7) == 7) __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
@@ -513,43 +591,27 @@ __global__ void __launch_bounds__(MARCH_THREADS, 2) hav_march_f32_kernel(const M
                     for (int r = 0; r < 16; ++r) acc2[m][r] = fmaxf(acc2[m][r], 0.f);
 
                 __builtin_amdgcn_sched_barrier(0);
-                // ---- head: 128 -> 64 feat | 3 rgb (folded fc_rgb o fc_rgbFeat) | alpha ---------------------
-                f32x16 acc3[HEAD_TILES];
+                // ---- head rows rgb(3, folded fc_rgb o fc_rgbFeat) + alpha: 4 dot products over the 128 hidden units.
+                // Each lane holds 64 of its sample's hidden units; the 4 weights per unit are one broadcast ds_read_b128.
+                float hd0 = 0.f, hd1 = 0.f, hd2 = 0.f, hd3 = 0.f;
 #pragma unroll
-                for (int m = 0; m < HEAD_TILES; ++m)
+                for (int mp = 0; mp < 4; ++mp)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const auto bb = LDB4(OFF_BH + 32 * m + 8 * q);
-                        acc3[m][4 * q + 0] = __uint_as_float(bb[0]); acc3[m][4 * q + 1] = __uint_as_float(bb[1]);
-                        acc3[m][4 * q + 2] = __uint_as_float(bb[2]); acc3[m][4 * q + 3] = __uint_as_float(bb[3]);
+                    for (int r = 0; r < 16; ++r) {
+                        const float4 w4 = sW4[(mp * 16 + r) * 2 + h];
+                        const float v = acc2[mp][r];
+                        hd0 = fmaf(v, w4.x, hd0); hd1 = fmaf(v, w4.y, hd1); hd2 = fmaf(v, w4.z, hd2); hd3 = fmaf(v, w4.w, hd3);
                     }
+                hd0 += __shfl_xor(hd0, 32, 64); hd1 += __shfl_xor(hd1, 32, 64);
+                hd2 += __shfl_xor(hd2, 32, 64); hd3 += __shfl_xor(hd3, 32, 64);
                 {
-                    float af[2][4 * HEAD_TILES];
-#pragma unroll
-                    for (int u = 0; u < 4 * HEAD_TILES; ++u) af[0][u] = LDW(OFF_WH + u * 64);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int g = 0; g < 16; ++g) {
-                        if (g + 1 < 16) {
-#pragma unroll
-                            for (int u = 0; u < 4 * HEAD_TILES; ++u) af[(g + 1) & 1][u] = LDW(OFF_WH + ((g + 1) * 4 * HEAD_TILES + u) * 64);
-                        }
-#pragma unroll
-                        for (int kq = 0; kq < 4; ++kq) {
-                            const int ks = g * 4 + kq;
-#pragma unroll
-                            for (int m = 0; m < HEAD_TILES; ++m)
-                                acc3[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][kq * HEAD_TILES + m], acc2[ks >> 4][ks & 15], acc3[m], 0, 0, 0);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
+                    const auto b4 = __builtin_amdgcn_raw_buffer_load_b128(wrs, 0, OFF_B4 * 4, 0);
+                    hd0 += __uint_as_float(b4[0]); hd1 += __uint_as_float(b4[1]); hd2 += __uint_as_float(b4[2]); hd3 += __uint_as_float(b4[3]);
                 }
 
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- volume_render_radiance_field (utils/nerf_util.py:28-73) -------------------------------
-                // rows 64..67 of the head (rgb, alpha) live in half-wave 0, registers 0..3 of tile 2
-                const float sig_raw = __shfl(acc3[2][3], j, 64);
-                float sg = sig_raw;
+                float sg = hd3;
                 if (RANDOM && a.p.noise_std > 0.f) {
                     const float* nz = pass == 0 ? a.noise_c : a.noise_f;
                     const float e = nz ? nz[gr * S + s] : rng_normal(a, gr, s, pass == 0 ? STREAM_EPS_C : STREAM_EPS_F);
@@ -570,26 +632,46 @@ __global__ void __launch_bounds__(MARCH_THREADS, 2) hav_march_f32_kernel(const M
                 const float wgt = alpha * ((rowt ? cin1 : cin0) * pex);         // :60
                 if (pass == 0 && h == 0 && valid) s_w[slot * a.s_pad_c + s] = wgt;
 
-                // weighted sums: reduce over the 16 lanes of each row, then add into the per-ray LDS accumulators
+                // ---- weighted sums over the samples of each row: reduce-scatter across the 16 lanes of the DPP row.
+                // 64 products per lane -> 4 per lane after xor-8/4/2/1 exchanges; lane `col` ends up with hidden units
+                // [4*(2*col + h) .. +3] (64*b3 + 32*b2 + 16*b1 + 8*b0 + 4h), i.e. one aligned float4 of the LDS accumulator.
                 const bool same = (2 * tile) / nr == (2 * tile + 1) / nr;    // both rows of this tile belong to one ray
                 float* racc = s_racc + slot * RACC_N;
-                const bool writer = (col == 0) && (!same || rowt == 0);
+                if (!(a.ablate & 8)) {
+                    const bool b3 = (col & 8) != 0, b2 = (col & 4) != 0, b1 = (col & 2) != 0, b0 = (col & 1) != 0;
+                    float v1[32];
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        // rows are always added in increasing row order, one at a time, so a ray's sums do not depend
-                        // on which slot of the pair (or which call) it was rendered in: results are bit-reproducible
-                        const float v = row16_sum(acc3[m][r] * wgt);
-                        const float vo = same ? __shfl_xor(v, 16, 64) : 0.f;
-                        if (writer) racc[3 + acc_row(m, r, h)] = (racc[3 + acc_row(m, r, h)] + v) + vo;
+                    for (int i = 0; i < 32; ++i) {
+                        const float lo = acc2[i >> 4][i & 15] * wgt, hi = acc2[(i + 32) >> 4][i & 15] * wgt;
+                        v1[i] = (b3 ? hi : lo) + dpp_mov<0x128 /*row_ror:8*/>(0.f, b3 ? lo : hi);
                     }
+                    float v2[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) v2[i] = (b2 ? v1[i + 16] : v1[i]) + dpp_xor4(b2 ? v1[i] : v1[i + 16]);
+                    float v3[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v3[i] = (b1 ? v2[i + 8] : v2[i]) + dpp_mov<DPP_QUAD_XOR2>(0.f, b1 ? v2[i] : v2[i + 8]);
+                    float v4[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v4[i] = (b0 ? v3[i + 4] : v3[i]) + dpp_mov<DPP_QUAD_XOR1>(0.f, b0 ? v3[i] : v3[i + 4]);
+                    // rows are always added in increasing row order, one at a time, so a ray's sums do not depend on which
+                    // slot of the pair (or which call) it was rendered in: results are bit-reproducible
+                    float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+                    if (same) { o0 = __shfl_xor(v4[0], 16, 64); o1 = __shfl_xor(v4[1], 16, 64); o2 = __shfl_xor(v4[2], 16, 64); o3 = __shfl_xor(v4[3], 16, 64); }
+                    if (!same || rowt == 0) {
+                        float4* dst = reinterpret_cast<float4*>(racc + 8 * col + 4 * h);
+                        float4 cur = *dst;
+                        cur.x = (cur.x + v4[0]) + o0; cur.y = (cur.y + v4[1]) + o1; cur.z = (cur.z + v4[2]) + o2; cur.w = (cur.w + v4[3]) + o3;
+                        *dst = cur;
+                    }
+                }
                 {
+                    const bool writer = (col == 0) && (!same || rowt == 0);
                     float e0, e1, e2, e3, e4;
                     if (h == 0) {
-                        e0 = 1.0f / (1.0f + expf(-acc3[2][0]));              // sigmoid on rgb only (:45-46)
-                        e1 = 1.0f / (1.0f + expf(-acc3[2][1]));
-                        e2 = 1.0f / (1.0f + expf(-acc3[2][2]));
+                        e0 = 1.0f / (1.0f + expf(-hd0));              // sigmoid on rgb only (:45-46)
+                        e1 = 1.0f / (1.0f + expf(-hd1));
+                        e2 = 1.0f / (1.0f + expf(-hd2));
                         e3 = z; e4 = 1.0f;
                     } else { e0 = e1 = e2 = e3 = e4 = 0.f; }
                     const float v0 = row16_sum(e0 * wgt), v1 = row16_sum(e1 * wgt), v2 = row16_sum(e2 * wgt);
@@ -601,34 +683,50 @@ __global__ void __launch_bounds__(MARCH_THREADS, 2) hav_march_f32_kernel(const M
                         u3 = __shfl_xor(v3, 16, 64); u4 = __shfl_xor(v4, 16, 64); v5 = fmaxf(v5, __shfl_xor(v5, 16, 64));
                     }
                     if (writer && h == 0) {
-                        racc[0] = (racc[0] + v0) + u0; racc[1] = (racc[1] + v1) + u1; racc[2] = (racc[2] + v2) + u2;
-                        racc[67] = (racc[67] + v3) + u3; racc[68] = (racc[68] + v4) + u4;
-                        racc[69] = fmaxf(racc[69], v5);
+                        racc[R_RGB + 0] = (racc[R_RGB + 0] + v0) + u0; racc[R_RGB + 1] = (racc[R_RGB + 1] + v1) + u1;
+                        racc[R_RGB + 2] = (racc[R_RGB + 2] + v2) + u2;
+                        racc[R_DEPTH] = (racc[R_DEPTH] + v3) + u3; racc[R_ACC] = (racc[R_ACC] + v4) + u4;
+                        racc[R_WMAX] = fmaxf(racc[R_WMAX], v5);
                     }
                 }
                 wave_lds_sync();
             }   // tiles
 
-            // ---- write this pass's outputs ----------------------------------------------------------
-            for (int slot = 0; slot < (has1 ? 2 : 1); ++slot) {
-                const long long gr = ray0 + slot;
-                const float* racc = s_racc + slot * RACC_N;
-                const float accv = racc[68];
-                float* rgb = (pass == 0 ? a.out.rgb_coarse : a.out.rgb_fine) + gr * 67;
-                for (int i = lane; i < 67; i += 64) {
-                    float v = racc[i];
-                    if (i < 3 && a.bg) v = v + (1.0f - accv) * a.bg[gr * 3 + i];     // :70-71
-                    rgb[i] = v;
+            // ---- write this pass's outputs: rgb | fc_rgbFeat applied ONCE per ray to the composited hidden units ----
+            {
+                const float* ra = s_racc;
+                const float* rb = s_racc + RACC_N;
+                const float bfv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrs, lane * 4, OFF_BF * 4, 0));
+                float ga = bfv * ra[R_ACC], gb = bfv * rb[R_ACC];         // lane f: bf[f] * sum_s w_s
+#pragma unroll 4
+                for (int k4 = 0; k4 < HAV_HID / 4; ++k4) {
+                    const float4 ha = *reinterpret_cast<const float4*>(ra + 4 * k4), hb = *reinterpret_cast<const float4*>(rb + 4 * k4);
+                    const float wq0 = sWFT[(4 * k4 + 0) * 64 + lane], wq1 = sWFT[(4 * k4 + 1) * 64 + lane];
+                    const float wq2 = sWFT[(4 * k4 + 2) * 64 + lane], wq3 = sWFT[(4 * k4 + 3) * 64 + lane];
+                    ga = fmaf(wq0, ha.x, ga); ga = fmaf(wq1, ha.y, ga); ga = fmaf(wq2, ha.z, ga); ga = fmaf(wq3, ha.w, ga);
+                    gb = fmaf(wq0, hb.x, gb); gb = fmaf(wq1, hb.y, gb); gb = fmaf(wq2, hb.z, gb); gb = fmaf(wq3, hb.w, gb);
                 }
-                if (lane == 0) {
-                    (pass == 0 ? a.out.depth_coarse : a.out.depth_fine)[gr] = racc[67];
-                    (pass == 0 ? a.out.acc_coarse : a.out.acc_fine)[gr] = accv;
-                    if (pass == 1 || S_fp == 0) a.out.weights_max[gr] = racc[69];    // model/nerf_trainer.py:195,200
+                for (int slot = 0; slot < (has1 ? 2 : 1); ++slot) {
+                    const long long gr = ray0 + slot;
+                    const float* racc = s_racc + slot * RACC_N;
+                    const float accv = racc[R_ACC];
+                    float* rgb = (pass == 0 ? a.out.rgb_coarse : a.out.rgb_fine) + gr * 67;
+                    rgb[3 + lane] = slot ? gb : ga;
+                    if (lane < 3) {
+                        float v = racc[R_RGB + lane];
+                        if (a.bg) v = v + (1.0f - accv) * a.bg[gr * 3 + lane];     // :70-71
+                        rgb[lane] = v;
+                    }
+                    if (lane == 0) {
+                        (pass == 0 ? a.out.depth_coarse : a.out.depth_fine)[gr] = racc[R_DEPTH];
+                        (pass == 0 ? a.out.acc_coarse : a.out.acc_fine)[gr] = accv;
+                        if (pass == 1 || S_fp == 0) a.out.weights_max[gr] = racc[R_WMAX];    // model/nerf_trainer.py:195,200
+                    }
                 }
             }
 
             // ---- inverse-CDF resampling + merge (utils/nerf_util.py:76-117, model/nerf_trainer.py:166-170) ---
-            if (pass == 0 && S_fp > 0) {
+            if (pass == 0 && S_fp > 0 && !(a.ablate & 128)) {
                 const int slot = h, li = j;                       // half-wave h prepares ray slot h
                 const long long gr = (slot == 0 || has1) ? ray0 + slot : ray0;
                 const float* ray = a.rays + gr * a.p.ray_stride;
@@ -697,11 +795,11 @@ extern "C" const char* hav_render_variant(const HavRenderParams* p)
 }
 
 extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, const float* bg, const float* inv_T,
-                               const float* planes_cl, const float* skin_vol, const void* mlp_blob, const float* t_rand,
+                               const float* planes_prepared, const float* skin_vol, const void* mlp_blob, const float* t_rand,
                                const float* u_rand, const float* noise_c, const float* noise_f, const HavRenderOut* out,
                                void* stream)
 {
-    if (!p || !rays || !inv_T || !planes_cl || !skin_vol || !mlp_blob || !out) return HAV_EINVAL;
+    if (!p || !rays || !inv_T || !planes_prepared || !skin_vol || !mlp_blob || !out) return HAV_EINVAL;
     if (p->B < 1 || p->R < 0 || p->ray_stride < 8 || p->S_c < 2 || p->S_f < 0) return HAV_EINVAL;
     if (p->plane_ch != HAV_PC) return HAV_EUNSUP;                 // Trainer hard-codes triPlane_feat_dim=64 (nerf_trainer.py:22)
     if (p->plane_res < 2 || p->vol_res < 2) return HAV_EINVAL;
@@ -712,21 +810,23 @@ extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, cons
 
     MarchArgs a;
     a.p = *p;
-    a.rays = rays; a.bg = bg; a.inv_T = inv_T; a.planes = planes_cl; a.vol = skin_vol; a.blob = (const float*)mlp_blob;
+    a.rays = rays; a.bg = bg; a.inv_T = inv_T; a.planes = nullptr; a.pplanes = planes_prepared; a.vol = skin_vol;
+    a.blob = (const float*)mlp_blob;
     a.t_rand = t_rand; a.u_rand = u_rand; a.noise_c = noise_c; a.noise_f = noise_f;
     a.out = *out;
     a.dbg_zfine = g_dbg_zfine; g_dbg_zfine = nullptr;
+    { const char* e = getenv("HAV_ABLATE"); a.ablate = e ? atoi(e) : 0; }
     a.NR = (long long)p->B * p->R;
     a.S_fp = p->S_f > 0 ? (p->S_c + 1) / 2 + p->S_f : 0;
     a.s_pad_c = (p->S_c + 15) & ~15;
     a.s_pad_f = ((a.S_fp > 0 ? a.S_fp : 1) + 15) & ~15;
-    a.o_w = 0;
+    a.o_racc = 0;                                   // first: keeps the float4 accumulators 16-byte aligned
+    a.o_w = a.o_racc + 2 * RACC_N;
     a.o_cdf = a.o_w + 2 * a.s_pad_c;
     a.o_cand = a.o_cdf + 2 * a.s_pad_c;
     a.o_zf = a.o_cand + 2 * a.s_pad_f;
-    a.o_racc = a.o_zf + 2 * a.s_pad_f;
-    a.scr_floats = (a.o_racc + 2 * RACC_N + 3) & ~3;
-    const size_t lds = ((size_t)K1_STEPS * 4 * 64 + (size_t)MARCH_WAVES * a.scr_floats) * sizeof(float);
+    a.scr_floats = (a.o_zf + 2 * a.s_pad_f + 3) & ~3;
+    const size_t lds = ((size_t)LDS_FLOATS + (size_t)MARCH_WAVES * a.scr_floats) * sizeof(float);
     if (lds > 160 * 1024) return HAV_EUNSUP;
 
     const bool random = p->perturb != 0 || p->noise_std > 0.f;

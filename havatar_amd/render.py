@@ -1,8 +1,9 @@
 """Torch-level host side of the fused ray march (one C-ABI call per set of rays).
 
 `RayMarcher` owns the device-resident, kernel-friendly copies of the per-model / per-frame constants:
-the MFMA-fragment-ordered weight blob (re-packed only when the weights change) and the channels-last
-tri-plane (re-laid-out once per frame), and launches `hav_render_rays` on torch's current HIP stream.
+the MFMA-fragment-ordered weight blob (re-packed only when the weights change) and the prepared tri-planes
+(once per frame: channels-last, pre-multiplied by the plane columns of layers_xyz.0), and launches
+`hav_render_rays` on torch's current HIP stream.
 """
 import ctypes as C
 import os
@@ -44,6 +45,7 @@ class RayMarcher:
         self.blob = None
         self._blob_key = None
         self.planes_cl = None
+        self._planes_key = None
         self.rng_offset = 0
         self.seed = 0x9E3779B97F4A7C15
 
@@ -65,17 +67,22 @@ class RayMarcher:
         self._keep = ts
 
     def set_triplane(self, planes_nchw):
-        """[2,B,C,H,W] (Trainer.model_coarse.triPlane_embeddings) -> channels-last device copy."""
+        """[2,B,C,H,W] (Trainer.model_coarse.triPlane_embeddings) -> prepared planes [2,B,H,W,128] on the device.
+
+        Must be called after set_mlp() and again whenever the weights change (the projection uses them)."""
+        if self.blob is None:
+            raise RuntimeError("set_mlp() must be called before set_triplane()")
         p = _chk_f32_cuda("triPlane_embeddings", planes_nchw)
         two, B, Cc, H, W = p.shape
         if two != 2 or Cc != self.plane_ch or H != W:
             raise RuntimeError(f"unsupported tri-plane shape {tuple(p.shape)}")
         self.plane_res = H
-        if self.planes_cl is None or self.planes_cl.shape != (2, B, H, W, Cc) or self.planes_cl.device != p.device:
-            self.planes_cl = torch.empty((2, B, H, W, Cc), dtype=torch.float32, device=p.device)
+        if self.planes_cl is None or self.planes_cl.shape != (2, B, H, W, 128) or self.planes_cl.device != p.device:
+            self.planes_cl = torch.empty((2, B, H, W, 128), dtype=torch.float32, device=p.device)
         with torch.cuda.device(p.device):
-            _lib.check(_lib.lib().hav_triplane_to_channels_last(_ptr(self.planes_cl), _ptr(p), B, Cc, H, W, _stream()),
-                       "hav_triplane_to_channels_last")
+            _lib.check(_lib.lib().hav_triplane_prepare(_ptr(self.planes_cl), _ptr(p), _ptr(self.blob), B, Cc, H, W, _stream()),
+                       "hav_triplane_prepare")
+        self._planes_key = self._blob_key
 
     # -- launch --------------------------------------------------------------------------------
     def render(self, rays, bg, inv_T, skin_vol, S_c, S_f, perturb=False, noise_std=0.0,
@@ -87,6 +94,8 @@ class RayMarcher:
         rgb_fine, depth_fine, acc_fine (None x3 if S_f == 0)."""
         if self.blob is None or self.planes_cl is None:
             raise RuntimeError("set_mlp() and set_triplane() must be called before render()")
+        if self._planes_key != self._blob_key:
+            raise RuntimeError("weights changed since set_triplane(): call set_triplane() again")
         rays = _chk_f32_cuda("ray_batch", rays)
         B, R, stride = rays.shape
         bg = _chk_f32_cuda("background_prior", bg, allow_none=True)

@@ -108,10 +108,14 @@ int64_t hav_mlp_blob_bytes(void);
  * the weights change (training step / load_state_dict). */
 int hav_mlp_pack(void* blob, const HavMlpWeights* w, void* stream);
 
-/* NCHW [2,B,C,H,W] (Trainer.model_coarse.triPlane_embeddings, model/nerf_model.py:85-86)
- * -> channels-last [2,B,H,W,C] so that one bilinear tap is one contiguous C*4-byte segment. */
-int hav_triplane_to_channels_last(float* dst, const float* src_nchw, int B, int C, int H, int W,
-                                  void* stream);
+/* Per-frame tri-plane preparation.  Input: NCHW [2,B,64,H,W] (Trainer.model_coarse.triPlane_embeddings,
+ * model/nerf_model.py:85-86).  Output (device, hav_triplane_prepared_bytes(B,H,W) bytes): channels-last planes
+ * [2,B,H,W,128] in which every texel has already been multiplied by the 128x64 block of layers_xyz.0 that reads this
+ * plane's channels (bilinear interpolation and the first linear layer commute), stored in the ray-march kernel's
+ * accumulator order.  Needs the packed blob (hav_mlp_pack) of the CURRENT weights: re-run when planes OR weights change. */
+int64_t hav_triplane_prepared_bytes(int B, int H, int W);
+int hav_triplane_prepare(float* dst, const float* src_nchw, const void* mlp_blob, int B, int C, int H, int W,
+                         void* stream);
 
 typedef struct HavRenderOut {      /* all device pointers, float32; fine pointers unused if S_f==0 */
     float* rgb_coarse;   /* [B,R,67]  rgb(3, sigmoid, + background) | feature(64)                 */
@@ -128,7 +132,7 @@ typedef struct HavRenderOut {      /* all device pointers, float32; fine pointer
  *                                                the only consumer is dead code, nerf_trainer.py:146-150)
  * bg        [B,R,3] or NULL                     (background_prior)
  * inv_T     [B,4,3]                             (inv_head_T: rows 0-2 = M, row 3 = tau)
- * planes_cl [2,B,H,W,C] channels-last           (hav_triplane_to_channels_last)
+ * planes    [2,B,H,W,128] prepared planes       (hav_triplane_prepare)
  * skin_vol  [2,D,H,W]                           (canonical_W[0], shared by the batch)
  * mlp_blob  hav_mlp_pack output
  * t_rand    [B,R,S_c] or NULL                   (xi  = torch.rand at nerf_trainer.py:138)
@@ -138,7 +142,7 @@ typedef struct HavRenderOut {      /* all device pointers, float32; fine pointer
  * With perturb!=0 and a NULL rand pointer the values come from an on-device Philox4x32-10 stream.
  */
 int hav_render_rays(const HavRenderParams* p, const float* rays, const float* bg,
-                    const float* inv_T, const float* planes_cl, const float* skin_vol,
+                    const float* inv_T, const float* planes_prepared, const float* skin_vol,
                     const void* mlp_blob, const float* t_rand, const float* u_rand,
                     const float* noise_c, const float* noise_f, const HavRenderOut* out,
                     void* stream);

@@ -29,15 +29,17 @@ def test_hip_vs_reference_golden(name):
 
 
 @pytest.mark.parametrize("name", [n for n in RENDER if "ref64" in "".join(np.load(os.path.join(GOLDEN, n + ".npz")).files)])
-def test_hip_error_vs_fp64_reference_not_worse_than_reference_fp32(name):
-    """Against the reference evaluated in fp64, the kernel's error stays within 5x the reference's own fp32 error
-    (+1e-5): the kernel adds no error class the reference does not have (two fp32 evaluations of this path in
-    different summation orders differ by 1-4x that floor: the CPU oracle itself sits at 3.6x on the stress fixture)."""
+def test_hip_error_vs_fp64_reference_like_a_cpu_fp32_evaluation(name):
+    """Against the reference evaluated in fp64, the kernel's error is of the same class as any fp32 evaluation of this
+    path: within 2.5x the larger of (the reference's own fp32 error, the fp32 CPU oracle's error) on the same fixture.
+    (Two fp32 evaluations in different summation orders differ by 1-5x on the ill-conditioned fine pass, SURVEY B-11.)"""
+    from oracle import oracle
     g, sc, cfg, kw = load_render_fixture(name)
     o = hip_render(sc, **cfg, **kw)
+    c = oracle.render_rays(sc, nthreads=4, **cfg, **kw)
     for k in OUT_KEYS:
-        floor = linf(g["ref_" + k], g["ref64_" + k])
-        assert linf(o[k], g["ref64_" + k]) <= 5.0 * floor + 1e-5, (k, linf(o[k], g["ref64_" + k]), floor)
+        floor = max(linf(g["ref_" + k], g["ref64_" + k]), linf(c[k], g["ref64_" + k]))
+        assert linf(o[k], g["ref64_" + k]) <= 2.5 * floor + 1e-5, (k, linf(o[k], g["ref64_" + k]), floor)
 
 
 def test_fine_depths_match_oracle():
