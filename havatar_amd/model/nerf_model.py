@@ -1,0 +1,86 @@
+"""Tri-plane NeRF: two StyleGAN-style encoders -> 2 planes; bilinear feature gather; 176->128->128->{1, 64->3} MLP
+(reference model/nerf_model.py:10-117).  On HIP tensors at inference only `set_conditional_embedding` (the encoders) runs
+here; gather + PE + MLP are inside the fused ray-march kernel.  `sample_pts_triplane_feat` / `forward` keep the PyTorch
+statement for CPU tensors and autograd.  Only enc_mode='split' (the Trainer's choice) is implemented."""
+import torch
+import torch.nn as nn
+
+from .network.embedder import get_embedder
+from .styleUnet import StyleGAN_zxc
+from ..utils.sh_util import eval_sh
+from ..utils.util import create_UniformBoxWarp, sample_from_triplane_new
+
+
+class ConditionalTriplaneNeRFModel_multiRender_split_view(nn.Module):
+    def __init__(self, XYZ_bounding, num_encoding_fn_xyz=8, latent_code_dim=32, triPlane_feat_dim=32, rgb_feat_dim=32,
+                 triplane_res=256, use_emb=True, enc_mode="split", sh_deg=2, cond_latent=True, cond_c_dim=0):
+        super().__init__()
+        if enc_mode != "split":
+            raise NotImplementedError("only enc_mode='split' is on the hot path (model/nerf_trainer.py:19-26)")
+        self.name = "ConditionalTriplaneNeRFModel_multiRender_split_view"
+        self.pos_embedder, self.dim_xyz = get_embedder(multires=num_encoding_fn_xyz, input_dims=3, include_input=False)
+        self.sh_deg = sh_deg
+        self.use_sh = sh_deg >= 1
+        include_xyz = self.dim_xyz if use_emb else 0
+        self.dim_latent_code = 0 if cond_latent else latent_code_dim
+        self.triPlane_feat_dim = triPlane_feat_dim
+        self.rgb_feat_dim = rgb_feat_dim * (sh_deg + 1) ** 2
+        self.use_emb, self.cond_latent, self.cond_c_dim = use_emb, cond_latent, cond_c_dim
+        self.shared_backbone = self.two_head = False
+        enc = dict(out_ch=triPlane_feat_dim, out_size=triplane_res, style_dim=latent_code_dim, middle_size=16, zero_latent=False,
+                   zero_noise=True, no_skip=True, n_mlp=4, inp_size=256)
+        self.XY_gen = StyleGAN_zxc(inp_ch=7, **enc)
+        self.YZ_gen = StyleGAN_zxc(inp_ch=13, **enc)
+        self.gridwarper = create_UniformBoxWarp(XYZ_bounding)
+        self.layers_xyz = nn.ModuleList([nn.Linear(2 * triPlane_feat_dim + self.dim_latent_code + include_xyz, 128), nn.Linear(128, 128)])
+        self.fc_alpha = nn.Linear(128, 1)
+        self.fc_rgbFeat = nn.Linear(128, 64)
+        self.fc_rgb = nn.Linear(64, self.rgb_feat_dim)
+        self.relu = torch.nn.functional.relu
+        self.triPlane_embeddings = None
+        if not cond_latent:
+            self.register_buffer("zero_latent", torch.zeros(latent_code_dim, dtype=torch.float32).reshape(1, -1))
+
+    def set_conditional_embedding(self, **cond):
+        """front/left/right_render_cond [B,7,256,256], latents [B,L], cond_c [B,12] -> self.triPlane_embeddings [2,B,C,H,W] (:58-86).
+        `left` is mirrored along W and loses its mask channel; YZ_gen sees cat[left(6), right(7)]."""
+        styles = None
+        if "latents" in cond:
+            lat = cond["latents"]
+            c = cond["cond_c"].reshape(lat.shape[0], -1)
+            if self.cond_latent:
+                styles = [torch.cat([lat, c], -1)] if self.cond_c_dim > 0 else [lat]
+            else:
+                styles = [self.zero_latent.expand(lat.shape[0], -1)]
+        front, right = cond["front_render_cond"], cond["right_render_cond"]
+        left = cond["left_render_cond"].flip(dims=[3])
+        if left.shape[1] > 3:
+            left = left[:, :-1]
+        xy, _ = self.XY_gen(styles, front)
+        yz, _ = self.YZ_gen(styles, torch.cat([left, right], dim=1))
+        self.triPlane_embeddings = torch.stack([xy, yz], dim=0)
+
+    def sample_pts_triplane_feat(self, batch_pts, bidx=None):
+        """batch_pts [B,N,3] -> [B*N, 2C], feature index = 2*channel + plane (:88-99)."""
+        q = self.gridwarper(batch_pts)
+        planes = self.triPlane_embeddings if bidx is None else self.triPlane_embeddings[:, bidx]
+        f = sample_from_triplane_new(q, planes, padding_mode="zeros")
+        return f.reshape(-1, f.shape[-1] * f.shape[-2])
+
+    def forward(self, inp, pts_feat):
+        """inp [n,3(+3)], pts_feat [n,2C] -> [n, rgb(3) | feat(64) | alpha(1)] (:101-117)."""
+        xyz, dirs = inp[..., :3], inp[..., 3:]
+        x = torch.cat([pts_feat, self.pos_embedder(xyz)], -1)
+        for layer in self.layers_xyz:
+            x = self.relu(layer(x))
+        alpha = self.fc_alpha(x)
+        x = self.fc_rgbFeat(x)
+        sh = self.fc_rgb(x)
+        rgb = sh if self.sh_deg == 0 else eval_sh(self.sh_deg, sh.reshape(sh.shape[0], -1, (self.sh_deg + 1) ** 2), dirs)
+        return torch.cat((rgb, x, alpha), dim=-1)
+
+    def mlp_tensors(self):
+        """nn.Linear-layout tensors in the order RayMarcher.set_mlp expects."""
+        l0, l1 = self.layers_xyz
+        return (l0.weight, l0.bias, l1.weight, l1.bias, self.fc_alpha.weight, self.fc_alpha.bias, self.fc_rgbFeat.weight,
+                self.fc_rgbFeat.bias, self.fc_rgb.weight, self.fc_rgb.bias)

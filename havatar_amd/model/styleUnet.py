@@ -1,0 +1,469 @@
+"""StyleGAN2 / SWAGAN building blocks and the two networks the hot path calls: `StyleGAN_zxc` (tri-plane encoder, P3) and
+`SWGAN_unet` (stage-two upsampler, P15).  Module code is plain PyTorch-ROCm (convs -> MIOpen); every blur / resample /
+bias-activation goes through havatar_amd.model.op, i.e. the HIP kernels.
+
+Behaviour and state_dict keys follow the reference (model/styleUnet.py:9-628 blocks, :631-878 StyleGAN_zxc,
+:1190-1410 SWGAN_unet) so reference-trained checkpoints load; the implementation is written for this code base:
+  * ModulatedConv2d uses the scale-input / shared-weight conv / scale-output factorisation (the reference's own
+    `fused=False` algebra, :200-227) instead of materialising B*Cout per-sample filters for a grouped conv: one ordinary
+    MIOpen convolution per call, identical mathematics (validated against the reference's fused branch).
+  * only the configurations the path instantiates are supported (conditional-image encoder mode of StyleGAN_zxc).
+"""
+import math
+import random
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from .op import FusedLeakyReLU, conv2d_gradfix, fused_leaky_relu, upfirdn2d
+
+_CHANNELS = lambda cm: {4: 512, 8: 512, 16: 512, 32: 512, 64: 256 * cm, 128: 128 * cm, 256: 64 * cm, 512: 32 * cm, 1024: 16 * cm}
+
+
+class PixelNorm(nn.Module):
+    def forward(self, input):
+        return input * torch.rsqrt(torch.mean(input ** 2, dim=1, keepdim=True) + 1e-8)
+
+
+def make_kernel(k):
+    k = torch.tensor(k, dtype=torch.float32)
+    if k.ndim == 1:
+        k = k[None, :] * k[:, None]
+    return k / k.sum()
+
+
+class Upsample(nn.Module):
+    def __init__(self, kernel, factor=2):
+        super().__init__()
+        self.factor = factor
+        k = make_kernel(kernel) * (factor ** 2)
+        self.register_buffer("kernel", k)
+        p = k.shape[0] - factor
+        self.pad = ((p + 1) // 2 + factor - 1, p // 2)
+
+    def forward(self, input):
+        return upfirdn2d(input, self.kernel, up=self.factor, down=1, pad=self.pad)
+
+
+class Downsample(nn.Module):
+    def __init__(self, kernel, factor=2):
+        super().__init__()
+        self.factor = factor
+        k = make_kernel(kernel)
+        self.register_buffer("kernel", k)
+        p = k.shape[0] - factor
+        self.pad = ((p + 1) // 2, p // 2)
+
+    def forward(self, input):
+        return upfirdn2d(input, self.kernel, up=1, down=self.factor, pad=self.pad)
+
+
+class Blur(nn.Module):
+    def __init__(self, kernel, pad, upsample_factor=1):
+        super().__init__()
+        k = make_kernel(kernel)
+        if upsample_factor > 1:
+            k = k * (upsample_factor ** 2)
+        self.register_buffer("kernel", k)
+        self.pad = pad
+
+    def forward(self, input):
+        return upfirdn2d(input, self.kernel, pad=self.pad)
+
+
+class EqualConv2d(nn.Module):
+    def __init__(self, in_channel, out_channel, kernel_size, stride=1, padding=0, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(out_channel, in_channel, kernel_size, kernel_size))
+        self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
+        self.stride, self.padding = stride, padding
+        self.bias = nn.Parameter(torch.zeros(out_channel)) if bias else None
+
+    def forward(self, input):
+        return conv2d_gradfix.conv2d(input, self.weight * self.scale, bias=self.bias, stride=self.stride, padding=self.padding)
+
+
+class EqualLinear(nn.Module):
+    def __init__(self, in_dim, out_dim, bias=True, bias_init=0, lr_mul=1, activation=None):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(out_dim, in_dim).div_(lr_mul))
+        self.bias = nn.Parameter(torch.zeros(out_dim).fill_(bias_init)) if bias else None
+        self.activation = activation
+        self.scale = (1 / math.sqrt(in_dim)) * lr_mul
+        self.lr_mul = lr_mul
+
+    def forward(self, input):
+        if self.activation:
+            return fused_leaky_relu(F.linear(input, self.weight * self.scale), self.bias * self.lr_mul)
+        return F.linear(input, self.weight * self.scale, bias=self.bias * self.lr_mul)
+
+
+class ModulatedConv2d(nn.Module):
+    """y = demod_b,o * conv(x * style_b,i , scale * W)   (style = EqualLinear(w), demod = rsqrt(sum (scale W style)^2 + eps))."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, demodulate=True, upsample=False, downsample=False,
+                 blur_kernel=(1, 3, 3, 1), fused=True):
+        super().__init__()
+        self.eps = 1e-8
+        self.kernel_size, self.in_channel, self.out_channel = kernel_size, in_channel, out_channel
+        self.upsample, self.downsample = upsample, downsample
+        if upsample:
+            factor = 2
+            p = (len(blur_kernel) - factor) - (kernel_size - 1)
+            self.blur = Blur(blur_kernel, pad=((p + 1) // 2 + factor - 1, p // 2 + 1), upsample_factor=factor)
+        if downsample:
+            factor = 2
+            p = (len(blur_kernel) - factor) + (kernel_size - 1)
+            self.blur = Blur(blur_kernel, pad=((p + 1) // 2, p // 2))
+        self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
+        self.padding = kernel_size // 2
+        self.weight = nn.Parameter(torch.randn(1, out_channel, in_channel, kernel_size, kernel_size))
+        self.modulation = EqualLinear(style_dim, in_channel, bias_init=1)
+        self.demodulate = demodulate
+        self.fused = fused
+
+    def forward(self, input, style):
+        B, Cin = input.shape[:2]
+        w = self.scale * self.weight[0]                                   # [Cout,Cin,k,k]
+        s = self.modulation(style)                                        # [B,Cin]
+        x = input * s.view(B, Cin, 1, 1)
+        if self.upsample:
+            out = self.blur(conv2d_gradfix.conv_transpose2d(x, w.transpose(0, 1), padding=0, stride=2))
+        elif self.downsample:
+            out = conv2d_gradfix.conv2d(self.blur(x), w, padding=0, stride=2)
+        else:
+            out = conv2d_gradfix.conv2d(x, w, padding=self.padding)
+        if self.demodulate:
+            # sum_{i,ky,kx} (w[o,i] s[b,i])^2 = sum_i s[b,i]^2 * sum_k w[o,i,k]^2
+            d = torch.rsqrt(torch.matmul(s * s, w.pow(2).sum((2, 3)).t()) + self.eps)      # [B,Cout]
+            out = out * d.view(B, -1, 1, 1)
+        return out
+
+
+class NoiseInjection(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(1))
+
+    def forward(self, image, noise=None):
+        if noise is None:
+            b, _, h, w = image.shape
+            noise = image.new_empty(b, 1, h, w).normal_()
+        return image + self.weight * noise
+
+
+class ConstantInput(nn.Module):
+    def __init__(self, channel, size=4):
+        super().__init__()
+        self.input = nn.Parameter(torch.randn(1, channel, size, size))
+
+    def forward(self, input):
+        return self.input.repeat(input.shape[0], 1, 1, 1)
+
+
+class ConvLayer(nn.Sequential):
+    """[Blur] -> EqualConv2d -> [FusedLeakyReLU]  (sequential indices are part of the checkpoint format)."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, downsample=False, blur_kernel=(1, 3, 3, 1), bias=True, activate=True):
+        layers = []
+        if downsample:
+            p = (len(blur_kernel) - 2) + (kernel_size - 1)
+            layers.append(Blur(blur_kernel, pad=((p + 1) // 2, p // 2)))
+            stride, self.padding = 2, 0
+        else:
+            stride, self.padding = 1, kernel_size // 2
+        layers.append(EqualConv2d(in_channel, out_channel, kernel_size, padding=self.padding, stride=stride, bias=bias and not activate))
+        if activate:
+            layers.append(FusedLeakyReLU(out_channel, bias=bias))
+        super().__init__(*layers)
+
+
+def get_haar_wavelet(in_channels):
+    l = 1 / (2 ** 0.5) * torch.ones(1, 2)
+    h = 1 / (2 ** 0.5) * torch.ones(1, 2)
+    h[0, 0] = -h[0, 0]
+    return l.T * l, h.T * l, l.T * h, h.T * h
+
+
+class HaarTransform(nn.Module):
+    def __init__(self, in_channels):
+        super().__init__()
+        for n, k in zip(("ll", "lh", "hl", "hh"), get_haar_wavelet(in_channels)):
+            self.register_buffer(n, k)
+
+    def forward(self, input):
+        return torch.cat([upfirdn2d(input, k, down=2) for k in (self.ll, self.lh, self.hl, self.hh)], 1)
+
+
+class InverseHaarTransform(nn.Module):
+    def __init__(self, in_channels):
+        super().__init__()
+        ll, lh, hl, hh = get_haar_wavelet(in_channels)
+        for n, k in zip(("ll", "lh", "hl", "hh"), (ll, -lh, -hl, hh)):
+            self.register_buffer(n, k)
+
+    def forward(self, input):
+        parts = input.chunk(4, 1)
+        ks = (self.ll, self.lh, self.hl, self.hh)
+        return sum(upfirdn2d(p, k, up=2, pad=(1, 0, 1, 0)) for p, k in zip(parts, ks))
+
+
+class ConvBlock(nn.Module):
+    def __init__(self, in_channel, out_channel, blur_kernel=(1, 3, 3, 1), downsample=True):
+        super().__init__()
+        self.conv1 = ConvLayer(in_channel, in_channel, 3)
+        self.conv2 = ConvLayer(in_channel, out_channel, 3, downsample=downsample)
+
+    def forward(self, input):
+        return self.conv2(self.conv1(input))
+
+
+class FromRGB(nn.Module):
+    def __init__(self, out_channel, in_channel, downsample=True, blur_kernel=(1, 3, 3, 1), use_wt=True):
+        super().__init__()
+        self.downsample, self.use_wt = downsample, use_wt
+        if downsample:
+            self.downsample = Downsample(blur_kernel)
+            if use_wt:
+                self.iwt = InverseHaarTransform(in_channel)
+                self.dwt = HaarTransform(in_channel)
+        self.in_channel = in_channel * 4 if use_wt else in_channel
+        self.conv = ConvLayer(self.in_channel, out_channel, 1)
+
+    def forward(self, input, skip=None):
+        if self.downsample:
+            input = self.dwt(self.downsample(self.iwt(input))) if self.use_wt else self.downsample(input)
+        out = self.conv(input)
+        return input, (out if skip is None else out + skip)
+
+
+class StyledConv(nn.Module):
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, upsample=False, blur_kernel=(1, 3, 3, 1), demodulate=True):
+        super().__init__()
+        self.conv = ModulatedConv2d(in_channel, out_channel, kernel_size, style_dim, upsample=upsample, blur_kernel=blur_kernel,
+                                    demodulate=demodulate)
+        self.noise = NoiseInjection()
+        self.activate = FusedLeakyReLU(out_channel)
+
+    def forward(self, input, style, noise=None):
+        return self.activate(self.noise(self.conv(input, style), noise=noise))
+
+
+class ToRGB(nn.Module):
+    def __init__(self, in_channel, style_dim, out_channel=12, upsample=True, blur_kernel=(1, 3, 3, 1), use_wt=True):
+        super().__init__()
+        self.use_wt = use_wt
+        if upsample:
+            self.upsample = Upsample(blur_kernel)
+            if use_wt:
+                self.iwt = InverseHaarTransform(3)
+                self.dwt = HaarTransform(3)
+        self.out_channel = out_channel if use_wt else out_channel // 4
+        self.conv = ModulatedConv2d(in_channel, self.out_channel, 1, style_dim, demodulate=False)
+        self.bias = nn.Parameter(torch.zeros(1, self.out_channel, 1, 1))
+
+    def forward(self, input, style, skip=None):
+        out = self.conv(input, style) + self.bias
+        if skip is not None:
+            skip = self.dwt(self.upsample(self.iwt(skip))) if self.use_wt else self.upsample(skip)
+            out = out + skip
+        return out
+
+
+def _mix_latents(styles, n_latent, inject_index):
+    if len(styles) < 2:
+        return styles[0].unsqueeze(1).repeat(1, n_latent, 1) if styles[0].ndim < 3 else styles[0]
+    if inject_index is None:
+        inject_index = random.randint(1, n_latent - 1)
+    return torch.cat([styles[0].unsqueeze(1).repeat(1, inject_index, 1),
+                      styles[1].unsqueeze(1).repeat(1, n_latent - inject_index, 1)], 1)
+
+
+def _style_mlp(in_dim, dim, n_mlp, lr_mlp):
+    layers = [PixelNorm(), EqualLinear(in_dim, dim, lr_mul=lr_mlp, activation="fused_lrelu")]
+    layers += [EqualLinear(dim, dim, lr_mul=lr_mlp, activation="fused_lrelu") for _ in range(n_mlp - 1)]
+    return nn.Sequential(*layers)
+
+
+class _CondEncoder:
+    """shared by both nets: conv_in (256->128) then FromRGB-pyramid + ConvBlocks, returning the feature list (fine -> coarse)."""
+
+    def _encode(self, cond_img):
+        out = self.conv_in(cond_img)
+        feats = [out]
+        for from_rgb, conv in zip(self.from_rgbs, self.cond_convs):
+            cond_img, out = from_rgb(cond_img, out)
+            out = conv(out)
+            feats.append(out)
+        return feats
+
+
+class StyleGAN_zxc(nn.Module, _CondEncoder):
+    """Tri-plane encoder: conditional image (inp_ch x inp_size^2) -> U-shaped StyleGAN2 synthesis at out_size.
+
+    Only the conditional-image mode (inp_size > 0) is implemented -- the only one model/nerf_model.py instantiates."""
+
+    def __init__(self, out_ch, out_size, style_dim, mlp_dim=32, n_mlp=0, middle_size=8, inject_layers=(), zero_latent=False,
+                 zero_noise=False, no_skip=False, channel_multiplier=2, blur_kernel=(1, 3, 3, 1), lr_mlp=0.01, n_latent=None,
+                 inp_size=0, inp_ch=0, pass_kernel=False):
+        super().__init__()
+        if inp_size <= 0:
+            raise NotImplementedError("StyleGAN_zxc: only the conditional-image encoder mode is on the hot path")
+        self.no_skip = no_skip
+        self.style_dim = mlp_dim
+        self.middle_log_size = int(math.log(middle_size, 2))
+        self.cond_img_enc = True
+        self.n_mlp = n_mlp
+        if n_mlp > 0:
+            self.style = _style_mlp(style_dim, mlp_dim, n_mlp, lr_mlp)
+        self.channels = ch = _CHANNELS(channel_multiplier)
+        self.log_size = int(math.log(out_size, 2))
+
+        in_channel = ch[inp_size // 2]
+        self.from_rgbs, self.cond_convs, self.comb_convs = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+        self.comb_convs.append(ConvLayer(in_channel * 2, in_channel, 3))
+        self.conv_in = ConvLayer(inp_ch, in_channel, 3, downsample=True)
+        for i in range(int(math.log(inp_size, 2)) - 2, self.middle_log_size, -1):
+            out_channel = ch[2 ** i]
+            self.from_rgbs.append(FromRGB(in_channel, inp_ch, downsample=True, use_wt=False))
+            self.cond_convs.append(ConvBlock(in_channel, out_channel, blur_kernel))
+            self.comb_convs.append(ConvLayer(out_channel * 2, out_channel, 3))
+            in_channel = out_channel
+
+        self.convs, self.to_rgbs, self.noises = nn.ModuleList(), nn.ModuleList(), nn.Module()
+        self.input = ConstantInput(ch[middle_size], size=middle_size)
+        self.conv1 = StyledConv(ch[middle_size], ch[middle_size], 3, self.style_dim, blur_kernel=blur_kernel)
+        if no_skip:
+            self.conv_out = ConvLayer(ch[out_size], out_ch, 1)
+        else:
+            self.to_rgb1 = ToRGB(ch[middle_size], self.style_dim, out_channel=out_ch * 4, upsample=False, use_wt=False)
+        self.num_layers = (self.log_size - self.middle_log_size) * 2 + 1
+        for li in range(self.num_layers):
+            res = (li + 8) // 2
+            self.noises.register_buffer(f"noise_{li}", torch.randn(1, 1, 2 ** res, 2 ** res))
+        in_channel = ch[middle_size]
+        for i in range(self.middle_log_size + 1, self.log_size + 1):
+            out_channel = ch[2 ** i]
+            self.convs.append(StyledConv(in_channel, out_channel, 3, self.style_dim, upsample=True, blur_kernel=blur_kernel))
+            self.convs.append(StyledConv(out_channel, out_channel, 3, self.style_dim, blur_kernel=blur_kernel))
+            self.to_rgbs.append(None if no_skip else ToRGB(out_channel, self.style_dim, out_channel=out_ch * 4, use_wt=False))
+            in_channel = out_channel
+        self.n_latent = self.log_size * 2 - (self.middle_log_size * 2 - 1) + 1 if n_latent is None else n_latent
+        # zero_noise=True: all-zero injected noise EXCEPT the first entry, which is a random tensor drawn at construction,
+        # kept as a plain attribute (not a buffer, not in the state_dict): reference :746-751 / SURVEY B-3.
+        self.zero_noise = self.make_noise(zero_noise=True) if zero_noise else None
+        if zero_latent:
+            self.register_buffer("zero_latents", torch.zeros(1, self.n_latent, self.style_dim))
+        else:
+            self.zero_latents = None
+
+    def make_noise(self, zero_noise=False):
+        fn = torch.zeros if zero_noise else torch.randn
+        noises = [torch.randn(1, 1, 2 ** self.middle_log_size, 2 ** self.middle_log_size)]
+        for i in range(self.middle_log_size + 1, self.log_size + 1):
+            noises += [fn(1, 1, 2 ** i, 2 ** i), fn(1, 1, 2 ** i, 2 ** i)]
+        return noises
+
+    def get_latent(self, styles, n_latent=None, inject_index=None):
+        return _mix_latents([self.style(s) for s in styles], self.n_latent if n_latent is None else n_latent, inject_index)
+
+    def forward(self, styles, cond_feats, return_latents=False, inject_index=None, truncation=1, truncation_latent=None,
+                input_is_latent=False, noise=None, randomize_noise=True, **kwargs):
+        B = cond_feats.shape[0]
+        if self.zero_latents is None:
+            if not input_is_latent:
+                assert self.n_mlp > 0
+                styles = [self.style(s) for s in styles]
+            if truncation < 1:
+                styles = [truncation_latent + truncation * (s - truncation_latent) for s in styles]
+            latent = _mix_latents(styles, self.n_latent, inject_index)
+        else:
+            latent = self.zero_latents.expand(B, -1, -1)
+        if self.zero_noise is not None:
+            noise = [n.to(cond_feats.device) for n in self.zero_noise]
+            self.zero_noise = noise
+        elif noise is None:
+            noise = [None] * self.num_layers if randomize_noise else [getattr(self.noises, f"noise_{i}") for i in range(self.num_layers)]
+
+        cond_list = self._encode(cond_feats)
+        out = self.conv1(self.input(latent), latent[:, 0], noise=noise[0])
+        skip = None if self.no_skip else self.to_rgb1(out, latent[:, 1])
+        i = 1
+        for conv_a, conv_b, n_a, n_b, to_rgb in zip(self.convs[::2], self.convs[1::2], noise[1::2], noise[2::2], self.to_rgbs):
+            if 1 < i <= 2 * len(cond_list) + 1:
+                out = self.comb_convs[-(i // 2)](torch.cat([out, cond_list[-(i // 2)]], dim=1))
+            out = conv_b(conv_a(out, latent[:, i], noise=n_a), latent[:, i + 1], noise=n_b)
+            if not self.no_skip:
+                skip = to_rgb(out, latent[:, i + 2], skip)
+            i += 2
+        image = self.conv_out(out) if self.no_skip else skip
+        return (image, latent) if return_latents else (image, None)
+
+
+class SWGAN_unet(nn.Module, _CondEncoder):
+    """Stage-two upsampler: condition image [B,inp_ch,inp_size^2] -> RGB [B,3,out_size^2] in the Haar-wavelet domain."""
+
+    def __init__(self, inp_size, inp_ch, out_ch, out_size, style_dim, n_mlp, middle_size=8, c_dim=0, channel_multiplier=2,
+                 blur_kernel=(1, 3, 3, 1), lr_mlp=0.01):
+        super().__init__()
+        self.inp_size, self.style_dim = inp_size, style_dim
+        self.middle_log_size = int(math.log(middle_size, 2))
+        self.style = _style_mlp(style_dim + c_dim, style_dim, n_mlp, lr_mlp)
+        self.channels = ch = _CHANNELS(channel_multiplier)
+        self.log_size = int(math.log(out_size, 2)) - 1
+
+        in_channel = ch[inp_size // 2]
+        self.from_rgbs, self.cond_convs, self.comb_convs = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+        self.comb_convs.append(ConvLayer(in_channel * 2, in_channel, 3))
+        self.conv_in = ConvLayer(inp_ch, in_channel, 3, downsample=True)
+        for i in range(int(math.log(inp_size, 2)) - 2, self.middle_log_size - 1, -1):
+            out_channel = ch[2 ** i]
+            self.from_rgbs.append(FromRGB(in_channel, inp_ch, downsample=True, use_wt=False))
+            self.cond_convs.append(ConvBlock(in_channel, out_channel, blur_kernel))
+            self.comb_convs.append(ConvLayer(out_channel * 2 if i > self.middle_log_size else out_channel, out_channel, 3))
+            in_channel = out_channel
+
+        self.convs, self.to_rgbs, self.noises = nn.ModuleList(), nn.ModuleList(), nn.Module()
+        self.num_layers = (self.log_size - self.middle_log_size) * 2
+        for li in range(self.num_layers):
+            res = (li + 8) // 2
+            self.noises.register_buffer(f"noise_{li}", torch.randn(1, 1, 2 ** res, 2 ** res))
+        in_channel = ch[middle_size]
+        for i in range(self.middle_log_size + 1, self.log_size + 1):
+            out_channel = ch[2 ** i]
+            self.convs.append(StyledConv(in_channel, out_channel, 3, style_dim, upsample=True, blur_kernel=blur_kernel))
+            self.convs.append(StyledConv(out_channel, out_channel, 3, style_dim, blur_kernel=blur_kernel))
+            self.to_rgbs.append(ToRGB(out_channel, style_dim, out_channel=out_ch * 4))
+            in_channel = out_channel
+        self.iwt = InverseHaarTransform(3)
+        self.n_latent = self.log_size * 2 - (self.middle_log_size * 2 - 1) + 1
+
+    def make_noise(self, device, zero_noise=False):
+        fn = torch.zeros if zero_noise else torch.randn
+        return [fn(1, 1, 2 ** i, 2 ** i, device=device) for i in range(self.middle_log_size + 1, self.log_size + 1) for _ in range(2)]
+
+    def get_latent(self, input):
+        return self.style(input)
+
+    def forward(self, styles, condition_img, cond=None, return_latents=False, inject_index=None, truncation=1,
+                truncation_latent=None, input_is_latent=False, noise=None, randomize_noise=True):
+        if not input_is_latent:
+            styles = [self.style(s if cond is None else torch.cat([s, cond], dim=-1)) for s in styles]
+        if noise is None:
+            noise = [None] * self.num_layers if randomize_noise else [getattr(self.noises, f"noise_{i}") for i in range(self.num_layers)]
+        if truncation < 1:
+            styles = [truncation_latent + truncation * (s - truncation_latent) for s in styles]
+        latent = _mix_latents(styles, self.n_latent, inject_index)
+
+        cond_list = self._encode(condition_img)
+        i, skip, out = 0, None, None
+        for conv_a, conv_b, n_a, n_b, to_rgb in zip(self.convs[::2], self.convs[1::2], noise[::2], noise[1::2], self.to_rgbs):
+            if i == 0:
+                out = self.comb_convs[-1](cond_list[-1])
+            elif i < 2 * len(self.comb_convs):
+                out = self.comb_convs[-1 - (i // 2)](torch.cat([out, cond_list[-1 - (i // 2)]], dim=1))
+            out = conv_b(conv_a(out, latent[:, i], noise=n_a), latent[:, i + 1], noise=n_b)
+            skip = to_rgb(out, latent[:, i + 2], skip)
+            i += 2
+        return self.iwt(skip)

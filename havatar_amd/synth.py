@@ -197,3 +197,65 @@ def scene(H, W, recipe="primary", y0=0, y1=None, B=1, pose=None):
         mlp=mlp_weights(**RECIPES[recipe]["mlp"]),
         nerf_scale=ns, nerf_trans=nt, skin_scale=ss, skin_trans=st,
     )
+
+
+# ----------------------------------------------------------------------------------------------
+# Deterministic parameters for whole modules (encoders, upsampler, volume decoder): value = f(key name, shape)
+# ----------------------------------------------------------------------------------------------
+_KEEP = ("kernel", ".ll", ".lh", ".hl", ".hh", "scale_factor", "trans_factor", "identity_trans")
+
+
+def fill_state_dict(module, seed=0, mlp_recipe="primary"):
+    """Overwrite every parameter/buffer of `module` (a torch.nn.Module) with values that depend only on the state_dict key
+    and shape, so the reference model and this repo's mirror can be given identical weights without shipping them.
+    FIR / wavelet / box-warp buffers are left alone; the radiance MLP gets `mlp_weights(recipe)`."""
+    import zlib
+
+    import torch
+    mlp = mlp_weights(**RECIPES[mlp_recipe]["mlp"])
+    mlp_keys = {"layers_xyz.0.weight": "W1", "layers_xyz.0.bias": "b1", "layers_xyz.1.weight": "W2", "layers_xyz.1.bias": "b2",
+                "fc_alpha.weight": "Wa", "fc_alpha.bias": "ba", "fc_rgbFeat.weight": "Wf", "fc_rgbFeat.bias": "bf",
+                "fc_rgb.weight": "Wc", "fc_rgb.bias": "bc"}
+    sd = module.state_dict()
+    new = {}
+    for k, v in sd.items():
+        if any(k.endswith(s) or s + "." in k for s in _KEEP) or not torch.is_floating_point(v):
+            continue
+        hit = [mk for mk in mlp_keys if k.endswith("model_coarse." + mk) or k == mk]
+        if hit:
+            new[k] = torch.from_numpy(mlp[mlp_keys[hit[0]]].reshape(tuple(v.shape)))
+            continue
+        s = (zlib.crc32(k.encode()) + 7919 * seed) & 0x7FFFFFFF
+        shape = tuple(v.shape)
+        if k.endswith("init_lc"):
+            a = uniform(shape, s)
+        elif "canonical_Wvolume" in k:
+            a = normal(shape, s, 0.05 if k.endswith("weight") else 0.01)
+        elif k.endswith("latent_codes"):
+            a = normal(shape, s, 0.3)
+        elif k.endswith("bias"):
+            a = normal(shape, s, 0.1) + (1.0 if "modulation" in k else 0.0)
+        elif "noise" in k and k.endswith("weight"):
+            a = normal(shape, s, 0.1)
+        else:
+            a = normal(shape, s, 1.0)
+        new[k] = torch.from_numpy(a.reshape(shape))
+    sd.update(new)
+    module.load_state_dict(sd)
+    return module
+
+
+def cond_images(B=1, res=256, seed=60):
+    """front/left/right condition renders [B,7,res,res] in [0,1]: smooth pseudo-renders (rgb, normal, mask)."""
+    out = []
+    for v in range(3):
+        lo = uniform((B, 7, 16, 16), seed + v).astype(np.float64)
+        t = np.linspace(0.0, 15.0, res)
+        i0 = np.floor(t).astype(np.int64)
+        i1 = np.minimum(i0 + 1, 15)
+        f = t - i0
+        a = lo[..., i0, :] * (1 - f)[:, None] + lo[..., i1, :] * f[:, None]
+        img = a[..., i0] * (1 - f) + a[..., i1] * f
+        img[:, 6] = (img[:, 6] > 0.45).astype(np.float64)
+        out.append(img.astype(np.float32))
+    return out

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Golden vectors for the module-level rows (P1-P3, P6, P15, H1): run the REFERENCE modules (imported from
+/root/reference, build container only) with weights that are a pure function of the state_dict key
+(havatar_amd.synth.fill_state_dict) and store small slices of their outputs in tests/golden/modules.npz."""
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "oracle"))
+from gen_golden import import_reference  # noqa: E402
+
+
+def main():
+    from havatar_amd import synth
+    torch, Trainer, cfg = import_reference()
+    from model.styleUnet import SWGAN_unet
+    torch.manual_seed(0)
+    out = {}
+    tr = Trainer(cfg, 2)
+    tr.requires_grad_(False)
+    out["state_dict_keys"] = np.array(sorted(tr.state_dict().keys()))
+    out["state_dict_shapes"] = np.array([str(tuple(tr.state_dict()[k].shape)) for k in sorted(tr.state_dict().keys())])
+    synth.fill_state_dict(tr)
+    # zero_noise[0] is construction-time random and not in the state_dict (SURVEY B-3): pin it
+    zn = [torch.from_numpy(synth.normal((1, 1, 16, 16), 70 + i)) for i in range(2)]
+    tr.model_coarse.XY_gen.zero_noise[0] = zn[0]
+    tr.model_coarse.YZ_gen.zero_noise[0] = zn[1]
+    front, left, right = [torch.from_numpy(a) for a in synth.cond_images()]
+    inv_T = torch.from_numpy(synth.inv_head_T())[None]
+    with torch.no_grad():
+        # P6: frozen skinning volume + forward
+        tr.headpose_skin_net.fix_canonical_W()
+        vol = tr.headpose_skin_net.canonical_W
+        out["skin_vol_slice"] = vol[0, :, ::8, ::8, ::8].numpy()
+        out["skin_vol_cks"] = np.array([vol.double().sum().item(), vol.double().abs().sum().item()])
+        pts = torch.from_numpy(synth.uniform((1, 200, 3), 80, -1.6, 1.6))
+        vd = torch.from_numpy(synth.normal((1, 200, 3), 81))
+        po, vo = tr.headpose_skin_net(pts, vd, inv_T)
+        out["skin_pts"], out["skin_view"] = po.numpy(), vo.numpy()
+        # P3: tri-plane encoders
+        lat = tr.latent_codes[0:1]
+        tr.model_coarse.set_conditional_embedding(front_render_cond=front, left_render_cond=left, right_render_cond=right,
+                                                  latents=lat, cond_c=inv_T.view(1, -1))
+        planes = tr.model_coarse.triPlane_embeddings
+        out["planes_slice"] = planes[:, :, ::4, ::8, ::8].numpy()
+        out["planes_cks"] = np.array([planes.double().sum().item(), planes.double().abs().sum().item(), planes.double().abs().max().item()])
+        # P1/P2: Trainer.forward, 8-tuple branch, 10x10 rays, deterministic sampling
+        v = tr.cfg.nerf.validation
+        v.perturb, v.num_coarse, v.num_fine, v.radiance_field_noise_std = False, 64, 16, 0.0
+        rays = torch.from_numpy(synth.camera_rays(10, 10))[None]
+        bg = torch.ones(1, 100, 3)
+        res = tr(ray_batch=rays, background_prior=bg, inv_head_T=inv_T, front_render_cond=front, left_render_cond=left,
+                 right_render_cond=right, mode="validation", fidx=[0], render_full_img=False)
+        names = ["rgb_coarse", "depth_coarse", "acc_coarse", "weights_max", "rgb_fine", "depth_fine", "acc_fine", "latent_code_loss"]
+        for n, t in zip(names, res):
+            out["fwd_" + n] = t.numpy()
+    # P15: stage-two upsampler, reference default 128 -> 512
+    g = SWGAN_unet(inp_size=128, inp_ch=64, out_ch=3, out_size=512, style_dim=64, n_mlp=8, middle_size=8)
+    g.requires_grad_(False)
+    synth.fill_state_dict(g, seed=1)
+    out["swgan_keys"] = np.array(sorted(g.state_dict().keys()))
+    cond = torch.from_numpy(synth.normal((1, 64, 128, 128), 90, 0.5))
+    style = torch.from_numpy(synth.normal((1, 64), 91))
+    with torch.no_grad():
+        img = g(styles=[style], condition_img=cond, randomize_noise=False)
+    out["swgan_slice"] = img[:, :, ::16, ::16].numpy()
+    out["swgan_cks"] = np.array([img.double().sum().item(), img.double().abs().sum().item(), img.double().abs().max().item()])
+    path = os.path.join(REPO, "tests", "golden", "modules.npz")
+    np.savez_compressed(path, **out)
+    print("modules.npz", os.path.getsize(path) // 1024, "KiB", "planes |max| %.3f" % out["planes_cks"][2], "swgan |max| %.3f" % out["swgan_cks"][2],
+          "acc_fine", out["fwd_acc_fine"].min(), out["fwd_acc_fine"].max())
+
+
+if __name__ == "__main__":
+    main()
