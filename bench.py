@@ -68,14 +68,23 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from havatar_amd import synth
-    from havatar_amd.render import RayMarcher
+    from havatar_amd.model.nerf_trainer import Trainer
+    from havatar_amd.utils.cfgnode import CfgNode
 
-    sc = synth.scene(8, 8, "primary")                       # constants; the rays below are the full 512x512 frame
+    # the reference's Trainer surface, scaled to a 512x512 NeRF frame (BASELINE config 2), key-derived synthetic weights
+    cfg = CfgNode.load_yaml(os.path.join(ROOT, "havatar_amd", "config", "hd_base.yml"))
+    cfg.models.StyleUnet.inp_size = H
+    v = cfg.nerf.validation
+    v.num_coarse, v.num_fine, v.perturb, v.radiance_field_noise_std = S_C, S_F, bool(args.perturb), 0.0
+    torch.manual_seed(0)
+    tr = Trainer(cfg, 1)
+    tr.requires_grad_(False)
+    synth.fill_state_dict(tr)
+    tr = tr.to(dev)
+    tr.headpose_skin_net.fix_canonical_W()                     # inference: frozen skinning volume (avatarHD_reenactment.py:144)
+    sc = synth.scene(8, 8, "primary")                           # CPU-baseline constants
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
-    rm = RayMarcher(sc["nerf_scale"], sc["nerf_trans"], sc["skin_scale"], sc["skin_trans"])
-    rm.set_mlp(*[t(sc["mlp"][k]) for k in ("W1", "b1", "W2", "b2", "Wa", "ba", "Wf", "bf", "Wc", "bc")])
-    planes = t(sc["planes"])
-    vol = t(sc["vol"])
+    front, left, right = [t(a) for a in synth.cond_images()]
     rays = t(synth.camera_rays(H, W))[None]
     bg = torch.ones(1, H * W, 3, device=dev)
     # frame k of the batch has its own head pose; rank r renders frames r, r+N, ...
@@ -83,8 +92,9 @@ def main():
     perturb = bool(args.perturb)
 
     def step(i):
-        rm.set_triplane(planes)                              # per-frame NCHW -> channels-last re-layout (planes change per frame)
-        return rm.render(rays, bg, poses[i % len(poses)], vol, S_C, S_F, perturb=perturb)
+        with torch.no_grad():
+            return tr(ray_batch=rays, background_prior=bg, inv_head_T=poses[i % len(poses)], front_render_cond=front,
+                      left_render_cond=left, right_render_cond=right, mode="validation", fidx=[0], render_full_img=True)
 
     for i in range(args.warmup):
         step(i)
@@ -92,13 +102,9 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
-        rm.set_triplane(planes)
-        ev[i][0].record()                                    # kernel time of the march on ITS stream (torch current stream)
-        out = rm.render(rays, bg, poses[i % len(poses)], vol, S_C, S_F, perturb=perturb)
-        ev[i][1].record()
+        out = step(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -108,18 +114,36 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     fps = world * args.steps / dt
+
+    # ---- outside the timed region: per-phase device times (HIP events on the launch stream = torch's current stream) ----
+    def timed(fn, n):
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for a_, b_ in ev:
+            a_.record(); fn(); b_.record()
+        torch.cuda.synchronize()
+        return float(np.median([a_.elapsed_time(b_) for a_, b_ in ev]))
+
+    m = tr._hip_marcher()
+    vol = tr.headpose_skin_net.current_volume()
+    n_ev = max(3, min(args.steps, 10))
+    with torch.no_grad():
+        kern_ms = timed(lambda: m.render(rays, bg, poses[0], vol, S_C, S_F, perturb=perturb), n_ev)
+        prep_ms = timed(lambda: m.set_triplane(tr.model_coarse.triPlane_embeddings), n_ev)
+        enc_ms = timed(lambda: tr.model_coarse.set_conditional_embedding(
+            front_render_cond=front, left_render_cond=left, right_render_cond=right, latents=tr.latent_codes[0:1],
+            cond_c=poses[0].view(1, -1)), n_ev)
+    rm = m
 
     if rank == 0:
         res = {
             "metric": "rendered frames/sec @512^2, 64 samples/ray", "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "cfg2: one 512x512 frame per GPU per step = 262144 rays x (64 coarse + 48 fine) = 29.36M "
-                                   "radiance-MLP queries; ray sampling + skinning lookup + tri-plane gather + PE + MLP + compositing + "
-                                   "resampling in one launch (P5-P12); tri-plane/skin volume/MLP resident in HBM, tri-plane "
-                                   "re-laid out per frame inside the step; tri-plane encoders (P3, MIOpen convs) not in the step",
+            "config": {"workload": "cfg2: Trainer.forward(render_full_img=True) for one 512x512 frame per GPU per step: tri-plane encoders "
+                                   "(P3: 2x StyleGAN_zxc, MIOpen convs + HIP upfirdn2d/fused_bias_act) -> per-frame plane projection -> fused "
+                                   "ray march (P5-P12) over 262144 rays x (64 coarse + 48 fine) = 29.36M radiance-MLP queries -> [1,67,512,512]",
+                       "phase_ms": {"encoders_P3": round(enc_ms, 3), "plane_prepare": round(prep_ms, 3), "ray_march_kernel": round(kern_ms, 3)},
                        "rays_per_frame": H * W, "num_coarse": S_C, "num_fine": S_F, "perturb": perturb,
                        "parallelism": "frames sharded, %d rank(s), no data-path collective" % world,
                        "kernel": rm.variant(S_C, S_F, perturb=perturb)},
