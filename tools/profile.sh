@@ -9,7 +9,7 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 BENCH="python bench.py --steps 8 --warmup 2 --no-cpu-baseline $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $BENCH > $OUT/bench_kt.log 2>&1
-tail -1 $OUT/bench_kt.log > $OUT/bench_line.json
+grep -m1 "^{\"metric\"" $OUT/bench_kt.log > $OUT/bench_line.json
 for pass in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" \
             "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU" \
             "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
@@ -17,4 +17,8 @@ for pass in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY 
   rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/pmc_$n -o pmc -- $BENCH > $OUT/pmc_$n.log 2>&1
 done
 python tools/prof_summary.py $OUT > $OUT/summary.txt 2>&1
+cp $OUT/kt/kt_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
+# keep only the compact artefacts (gpurun copies back <= 64 MiB)
+find $OUT -mindepth 1 -maxdepth 1 -type d -exec rm -r {} +
+rm -f $OUT/*.log
 cat $OUT/summary.txt
