@@ -56,7 +56,8 @@
 #define OFF_B4 (OFF_B2 + 128)                       // [4]  folded rgb biases, alpha bias
 #define OFF_BF (OFF_B4 + 4)                         // [64] fc_rgbFeat bias
 #define OFF_W1F (OFF_BF + 64)                       // [2][128][64] layer-1 plane columns per plane, rows in accumulator order
-#define BLOB_FLOATS (OFF_W1F + 2 * 128 * 64)
+#define OFF_WFF (OFF_W1F + 2 * 128 * 64)             // [64 k-steps][2 row tiles][64 lanes] fc_rgbFeat, fragment order (block kernel epilogue)
+#define BLOB_FLOATS (OFF_WFF + K2_STEPS * 2 * 64)
 
 extern "C" int64_t hav_mlp_blob_bytes(void) { return (int64_t)BLOB_FLOATS * 4; }
 
@@ -97,7 +98,11 @@ __global__ void __launch_bounds__(256) mlp_pack_kernel(float* __restrict__ blob,
             v = (float)s;
         } else v = w.ba[0];
     } else if (e < OFF_W1F) v = w.bf[e - OFF_BF];
-    else {                              // W1F[p][hu][c] = W1[unit(hu)][2c + p]; hu = h*64 + (m*16 + r)
+    else if (e >= OFF_WFF) {
+        const int q = e - OFF_WFF;
+        const int l = q & 63, m = (q >> 6) & 1, ks = q >> 7;
+        v = w.Wf[(32 * m + (l & 31)) * HAV_HID + acc_row(ks >> 4, ks & 15, l >> 5)];
+    } else {                            // W1F[p][hu][c] = W1[unit(hu)][2c + p]; hu = h*64 + (m*16 + r)
         const int q = e - OFF_W1F;
         const int c = q & 63, hu = (q >> 6) & 127, p = q >> 13;
         const int u = hu & 63;
@@ -327,6 +332,201 @@ __device__ __forceinline__ float z_coarse(const MarchArgs& a, long long gr, int 
 }
 
 // ------------------------------------------------------------------------------------------------
+// One sample per lane pair: geometry + skinning field, 8-tap gather of the prepared planes into the layer-1
+// accumulators, PE columns + layer 2 on the matrix cores, head rows on the VALU.
+// Outputs: acc2 = relu(h2) (this half-wave's 64 hidden units), hd0..2 = raw rgb, hd3 = raw density.
+// ------------------------------------------------------------------------------------------------
+struct LaneCtx {
+    const float* sW1; const float* sW2; const float4* sW4;
+    __amdgpu_buffer_rsrc_t wrs;
+    int lane, h, hoff;
+};
+
+#define LDB4(off_floats) __builtin_amdgcn_raw_buffer_load_b128(L.wrs, L.hoff, (off_floats) * 4, 0)
+
+__device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L, int b, float ox, float oy, float oz, float dx,
+                                            float dy, float dz, float z, f32x16 (&acc2)[4], float& hd0, float& hd1, float& hd2,
+                                            float& hd3)
+{
+    const int h = L.h, lane = L.lane;
+    const float* sW1 = L.sW1;
+    const float* sW2 = L.sW2;
+    const float4* sW4 = L.sW4;
+    const int PR = a.p.plane_res, VR = a.p.vol_res;
+    // ---- pts = o + d z; skinning field (model/Skinning_Field.py:77-95): half-wave h evaluates bone h ---------
+    const float px = ox + dx * z, py = oy + dy * z, pz = oz + dz * z;
+    const float* iT = a.inv_T + (size_t)b * 12;
+    const float tx_ = px + iT[9], ty_ = py + iT[10], tz_ = pz + iT[11];
+    const float p1x = tx_ * iT[0] + ty_ * iT[3] + tz_ * iT[6];
+    const float p1y = tx_ * iT[1] + ty_ * iT[4] + tz_ * iT[7];
+    const float p1z = tx_ * iT[2] + ty_ * iT[5] + tz_ * iT[8];
+    float wmine;
+    {
+        const float gx = (h ? p1x : px) * a.p.skin_scale[0] + a.p.skin_trans[0];
+        const float gy = (h ? p1y : py) * a.p.skin_scale[1] + a.p.skin_trans[1];
+        const float gz = (h ? p1z : pz) * a.p.skin_scale[2] + a.p.skin_trans[2];
+        // grid_sample 3-D, border padding, align_corners=True (utils/util.py:409-418)
+        const float lim = (float)(VR - 1);
+        float ix = ((gx + 1.0f) * 0.5f) * lim, iy = ((gy + 1.0f) * 0.5f) * lim, iz = ((gz + 1.0f) * 0.5f) * lim;
+        ix = fminf(fmaxf(ix, 0.f), lim); iy = fminf(fmaxf(iy, 0.f), lim); iz = fminf(fmaxf(iz, 0.f), lim);
+        const float x0f = floorf(ix), y0f = floorf(iy), z0f = floorf(iz);
+        const float fx = ix - x0f, fy = iy - y0f, fz = iz - z0f;
+        const int x0 = (int)x0f, y0 = (int)y0f, z0 = (int)z0f;
+        const int x1 = min(x0 + 1, VR - 1), y1 = min(y0 + 1, VR - 1), z1 = min(z0 + 1, VR - 1);  // weight is 0 when clamped
+        const float* v = a.vol + (size_t)h * VR * VR * VR;
+        float acc = 0.f;
+#pragma unroll
+        for (int cz = 0; cz < 2; ++cz)
+#pragma unroll
+            for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+                for (int cx = 0; cx < 2; ++cx) {
+                    const float wgt = (cx ? fx : 1.0f - fx) * (cy ? fy : 1.0f - fy) * (cz ? fz : 1.0f - fz);
+                    acc += v[((size_t)(cz ? z1 : z0) * VR + (cy ? y1 : y0)) * VR + (cx ? x1 : x0)] * wgt;
+                }
+        wmine = acc;
+    }
+    const float wother = __shfl_xor(wmine, 32, 64);
+    const float w0 = h ? wother : wmine, w1 = h ? wmine : wother;
+    const float den = (w0 + w1) + 1e-8f;
+    const float n0 = w0 / den, n1 = w1 / den;
+    const float qx_ = n0 * px + n1 * p1x, qy_ = n0 * py + n1 * p1y, qz_ = n0 * pz + n1 * p1z;   // p'
+
+    // ---- layer 1 (model/nerf_model.py:104-108): bias + 8 projected tri-plane taps + PE columns on the MFMA ----
+    f32x16 acc1[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const auto bb = LDB4(OFF_B1 + 32 * m + 8 * q);
+            acc1[m][4 * q + 0] = __uint_as_float(bb[0]); acc1[m][4 * q + 1] = __uint_as_float(bb[1]);
+            acc1[m][4 * q + 2] = __uint_as_float(bb[2]); acc1[m][4 * q + 3] = __uint_as_float(bb[3]);
+        }
+    if (!(a.ablate & 1)) {
+        // sample_from_triplane_new (utils/util.py:359-392): plane0 at (x,y), plane1 at (z,y); zeros padding.
+        // Each texel of the prepared planes already carries W1f . texel for this half-wave's 64 hidden units.
+        const float lim = (float)(PR - 1);
+        const float gy = qy_ * a.p.nerf_scale[1] + a.p.nerf_trans[1];
+        const float iy = ((gy + 1.0f) * 0.5f) * lim;
+        float y0f = floorf(iy);
+        const float wy1 = iy - y0f, wy0 = 1.0f - wy1;
+        y0f = fminf(fmaxf(y0f, -2.f), lim + 2.f);
+        const int y0 = (int)y0f, y1 = y0 + 1;
+        const bool vy0 = y0 >= 0 && y0 < PR, vy1 = y1 >= 0 && y1 < PR;
+        const int cy0 = min(max(y0, 0), PR - 1), cy1 = min(max(y1, 0), PR - 1);
+        float tw[8];
+        const float4* tp[8];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            const float gx = pl ? qz_ * a.p.nerf_scale[2] + a.p.nerf_trans[2] : qx_ * a.p.nerf_scale[0] + a.p.nerf_trans[0];
+            const float ix = ((gx + 1.0f) * 0.5f) * lim;
+            float x0f = floorf(ix);
+            const float wx1 = ix - x0f, wx0 = 1.0f - wx1;
+            x0f = fminf(fmaxf(x0f, -2.f), lim + 2.f);
+            const int x0 = (int)x0f, x1 = x0 + 1;
+            const bool vx0 = x0 >= 0 && x0 < PR, vx1 = x1 >= 0 && x1 < PR;
+            const int cx0 = min(max(x0, 0), PR - 1), cx1 = min(max(x1, 0), PR - 1);
+            tw[4 * pl + 0] = (vx0 && vy0) ? wx0 * wy0 : 0.f; tw[4 * pl + 1] = (vx1 && vy0) ? wx1 * wy0 : 0.f;
+            tw[4 * pl + 2] = (vx0 && vy1) ? wx0 * wy1 : 0.f; tw[4 * pl + 3] = (vx1 && vy1) ? wx1 * wy1 : 0.f;
+            const float* plb = a.pplanes + ((size_t)pl * a.p.B + b) * PR * PR * 128 + h * 64;
+            tp[4 * pl + 0] = reinterpret_cast<const float4*>(plb + ((size_t)cy0 * PR + cx0) * 128);
+            tp[4 * pl + 1] = reinterpret_cast<const float4*>(plb + ((size_t)cy0 * PR + cx1) * 128);
+            tp[4 * pl + 2] = reinterpret_cast<const float4*>(plb + ((size_t)cy1 * PR + cx0) * 128);
+            tp[4 * pl + 3] = reinterpret_cast<const float4*>(plb + ((size_t)cy1 * PR + cx1) * 128);
+        }
+        // 8 taps x 256 B per lane, two taps (32 x 16 B) in flight.  The empty asm pins each tap's FMAs before the
+        // loads that recycle its registers: left alone, the compiler hoists all 128 loads and spills them.
+        float4 tv[2][16];
+#pragma unroll
+        for (int c4 = 0; c4 < 16; ++c4) { tv[0][c4] = tp[0][c4]; tv[1][c4] = tp[1][c4]; }
+#pragma unroll
+        for (int tap = 0; tap < 8; ++tap) {
+            const float wt = tw[tap];
+#pragma unroll
+            for (int c4 = 0; c4 < 16; ++c4) {     // slot u = 4*c4+e  <->  accumulator (m = u>>4, r = u&15)
+                const float4 t4 = tv[tap & 1][c4];
+                acc1[c4 >> 2][4 * (c4 & 3) + 0] = fmaf(t4.x, wt, acc1[c4 >> 2][4 * (c4 & 3) + 0]);
+                acc1[c4 >> 2][4 * (c4 & 3) + 1] = fmaf(t4.y, wt, acc1[c4 >> 2][4 * (c4 & 3) + 1]);
+                acc1[c4 >> 2][4 * (c4 & 3) + 2] = fmaf(t4.z, wt, acc1[c4 >> 2][4 * (c4 & 3) + 2]);
+                acc1[c4 >> 2][4 * (c4 & 3) + 3] = fmaf(t4.w, wt, acc1[c4 >> 2][4 * (c4 & 3) + 3]);
+            }
+            asm volatile("" : "+v"(acc1[0]), "+v"(acc1[1]), "+v"(acc1[2]), "+v"(acc1[3]) : : "memory");
+            if (tap + 2 < 8) {
+#pragma unroll
+                for (int c4 = 0; c4 < 16; ++c4) tv[tap & 1][c4] = tp[tap + 2][c4];
+            }
+        }
+    }
+    // ---- PE octaves 4h..4h+3 of this half-wave (model/network/embedder.py:32-61) ---------------------
+    float pe[KPE_STEPS];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const float f = h ? (float)(16 << kk) : (float)(1 << kk);
+        pe_pair(qx_ * f, pe[6 * kk + 0], pe[6 * kk + 3]);
+        pe_pair(qy_ * f, pe[6 * kk + 1], pe[6 * kk + 4]);
+        pe_pair(qz_ * f, pe[6 * kk + 2], pe[6 * kk + 5]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    if (!(a.ablate & 16))
+#pragma unroll
+    for (int t = 0; t < KPE_STEPS; ++t) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            acc1[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(sW1[(t * 4 + m) * 64 + lane], pe[t], acc1[m], 0, 0, 0);
+        if ((t & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[m][r] = fmaxf(acc1[m][r], 0.f);
+
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- layer 2: 128 -> 128, relu; B operands are layer-1 accumulator registers, A fragments from LDS ------
+    #pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const auto bb = LDB4(OFF_B2 + 32 * m + 8 * q);
+            acc2[m][4 * q + 0] = __uint_as_float(bb[0]); acc2[m][4 * q + 1] = __uint_as_float(bb[1]);
+            acc2[m][4 * q + 2] = __uint_as_float(bb[2]); acc2[m][4 * q + 3] = __uint_as_float(bb[3]);
+        }
+    if (!(a.ablate & 32))
+#pragma unroll
+    for (int ks = 0; ks < K2_STEPS; ++ks) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            acc2[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(sW2[(ks * 4 + m) * 64 + lane], acc1[ks >> 4][ks & 15], acc2[m], 0, 0, 0);
+        if ((ks & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[m][r] = fmaxf(acc2[m][r], 0.f);
+
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- head rows rgb(3, folded fc_rgb o fc_rgbFeat) + alpha: 4 dot products over the 128 hidden units.
+    // Each lane holds 64 of its sample's hidden units; the 4 weights per unit are one broadcast ds_read_b128.
+    hd0 = 0.f; hd1 = 0.f; hd2 = 0.f; hd3 = 0.f;
+#pragma unroll
+    for (int mp = 0; mp < 4; ++mp)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float4 w4 = sW4[(mp * 16 + r) * 2 + h];
+            const float v = acc2[mp][r];
+            hd0 = fmaf(v, w4.x, hd0); hd1 = fmaf(v, w4.y, hd1); hd2 = fmaf(v, w4.z, hd2); hd3 = fmaf(v, w4.w, hd3);
+        }
+    hd0 += __shfl_xor(hd0, 32, 64); hd1 += __shfl_xor(hd1, 32, 64);
+    hd2 += __shfl_xor(hd2, 32, 64); hd3 += __shfl_xor(hd3, 32, 64);
+    {
+        const auto b4 = __builtin_amdgcn_raw_buffer_load_b128(L.wrs, 0, OFF_B4 * 4, 0);
+        hd0 += __uint_as_float(b4[0]); hd1 += __uint_as_float(b4[1]); hd2 += __uint_as_float(b4[2]); hd3 += __uint_as_float(b4[3]);
+    }
+
+}
+#undef LDB4
+
+// ------------------------------------------------------------------------------------------------
 // the kernel
 // ------------------------------------------------------------------------------------------------
 #define MARCH_THREADS 512
@@ -376,11 +576,10 @@ __global__ void __launch_bounds__(MARCH_THREADS, 2) hav_march_f32_kernel(const M
 
     const int j = lane & 31, h = lane >> 5, col = lane & 15, rowt = (lane >> 4) & 1;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.blob), 0, BLOB_FLOATS * 4, 0x00020000);
-    const int hoff = h * 16;
-#define LDB4(off_floats) __builtin_amdgcn_raw_buffer_load_b128(wrs, hoff, (off_floats) * 4, 0)
+    LaneCtx L;
+    L.sW1 = sW1; L.sW2 = sW2; L.sW4 = sW4; L.wrs = wrs; L.lane = lane; L.h = h; L.hoff = h * 16;
 
     const int S_c = a.p.S_c, S_fp = a.S_fp;
-    const int PR = a.p.plane_res, VR = a.p.vol_res;
     const long long NR = a.NR;
     const long long npairs = (NR + 1) >> 1;
 
@@ -438,176 +637,9 @@ __global__ void __launch_bounds__(MARCH_THREADS, 2) hav_march_f32_kernel(const M
                 }
                 const float dist = (s + 1 < S) ? (znb - z) : (z - znb);
 
-                // ---- pts = o + d z; skinning field (model/Skinning_Field.py:77-95): half-wave h evaluates bone h ---------
-                const float px = ox + dx * z, py = oy + dy * z, pz = oz + dz * z;
-                const float* iT = a.inv_T + (size_t)b * 12;
-                const float tx_ = px + iT[9], ty_ = py + iT[10], tz_ = pz + iT[11];
-                const float p1x = tx_ * iT[0] + ty_ * iT[3] + tz_ * iT[6];
-                const float p1y = tx_ * iT[1] + ty_ * iT[4] + tz_ * iT[7];
-                const float p1z = tx_ * iT[2] + ty_ * iT[5] + tz_ * iT[8];
-                float wmine;
-                {
-                    const float gx = (h ? p1x : px) * a.p.skin_scale[0] + a.p.skin_trans[0];
-                    const float gy = (h ? p1y : py) * a.p.skin_scale[1] + a.p.skin_trans[1];
-                    const float gz = (h ? p1z : pz) * a.p.skin_scale[2] + a.p.skin_trans[2];
-                    // grid_sample 3-D, border padding, align_corners=True (utils/util.py:409-418)
-                    const float lim = (float)(VR - 1);
-                    float ix = ((gx + 1.0f) * 0.5f) * lim, iy = ((gy + 1.0f) * 0.5f) * lim, iz = ((gz + 1.0f) * 0.5f) * lim;
-                    ix = fminf(fmaxf(ix, 0.f), lim); iy = fminf(fmaxf(iy, 0.f), lim); iz = fminf(fmaxf(iz, 0.f), lim);
-                    const float x0f = floorf(ix), y0f = floorf(iy), z0f = floorf(iz);
-                    const float fx = ix - x0f, fy = iy - y0f, fz = iz - z0f;
-                    const int x0 = (int)x0f, y0 = (int)y0f, z0 = (int)z0f;
-                    const int x1 = min(x0 + 1, VR - 1), y1 = min(y0 + 1, VR - 1), z1 = min(z0 + 1, VR - 1);  // weight is 0 when clamped
-                    const float* v = a.vol + (size_t)h * VR * VR * VR;
-                    float acc = 0.f;
-#pragma unroll
-                    for (int cz = 0; cz < 2; ++cz)
-#pragma unroll
-                        for (int cy = 0; cy < 2; ++cy)
-#pragma unroll
-                            for (int cx = 0; cx < 2; ++cx) {
-                                const float wgt = (cx ? fx : 1.0f - fx) * (cy ? fy : 1.0f - fy) * (cz ? fz : 1.0f - fz);
-                                acc += v[((size_t)(cz ? z1 : z0) * VR + (cy ? y1 : y0)) * VR + (cx ? x1 : x0)] * wgt;
-                            }
-                    wmine = acc;
-                }
-                const float wother = __shfl_xor(wmine, 32, 64);
-                const float w0 = h ? wother : wmine, w1 = h ? wmine : wother;
-                const float den = (w0 + w1) + 1e-8f;
-                const float n0 = w0 / den, n1 = w1 / den;
-                const float qx_ = n0 * px + n1 * p1x, qy_ = n0 * py + n1 * p1y, qz_ = n0 * pz + n1 * p1z;   // p'
-
-                // ---- layer 1 (model/nerf_model.py:104-108): bias + 8 projected tri-plane taps + PE columns on the MFMA ----
-                f32x16 acc1[4];
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const auto bb = LDB4(OFF_B1 + 32 * m + 8 * q);
-                        acc1[m][4 * q + 0] = __uint_as_float(bb[0]); acc1[m][4 * q + 1] = __uint_as_float(bb[1]);
-                        acc1[m][4 * q + 2] = __uint_as_float(bb[2]); acc1[m][4 * q + 3] = __uint_as_float(bb[3]);
-                    }
-                if (!(a.ablate & 1)) {
-                    // sample_from_triplane_new (utils/util.py:359-392): plane0 at (x,y), plane1 at (z,y); zeros padding.
-                    // Each texel of the prepared planes already carries W1f . texel for this half-wave's 64 hidden units.
-                    const float lim = (float)(PR - 1);
-                    const float gy = qy_ * a.p.nerf_scale[1] + a.p.nerf_trans[1];
-                    const float iy = ((gy + 1.0f) * 0.5f) * lim;
-                    float y0f = floorf(iy);
-                    const float wy1 = iy - y0f, wy0 = 1.0f - wy1;
-                    y0f = fminf(fmaxf(y0f, -2.f), lim + 2.f);
-                    const int y0 = (int)y0f, y1 = y0 + 1;
-                    const bool vy0 = y0 >= 0 && y0 < PR, vy1 = y1 >= 0 && y1 < PR;
-                    const int cy0 = min(max(y0, 0), PR - 1), cy1 = min(max(y1, 0), PR - 1);
-                    float tw[8];
-                    const float4* tp[8];
-#pragma unroll
-                    for (int pl = 0; pl < 2; ++pl) {
-                        const float gx = pl ? qz_ * a.p.nerf_scale[2] + a.p.nerf_trans[2] : qx_ * a.p.nerf_scale[0] + a.p.nerf_trans[0];
-                        const float ix = ((gx + 1.0f) * 0.5f) * lim;
-                        float x0f = floorf(ix);
-                        const float wx1 = ix - x0f, wx0 = 1.0f - wx1;
-                        x0f = fminf(fmaxf(x0f, -2.f), lim + 2.f);
-                        const int x0 = (int)x0f, x1 = x0 + 1;
-                        const bool vx0 = x0 >= 0 && x0 < PR, vx1 = x1 >= 0 && x1 < PR;
-                        const int cx0 = min(max(x0, 0), PR - 1), cx1 = min(max(x1, 0), PR - 1);
-                        tw[4 * pl + 0] = (vx0 && vy0) ? wx0 * wy0 : 0.f; tw[4 * pl + 1] = (vx1 && vy0) ? wx1 * wy0 : 0.f;
-                        tw[4 * pl + 2] = (vx0 && vy1) ? wx0 * wy1 : 0.f; tw[4 * pl + 3] = (vx1 && vy1) ? wx1 * wy1 : 0.f;
-                        const float* plb = a.pplanes + ((size_t)pl * a.p.B + b) * PR * PR * 128 + h * 64;
-                        tp[4 * pl + 0] = reinterpret_cast<const float4*>(plb + ((size_t)cy0 * PR + cx0) * 128);
-                        tp[4 * pl + 1] = reinterpret_cast<const float4*>(plb + ((size_t)cy0 * PR + cx1) * 128);
-                        tp[4 * pl + 2] = reinterpret_cast<const float4*>(plb + ((size_t)cy1 * PR + cx0) * 128);
-                        tp[4 * pl + 3] = reinterpret_cast<const float4*>(plb + ((size_t)cy1 * PR + cx1) * 128);
-                    }
-                    // 8 taps x 256 B per lane, two taps (32 x 16 B) in flight.  The empty asm pins each tap's FMAs before the
-                    // loads that recycle its registers: left alone, the compiler hoists all 128 loads and spills them.
-                    float4 tv[2][16];
-#pragma unroll
-                    for (int c4 = 0; c4 < 16; ++c4) { tv[0][c4] = tp[0][c4]; tv[1][c4] = tp[1][c4]; }
-#pragma unroll
-                    for (int tap = 0; tap < 8; ++tap) {
-                        const float wt = tw[tap];
-#pragma unroll
-                        for (int c4 = 0; c4 < 16; ++c4) {     // slot u = 4*c4+e  <->  accumulator (m = u>>4, r = u&15)
-                            const float4 t4 = tv[tap & 1][c4];
-                            acc1[c4 >> 2][4 * (c4 & 3) + 0] = fmaf(t4.x, wt, acc1[c4 >> 2][4 * (c4 & 3) + 0]);
-                            acc1[c4 >> 2][4 * (c4 & 3) + 1] = fmaf(t4.y, wt, acc1[c4 >> 2][4 * (c4 & 3) + 1]);
-                            acc1[c4 >> 2][4 * (c4 & 3) + 2] = fmaf(t4.z, wt, acc1[c4 >> 2][4 * (c4 & 3) + 2]);
-                            acc1[c4 >> 2][4 * (c4 & 3) + 3] = fmaf(t4.w, wt, acc1[c4 >> 2][4 * (c4 & 3) + 3]);
-                        }
-                        asm volatile("" : "+v"(acc1[0]), "+v"(acc1[1]), "+v"(acc1[2]), "+v"(acc1[3]) : : "memory");
-                        if (tap + 2 < 8) {
-#pragma unroll
-                            for (int c4 = 0; c4 < 16; ++c4) tv[tap & 1][c4] = tp[tap + 2][c4];
-                        }
-                    }
-                }
-                // ---- PE octaves 4h..4h+3 of this half-wave (model/network/embedder.py:32-61) ---------------------
-                float pe[KPE_STEPS];
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const float f = h ? (float)(16 << kk) : (float)(1 << kk);
-                    pe_pair(qx_ * f, pe[6 * kk + 0], pe[6 * kk + 3]);
-                    pe_pair(qy_ * f, pe[6 * kk + 1], pe[6 * kk + 4]);
-                    pe_pair(qz_ * f, pe[6 * kk + 2], pe[6 * kk + 5]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-
-                if (!(a.ablate & 16))
-#pragma unroll
-                for (int t = 0; t < KPE_STEPS; ++t) {
-#pragma unroll
-                    for (int m = 0; m < 4; ++m)
-                        acc1[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(sW1[(t * 4 + m) * 64 + lane], pe[t], acc1[m], 0, 0, 0);
-                    if ((t & 7) == 7) __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc1[m][r] = fmaxf(acc1[m][r], 0.f);
-
-                __builtin_amdgcn_sched_barrier(0);
-                // ---- layer 2: 128 -> 128, relu; B operands are layer-1 accumulator registers, A fragments from LDS ------
                 f32x16 acc2[4];
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const auto bb = LDB4(OFF_B2 + 32 * m + 8 * q);
-                        acc2[m][4 * q + 0] = __uint_as_float(bb[0]); acc2[m][4 * q + 1] = __uint_as_float(bb[1]);
-                        acc2[m][4 * q + 2] = __uint_as_float(bb[2]); acc2[m][4 * q + 3] = __uint_as_float(bb[3]);
-                    }
-                if (!(a.ablate & 32))
-#pragma unroll
-                for (int ks = 0; ks < K2_STEPS; ++ks) {
-#pragma unroll
-                    for (int m = 0; m < 4; ++m)
-                        acc2[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(sW2[(ks * 4 + m) * 64 + lane], acc1[ks >> 4][ks & 15], acc2[m], 0, 0, 0);
-                    if ((ks & 7) == 7) __builtin_amdgcn_sched_barrier(0);
-                }
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc2[m][r] = fmaxf(acc2[m][r], 0.f);
-
-                __builtin_amdgcn_sched_barrier(0);
-                // ---- head rows rgb(3, folded fc_rgb o fc_rgbFeat) + alpha: 4 dot products over the 128 hidden units.
-                // Each lane holds 64 of its sample's hidden units; the 4 weights per unit are one broadcast ds_read_b128.
-                float hd0 = 0.f, hd1 = 0.f, hd2 = 0.f, hd3 = 0.f;
-#pragma unroll
-                for (int mp = 0; mp < 4; ++mp)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float4 w4 = sW4[(mp * 16 + r) * 2 + h];
-                        const float v = acc2[mp][r];
-                        hd0 = fmaf(v, w4.x, hd0); hd1 = fmaf(v, w4.y, hd1); hd2 = fmaf(v, w4.z, hd2); hd3 = fmaf(v, w4.w, hd3);
-                    }
-                hd0 += __shfl_xor(hd0, 32, 64); hd1 += __shfl_xor(hd1, 32, 64);
-                hd2 += __shfl_xor(hd2, 32, 64); hd3 += __shfl_xor(hd3, 32, 64);
-                {
-                    const auto b4 = __builtin_amdgcn_raw_buffer_load_b128(wrs, 0, OFF_B4 * 4, 0);
-                    hd0 += __uint_as_float(b4[0]); hd1 += __uint_as_float(b4[1]); hd2 += __uint_as_float(b4[2]); hd3 += __uint_as_float(b4[3]);
-                }
+                float hd0, hd1, hd2, hd3;
+                sample_eval(a, L, b, ox, oy, oz, dx, dy, dz, z, acc2, hd0, hd1, hd2, hd3);
 
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- volume_render_radiance_field (utils/nerf_util.py:28-73) -------------------------------
@@ -783,15 +815,228 @@ __global__ void __launch_bounds__(MARCH_THREADS, 2) hav_march_f32_kernel(const M
 }
 
 // ------------------------------------------------------------------------------------------------
+// Block kernel: a wave owns 32 CONSECUTIVE rays (neighbouring pixels) and walks them through the sample index together:
+// tile = sample s of 32 rays.  Neighbouring rays hit the same texels, so the 64 lanes of every gather load touch a handful
+// of cache lines instead of 64 (the pair kernel's gather is texture-addresser bound), and compositing needs no cross-lane
+// work at all: transmittance, the composited hidden units, colour, depth and opacity are per-lane recurrences over s, summed
+// in the reference's sequential order.  fc_rgbFeat is applied to the composited hidden units on the matrix cores once per
+// 32 rays.  The coarse weights a ray needs for its inverse CDF are parked in that ray's own (not yet written) rgb_fine
+// row; the 16 importance samples per ray live in LDS and are merged with the even coarse depths on the fly.
+// Requires S_c <= 67 when a fine pass is requested (host falls back to the pair kernel otherwise).
+// ------------------------------------------------------------------------------------------------
+template <bool RANDOM>
+__global__ void __launch_bounds__(MARCH_THREADS, 2) hav_march_blk_f32_kernel(const MarchArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const float* sWFF = smem + OFF_WFT;           // fc_rgbFeat fragments live in the WFT slot for this kernel
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* s_n = smem + LDS_FLOATS + wave * a.scr_floats;      // [S_f][32] importance samples of this wave's rays
+    {
+        const float4* src = reinterpret_cast<const float4*>(a.blob);
+        float4* dst = reinterpret_cast<float4*>(smem);
+        for (int i = tid; i < OFF_WFT / 4; i += MARCH_THREADS) dst[i] = src[i];
+        const float4* srcf = reinterpret_cast<const float4*>(a.blob + OFF_WFF);
+        float4* dstf = reinterpret_cast<float4*>(smem + OFF_WFT);
+        for (int i = tid; i < K2_STEPS * 2 * 64 / 4; i += MARCH_THREADS) dstf[i] = srcf[i];
+    }
+    __syncthreads();
+
+    const int j = lane & 31, h = lane >> 5;
+    LaneCtx L;
+    L.sW1 = smem + OFF_W1PE; L.sW2 = smem + OFF_W2; L.sW4 = reinterpret_cast<const float4*>(smem + OFF_W4);
+    L.wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.blob), 0, BLOB_FLOATS * 4, 0x00020000);
+    L.lane = lane; L.h = h; L.hoff = h * 16;
+
+    const int S_c = a.p.S_c, S_f = a.p.S_f, S_fp = a.S_fp, S_half = (S_c + 1) >> 1;
+    const int R = a.p.R;
+    const int bpf = (R + 31) >> 5;                       // blocks per frame: a block never straddles two frames
+    const long long nblk = (long long)bpf * a.p.B;
+
+    long long chunk, base, span;
+    int lb, nbx;
+    if ((gridDim.x & 7) == 0) {
+        chunk = (nblk + 7) >> 3;
+        const int xcd = blockIdx.x & 7;
+        lb = blockIdx.x >> 3; nbx = gridDim.x >> 3;
+        base = chunk * xcd;
+        span = nblk - base; if (span > chunk) span = chunk; if (span < 0) span = 0;
+    } else { base = 0; span = nblk; lb = blockIdx.x; nbx = gridDim.x; }
+
+    for (long long local = (long long)lb * MARCH_WAVES + wave; local < span; local += (long long)nbx * MARCH_WAVES) {
+        const long long blk = base + local;
+        const int b = (int)(blk / bpf);
+        const int r0 = (int)(blk - (long long)b * bpf) * 32 + j;
+        const bool rayok = r0 < R;
+        const long long gr = (long long)b * R + (rayok ? r0 : R - 1);
+        const float* ray = a.rays + gr * a.p.ray_stride;
+        const float ox = ray[0], oy = ray[1], oz = ray[2], dx = ray[3], dy = ray[4], dz = ray[5];
+        const float near = ray[6], far = ray[7];
+        const float dn = sqrtf(dx * dx + dy * dy + dz * dz);
+        float* wpark = a.out.rgb_fine ? a.out.rgb_fine + gr * 67 : nullptr;   // this ray's parking row for w[0..S_c)
+
+        for (int pass = 0; pass < (S_fp > 0 ? 2 : 1); ++pass) {
+            const int S = pass == 0 ? S_c : S_fp;
+            f32x16 hsum[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hsum[m][r] = 0.f;
+            float T = 1.0f, c0 = 0.f, c1 = 0.f, c2 = 0.f, dep = 0.f, accw = 0.f, wmax = 0.f;
+            // merged fine depths are produced on the fly: even coarse depths and the LDS-resident importance samples
+            int ie = 0, ik = 0;
+            float ze = 0.f, nk = 0.f;
+            auto next_fine = [&]() -> float {
+                const bool take_e = (ie < S_half) && (ik >= S_f || ze <= nk);
+                const float v = take_e ? ze : nk;
+                if (take_e) { ++ie; ze = (ie < S_half) ? z_coarse<RANDOM>(a, gr, 2 * ie, near, far) : 3.0e38f; }
+                else { ++ik; nk = (ik < S_f) ? s_n[ik * 32 + j] : 3.0e38f; }
+                return v;
+            };
+            float z, znext;
+            if (pass == 0) { z = z_coarse<RANDOM>(a, gr, 0, near, far); znext = z_coarse<RANDOM>(a, gr, 1, near, far); }
+            else {
+                ze = z_coarse<RANDOM>(a, gr, 0, near, far);
+                nk = s_n[j];
+                z = next_fine(); znext = next_fine();
+            }
+            float dist = znext - z;
+
+            for (int s = 0; s < S; ++s) {
+                f32x16 acc2[4];
+                float hd0, hd1, hd2, hd3;
+                sample_eval(a, L, b, ox, oy, oz, dx, dy, dz, z, acc2, hd0, hd1, hd2, hd3);
+                __builtin_amdgcn_sched_barrier(0);
+                // volume_render_radiance_field (utils/nerf_util.py:28-73), one ray per lane, sequential in s
+                float sg = hd3;
+                if (RANDOM && a.p.noise_std > 0.f) {
+                    const float* nz = pass == 0 ? a.noise_c : a.noise_f;
+                    const float e = nz ? nz[gr * S + s] : rng_normal(a, gr, s, pass == 0 ? STREAM_EPS_C : STREAM_EPS_F);
+                    sg += e * a.p.noise_std;
+                }
+                sg = fmaxf(sg, 0.f);
+                const float alpha = 1.0f - expf(-sg * (dist * dn));
+                const float wgt = alpha * T;                                   // :60, exclusive product
+                T = T * ((1.0f - alpha) + 1e-10f);
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) hsum[m][r] = fmaf(wgt, acc2[m][r], hsum[m][r]);
+                c0 = fmaf(wgt, 1.0f / (1.0f + expf(-hd0)), c0);               // sigmoid on rgb only (:45-46)
+                c1 = fmaf(wgt, 1.0f / (1.0f + expf(-hd1)), c1);
+                c2 = fmaf(wgt, 1.0f / (1.0f + expf(-hd2)), c2);
+                dep = fmaf(wgt, z, dep);
+                accw += wgt;
+                wmax = fmaxf(wmax, wgt);
+                if (pass == 0 && S_fp > 0 && h == 0 && rayok) wpark[s] = wgt;
+                if (pass == 1 && a.dbg_zfine && h == 0 && rayok) a.dbg_zfine[gr * S_fp + s] = z;
+                // advance: dists[-1] repeats dists[-2] (:36-37)
+                z = znext;
+                if (s + 2 < S) {
+                    znext = pass == 0 ? z_coarse<RANDOM>(a, gr, s + 2, near, far) : next_fine();
+                    dist = znext - z;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+
+            // ---- fc_rgbFeat on the composited hidden units: [64 x 128] . [128 x 32 rays] on the matrix cores -------------
+            f32x16 og[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const auto bb = __builtin_amdgcn_raw_buffer_load_b128(L.wrs, L.hoff, (OFF_BF + 32 * m + 8 * q) * 4, 0);
+                    og[m][4 * q + 0] = __uint_as_float(bb[0]) * accw; og[m][4 * q + 1] = __uint_as_float(bb[1]) * accw;   // bf * sum_s w_s
+                    og[m][4 * q + 2] = __uint_as_float(bb[2]) * accw; og[m][4 * q + 3] = __uint_as_float(bb[3]) * accw;
+                }
+#pragma unroll
+            for (int ks = 0; ks < K2_STEPS; ++ks) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    og[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(sWFF[(ks * 2 + m) * 64 + lane], hsum[ks >> 4][ks & 15], og[m], 0, 0, 0);
+            }
+            if (rayok) {
+                float* rgb = (pass == 0 ? a.out.rgb_coarse : a.out.rgb_fine) + gr * 67;
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rgb[3 + acc_row(m, r, h)] = og[m][r];
+                if (h == 0) {
+                    const float bgx = a.bg ? a.bg[gr * 3 + 0] : 0.f, bgy = a.bg ? a.bg[gr * 3 + 1] : 0.f, bgz = a.bg ? a.bg[gr * 3 + 2] : 0.f;
+                    rgb[0] = a.bg ? c0 + (1.0f - accw) * bgx : c0;              // :70-71
+                    rgb[1] = a.bg ? c1 + (1.0f - accw) * bgy : c1;
+                    rgb[2] = a.bg ? c2 + (1.0f - accw) * bgz : c2;
+                    (pass == 0 ? a.out.depth_coarse : a.out.depth_fine)[gr] = dep;
+                    (pass == 0 ? a.out.acc_coarse : a.out.acc_fine)[gr] = accw;
+                    if (pass == 1 || S_fp == 0) a.out.weights_max[gr] = wmax;  // model/nerf_trainer.py:195,200
+                }
+            }
+
+            // ---- inverse-CDF resampling (utils/nerf_util.py:76-117): one ray per lane, one sequential sweep over the CDF ----
+            if (pass == 0 && S_fp > 0) {
+                const int nw = S_c - 2, nb = S_c - 1;
+                float sum = 0.f;
+                for (int i = 0; i < nw; ++i) sum += (wpark[1 + i] + 1e-5f);
+                float run = 0.f, cdf_lo = 0.f;
+                int k = 0;
+                auto u_of = [&](int kk) -> float {
+                    if (!RANDOM || !a.p.perturb) {
+                        const float st = 1.0f / (float)(S_f - 1);
+                        return (S_f == 1) ? 0.f : ((kk < S_f / 2) ? st * (float)kk : 1.0f - st * (float)(S_f - 1 - kk));
+                    }
+                    const float zeta = a.u_rand ? a.u_rand[gr * S_f + kk] : rng_uniform(a, gr, kk, STREAM_ZETA);
+                    const float sN = (float)(1.0 / (double)S_f);
+                    return (float)kk * sN + zeta * (float)(1.0 / (double)S_f - 1e-6);
+                };
+                float u = u_of(0);
+                for (int i = 0; i < nw; ++i) {
+                    run += (wpark[1 + i] + 1e-5f) / sum;
+                    const float cdf_hi = run;
+                    while (k < S_f && u < cdf_hi) {          // cdf[i] <= u < cdf[i+1]: below = i, above = i+1
+                        float dnm = cdf_hi - cdf_lo;
+                        if (dnm < 1e-5f) dnm = 1.0f;
+                        const float tt = (u - cdf_lo) / dnm;
+                        const float zi = z_coarse<RANDOM>(a, gr, i, near, far), zi1 = z_coarse<RANDOM>(a, gr, i + 1, near, far);
+                        const float zi2 = z_coarse<RANDOM>(a, gr, i + 2, near, far);
+                        const float bl = 0.5f * (zi1 + zi), ba = 0.5f * (zi2 + zi1);
+                        if (h == 0) s_n[k * 32 + j] = bl + tt * (ba - bl);
+                        ++k;
+                        u = (k < S_f) ? u_of(k) : 0.f;
+                    }
+                    cdf_lo = cdf_hi;
+                }
+                if (k < S_f) {                               // u >= cdf[nb-1]: below = above = nb-1 -> the last bin centre
+                    const float zl = 0.5f * (z_coarse<RANDOM>(a, gr, nb, near, far) + z_coarse<RANDOM>(a, gr, nb - 1, near, far));
+                    for (; k < S_f; ++k) if (h == 0) s_n[k * 32 + j] = zl;
+                }
+                wave_lds_sync();
+            }
+        }   // pass
+        wave_lds_sync();
+    }       // blocks
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 static float* g_dbg_zfine = nullptr;
 // test hook: next hav_render_rays call also dumps the merged fine depths [B*R,S_fp] to this device buffer
 extern "C" void hav_debug_set_zfine(float* dev_ptr) { g_dbg_zfine = dev_ptr; }
 
+static bool use_block_kernel(const HavRenderParams* p)
+{
+    const char* e = getenv("HAV_MARCH");                 // "pair" forces the ray-pair kernel (A/B runs)
+    if (e && e[0] == 'p') return false;
+    return p->S_f == 0 || p->S_c <= 67;                   // coarse weights are parked in the 67-float rgb_fine row
+}
+
 extern "C" const char* hav_render_variant(const HavRenderParams* p)
 {
-    return (p && (p->perturb != 0 || p->noise_std > 0.f)) ? "hav_march_f32_kernel<true>" : "hav_march_f32_kernel<false>";
+    if (!p) return "";
+    const bool rnd = p->perturb != 0 || p->noise_std > 0.f;
+    if (use_block_kernel(p)) return rnd ? "hav_march_blk_f32_kernel<true>" : "hav_march_blk_f32_kernel<false>";
+    return rnd ? "hav_march_f32_kernel<true>" : "hav_march_f32_kernel<false>";
 }
 
 extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, const float* bg, const float* inv_T,
@@ -832,10 +1077,26 @@ extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, cons
     const bool random = p->perturb != 0 || p->noise_std > 0.f;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)hav_march_f32_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)hav_march_f32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
+        const void* ks[4] = {(const void*)hav_march_f32_kernel<false>, (const void*)hav_march_f32_kernel<true>,
+                             (const void*)hav_march_blk_f32_kernel<false>, (const void*)hav_march_blk_f32_kernel<true>};
+        for (int i = 0; i < 4; ++i) {
+            hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return (int)e;
+        }
         attr_set = true;
+    }
+    if (use_block_kernel(p)) {
+        a.scr_floats = ((p->S_f > 0 ? p->S_f : 1) * 32 + 3) & ~3;
+        const size_t ldsb = ((size_t)LDS_FLOATS + (size_t)MARCH_WAVES * a.scr_floats) * sizeof(float);
+        if (ldsb > 160 * 1024) return HAV_EUNSUP;
+        const long long nblk = (long long)((p->R + 31) / 32) * p->B;
+        int gridb = hav_num_cus();
+        const long long needb = (nblk + MARCH_WAVES - 1) / MARCH_WAVES;
+        if (needb < gridb) gridb = (int)((needb + 7) / 8 * 8);
+        if (random) hipLaunchKernelGGL(hav_march_blk_f32_kernel<true>, dim3(gridb), dim3(MARCH_THREADS), ldsb, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(hav_march_blk_f32_kernel<false>, dim3(gridb), dim3(MARCH_THREADS), ldsb, (hipStream_t)stream, a);
+        HAV_LAUNCH_CHECK();
+        return 0;
     }
     const long long npairs = (a.NR + 1) / 2;
     int grid = hav_num_cus();
