@@ -294,12 +294,21 @@ struct MarchArgs {
 
 enum { STREAM_XI = 0, STREAM_ZETA = 1, STREAM_EPS_C = 2, STREAM_EPS_F = 3 };
 
+// Uniform [0,1) for the stratified jitter (xi, zeta): counter-based -- a pure function of (seed, call offset, ray, sample,
+// stream) -- built from two murmur3 finalisers over the mixed counter words.  The jitter only needs equidistribution inside a
+// bin, and this is ~25 integer ops where Philox4x32-10 (kept for the Gaussian density noise below) is ~120; the block
+// kernel evaluates one such number per sample on the critical VALU path.
+__device__ __forceinline__ uint32_t fmix32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
 __device__ __forceinline__ float rng_uniform(const MarchArgs& a, long long gr, int s, int stream)
 {
-    uint32_t o[4];
-    philox4x32((uint32_t)gr, (uint32_t)((unsigned long long)gr >> 32), (uint32_t)s,
-               (uint32_t)stream + 16u * (uint32_t)a.p.rng_offset, (uint32_t)a.p.seed, (uint32_t)(a.p.seed >> 32), o);
-    return (float)(o[0] >> 8) * (1.0f / 16777216.0f);
+    uint32_t x = fmix32((uint32_t)gr * 0x9E3779B1u + (uint32_t)a.p.seed);
+    x = fmix32(x ^ ((uint32_t)((unsigned long long)gr >> 32) * 0x7FEB352Du) ^ ((uint32_t)s * 0x846CA68Bu + (uint32_t)stream * 0x632BE5ABu));
+    x = fmix32(x + (uint32_t)(a.p.seed >> 32) + (uint32_t)a.p.rng_offset * 0x68E31DA4u);
+    return (float)(x >> 8) * (1.0f / 16777216.0f);
 }
 __device__ __forceinline__ float rng_normal(const MarchArgs& a, long long gr, int s, int stream)
 {
@@ -344,6 +353,9 @@ struct LaneCtx {
 
 #define LDB4(off_floats) __builtin_amdgcn_raw_buffer_load_b128(L.wrs, L.hoff, (off_floats) * 4, 0)
 
+// GQ = float4 loads per pipeline stage of the gather (two stages in flight): 16 = a whole 256-B tap per stage (128 VGPRs
+// of loads in flight, pair kernel), 8 = half a tap (64 VGPRs; block kernel, which also keeps 64 accumulators alive).
+template <int GQ>
 __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L, int b, float ox, float oy, float oz, float dx,
                                             float dy, float dz, float z, f32x16 (&acc2)[4], float& hd0, float& hd1, float& hd2,
                                             float& hd3)
@@ -436,24 +448,28 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
         }
         // 8 taps x 256 B per lane, two taps (32 x 16 B) in flight.  The empty asm pins each tap's FMAs before the
         // loads that recycle its registers: left alone, the compiler hoists all 128 loads and spills them.
-        float4 tv[2][16];
+        constexpr int NST = 8 * 16 / GQ;          // pipeline stages: stage g covers float4s [(g*GQ)%16, +GQ) of tap (g*GQ)/16
+        float4 tv[2][GQ];
 #pragma unroll
-        for (int c4 = 0; c4 < 16; ++c4) { tv[0][c4] = tp[0][c4]; tv[1][c4] = tp[1][c4]; }
+        for (int c = 0; c < GQ; ++c) { tv[0][c] = tp[0][c]; tv[1][c] = tp[GQ / 16][GQ % 16 + c]; }
 #pragma unroll
-        for (int tap = 0; tap < 8; ++tap) {
+        for (int g = 0; g < NST; ++g) {
+            const int tap = (g * GQ) / 16, c0 = (g * GQ) % 16;
             const float wt = tw[tap];
 #pragma unroll
-            for (int c4 = 0; c4 < 16; ++c4) {     // slot u = 4*c4+e  <->  accumulator (m = u>>4, r = u&15)
-                const float4 t4 = tv[tap & 1][c4];
+            for (int c = 0; c < GQ; ++c) {     // slot u = 4*c4+e  <->  accumulator (m = u>>4, r = u&15)
+                const int c4 = c0 + c;
+                const float4 t4 = tv[g & 1][c];
                 acc1[c4 >> 2][4 * (c4 & 3) + 0] = fmaf(t4.x, wt, acc1[c4 >> 2][4 * (c4 & 3) + 0]);
                 acc1[c4 >> 2][4 * (c4 & 3) + 1] = fmaf(t4.y, wt, acc1[c4 >> 2][4 * (c4 & 3) + 1]);
                 acc1[c4 >> 2][4 * (c4 & 3) + 2] = fmaf(t4.z, wt, acc1[c4 >> 2][4 * (c4 & 3) + 2]);
                 acc1[c4 >> 2][4 * (c4 & 3) + 3] = fmaf(t4.w, wt, acc1[c4 >> 2][4 * (c4 & 3) + 3]);
             }
             asm volatile("" : "+v"(acc1[0]), "+v"(acc1[1]), "+v"(acc1[2]), "+v"(acc1[3]) : : "memory");
-            if (tap + 2 < 8) {
+            if (g + 2 < NST) {
+                const int ntap = ((g + 2) * GQ) / 16, nc0 = ((g + 2) * GQ) % 16;
 #pragma unroll
-                for (int c4 = 0; c4 < 16; ++c4) tv[tap & 1][c4] = tp[tap + 2][c4];
+                for (int c = 0; c < GQ; ++c) tv[g & 1][c] = tp[ntap][nc0 + c];
             }
         }
     }
@@ -639,7 +655,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, 2) hav_march_f32_kernel(const M
 
                 f32x16 acc2[4];
                 float hd0, hd1, hd2, hd3;
-                sample_eval(a, L, b, ox, oy, oz, dx, dy, dz, z, acc2, hd0, hd1, hd2, hd3);
+                sample_eval<16>(a, L, b, ox, oy, oz, dx, dy, dz, z, acc2, hd0, hd1, hd2, hd3);
 
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- volume_render_radiance_field (utils/nerf_util.py:28-73) -------------------------------
@@ -906,7 +922,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, 2) hav_march_blk_f32_kernel(con
             for (int s = 0; s < S; ++s) {
                 f32x16 acc2[4];
                 float hd0, hd1, hd2, hd3;
-                sample_eval(a, L, b, ox, oy, oz, dx, dy, dz, z, acc2, hd0, hd1, hd2, hd3);
+                sample_eval<8>(a, L, b, ox, oy, oz, dx, dy, dz, z, acc2, hd0, hd1, hd2, hd3);
                 __builtin_amdgcn_sched_barrier(0);
                 // volume_render_radiance_field (utils/nerf_util.py:28-73), one ray per lane, sequential in s
                 float sg = hd3;
@@ -990,21 +1006,25 @@ __global__ void __launch_bounds__(MARCH_THREADS, 2) hav_march_blk_f32_kernel(con
                     return (float)kk * sN + zeta * (float)(1.0 / (double)S_f - 1e-6);
                 };
                 float u = u_of(0);
+                // bin centres are carried along the sweep (one coarse depth per bin) so the emission loop, which runs
+                // whenever ANY of the 32 rays emits, stays a handful of instructions
+                float zi = z_coarse<RANDOM>(a, gr, 0, near, far), zi1 = z_coarse<RANDOM>(a, gr, 1, near, far);
+                float zi2 = z_coarse<RANDOM>(a, gr, 2, near, far);
                 for (int i = 0; i < nw; ++i) {
                     run += (wpark[1 + i] + 1e-5f) / sum;
                     const float cdf_hi = run;
+                    const float bl = 0.5f * (zi1 + zi), ba = 0.5f * (zi2 + zi1);
+                    float dnm = cdf_hi - cdf_lo;
+                    if (dnm < 1e-5f) dnm = 1.0f;
                     while (k < S_f && u < cdf_hi) {          // cdf[i] <= u < cdf[i+1]: below = i, above = i+1
-                        float dnm = cdf_hi - cdf_lo;
-                        if (dnm < 1e-5f) dnm = 1.0f;
                         const float tt = (u - cdf_lo) / dnm;
-                        const float zi = z_coarse<RANDOM>(a, gr, i, near, far), zi1 = z_coarse<RANDOM>(a, gr, i + 1, near, far);
-                        const float zi2 = z_coarse<RANDOM>(a, gr, i + 2, near, far);
-                        const float bl = 0.5f * (zi1 + zi), ba = 0.5f * (zi2 + zi1);
                         if (h == 0) s_n[k * 32 + j] = bl + tt * (ba - bl);
                         ++k;
                         u = (k < S_f) ? u_of(k) : 0.f;
                     }
                     cdf_lo = cdf_hi;
+                    zi = zi1; zi1 = zi2;
+                    if (i + 3 < S_c) zi2 = z_coarse<RANDOM>(a, gr, i + 3, near, far);
                 }
                 if (k < S_f) {                               // u >= cdf[nb-1]: below = above = nb-1 -> the last bin centre
                     const float zl = 0.5f * (z_coarse<RANDOM>(a, gr, nb, near, far) + z_coarse<RANDOM>(a, gr, nb - 1, near, far));
