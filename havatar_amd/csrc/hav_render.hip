@@ -57,7 +57,12 @@
 #define OFF_BF (OFF_B4 + 4)                         // [64] fc_rgbFeat bias
 #define OFF_W1F (OFF_BF + 64)                       // [2][128][64] layer-1 plane columns per plane, rows in accumulator order
 #define OFF_WFF (OFF_W1F + 2 * 128 * 64)             // [64 k-steps][2 row tiles][64 lanes] fc_rgbFeat, fragment order (block kernel epilogue)
-#define BLOB_FLOATS (OFF_WFF + K2_STEPS * 2 * 64)
+// split-operand (3 x bf16) fragments for v_mfma_f32_32x32x16_bf16: per (16-wide k chunk, row tile, part hi/mid/lo, lane) 8 bf16
+#define OFF_A1S (OFF_WFF + K2_STEPS * 2 * 64)       // [3 chunks][4][3][64][4 dwords]  layer-1 PE columns
+#define OFF_A2S (OFF_A1S + 3 * 4 * 3 * 64 * 4)      // [8 chunks][4][3][64][4 dwords]  layer 2
+#define OFF_W4S (OFF_A2S + 8 * 4 * 3 * 64 * 4)      // copy of W4 so that [A1S | A2S | W4S] is one contiguous LDS image
+#define LDS3_FLOATS (3 * 4 * 3 * 64 * 4 + 8 * 4 * 3 * 64 * 4 + K2_STEPS * 2 * 4)    // 34304 dwords = 134 KB
+#define BLOB_FLOATS (OFF_W4S + K2_STEPS * 2 * 4)
 
 extern "C" int64_t hav_mlp_blob_bytes(void) { return (int64_t)BLOB_FLOATS * 4; }
 
@@ -98,7 +103,40 @@ __global__ void __launch_bounds__(256) mlp_pack_kernel(float* __restrict__ blob,
             v = (float)s;
         } else v = w.ba[0];
     } else if (e < OFF_W1F) v = w.bf[e - OFF_BF];
-    else if (e >= OFF_WFF) {
+    else if (e >= OFF_W4S) {
+        const int q = e - OFF_W4S;
+        const int c = q & 3, hh = (q >> 2) & 1, ks = q >> 3;
+        const int col = acc_row(ks >> 4, ks & 15, hh);
+        if (c < 3) {
+            double s = 0.0;
+            for (int k = 0; k < 64; ++k) s += (double)w.Wc[c * 64 + k] * (double)w.Wf[k * HAV_HID + col];
+            v = (float)s;
+        } else v = w.Wa[col];
+    } else if (e >= OFF_A1S) {
+        // dword d of lane l holds elements e0 = 2d, e1 = 2d+1 of the lane's 8 k-values; k-value e of half-wave hh in chunk:
+        //   layer 1: PE column 128 + 24 hh + 8 chunk + e ;  layer 2: hidden unit acc_row(chunk>>1, 8 (chunk&1) + e, hh)
+        const bool l2 = e >= OFF_A2S;
+        const int q = e - (l2 ? OFF_A2S : OFF_A1S);
+        const int d = q & 3, l = (q >> 2) & 63, part = (q >> 8) % 3, m = ((q >> 8) / 3) & 3, ch = (q >> 8) / 12;
+        const int row = 32 * m + (l & 31), hh = l >> 5;
+        uint32_t word = 0;
+        for (int t = 0; t < 2; ++t) {
+            const int el = 2 * d + t;
+            const float wv = l2 ? w.W2[row * HAV_HID + acc_row(ch >> 1, 8 * (ch & 1) + el, hh)]
+                                : w.W1[row * HAV_IN + 2 * HAV_PC + 24 * hh + 8 * ch + el];
+            // exact 3-way split, round-to-nearest-even at each level: wv = hi + mid + lo
+            float rem = wv;
+            uint32_t bits = 0;
+            for (int pp = 0; pp <= part; ++pp) {
+                const uint32_t u = __float_as_uint(rem);
+                const uint32_t r = u + 0x7FFFu + ((u >> 16) & 1u);
+                bits = r >> 16;
+                rem = rem - __uint_as_float(bits << 16);
+            }
+            word |= bits << (16 * t);
+        }
+        v = __uint_as_float(word);
+    } else if (e >= OFF_WFF) {
         const int q = e - OFF_WFF;
         const int l = q & 63, m = (q >> 6) & 1, ks = q >> 7;
         v = w.Wf[(32 * m + (l & 31)) * HAV_HID + acc_row(ks >> 4, ks & 15, l >> 5)];
@@ -347,6 +385,7 @@ __device__ __forceinline__ float z_coarse(const MarchArgs& a, long long gr, int 
 // ------------------------------------------------------------------------------------------------
 struct LaneCtx {
     const float* sW1; const float* sW2; const float4* sW4;
+    const uint4* sA1; const uint4* sA2;         // split-bf16 fragments (PREC == 1 kernels)
     __amdgpu_buffer_rsrc_t wrs;
     int lane, h, hoff;
 };
@@ -355,7 +394,62 @@ struct LaneCtx {
 
 // GQ = float4 loads per pipeline stage of the gather (two stages in flight): 16 = a whole 256-B tap per stage (128 VGPRs
 // of loads in flight, pair kernel), 8 = half a tap (64 VGPRs; block kernel, which also keeps 64 accumulators alive).
-template <int GQ>
+typedef short bf16x8_t __attribute__((ext_vector_type(8)));
+
+// 3-way split of two fp32 values into packed bf16 pairs: v = hi + mid + lo exactly (truncation at each level keeps every
+// remainder representable).  v_perm_b32 picks the upper halves of the two words, so no masking is needed for the packing.
+__device__ __forceinline__ void split3(float v0, float v1, uint32_t& ph, uint32_t& pm, uint32_t& pl)
+{
+    const uint32_t u0 = __float_as_uint(v0), u1 = __float_as_uint(v1);
+    ph = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    const float r0 = v0 - __uint_as_float(u0 & 0xFFFF0000u), r1 = v1 - __uint_as_float(u1 & 0xFFFF0000u);
+    const uint32_t a0 = __float_as_uint(r0), a1 = __float_as_uint(r1);
+    pm = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
+    const float q0 = r0 - __uint_as_float(a0 & 0xFFFF0000u), q1 = r1 - __uint_as_float(a1 & 0xFFFF0000u);
+    pl = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+}
+
+// acc[0..3] += W . x over NCH 16-wide k chunks with both operands split hi/mid/lo: the six products whose magnitude is
+// >= 2^-16 of the leading one (hh, hm, mh, hl, lh, mm), smallest first; every bf16 x bf16 product is exact in fp32 and the
+// MFMA accumulates in fp32, so the dropped terms (ml, lm, ll) bound the error at ~2^-23 relative per product -- fp32-sgemm
+// class.  The A fragments of group g+1 (one row tile of one chunk: 3 x ds_read_b128) are requested before the six MFMAs of
+// group g are issued (explicit register double buffer: under this kernel's register pressure the compiler otherwise
+// re-uses one buffer and every group waits out a full LDS round trip).
+template <int NCH, typename GetV>
+__device__ __forceinline__ void mfma_split3(f32x16 (&acc)[4], const uint4* frag /* [NCH][4 m][3 parts][64 lanes] */, int lane, GetV getv)
+{
+    uint4 A[2][3];
+    uint4 bh, bm, bl;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) A[0][q] = frag[q * 64 + lane];
+#pragma unroll
+    for (int g = 0; g < NCH * 4; ++g) {
+        const int m = g & 3, ch = g >> 2;
+        if (m == 0) {
+            float v[8];
+            getv(ch, v);
+            split3(v[0], v[1], bh.x, bm.x, bl.x); split3(v[2], v[3], bh.y, bm.y, bl.y);
+            split3(v[4], v[5], bh.z, bm.z, bl.z); split3(v[6], v[7], bh.w, bm.w, bl.w);
+        }
+        if (g + 1 < NCH * 4) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) A[(g + 1) & 1][q] = frag[((g + 1) * 3 + q) * 64 + lane];
+        }
+        const bf16x8_t xh = __builtin_bit_cast(bf16x8_t, bh), xm = __builtin_bit_cast(bf16x8_t, bm), xl = __builtin_bit_cast(bf16x8_t, bl);
+        const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, A[g & 1][0]), am = __builtin_bit_cast(bf16x8_t, A[g & 1][1]);
+        const bf16x8_t al = __builtin_bit_cast(bf16x8_t, A[g & 1][2]);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh, acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl, acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, xm, acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, xh, acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xm, acc[m], 0, 0, 0);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh, acc[m], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// PREC = 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  PREC = 1: split-operand bf16 MFMA (3 x bf16 per operand, 6 products).
+template <int GQ, int PREC>
 __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L, int b, float ox, float oy, float oz, float dx,
                                             float dy, float dz, float z, f32x16 (&acc2)[4], float& hd0, float& hd1, float& hd2,
                                             float& hd3)
@@ -484,7 +578,12 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    if (!(a.ablate & 16))
+    if (PREC == 1) {
+        mfma_split3<3>(acc1, L.sA1, lane, [&](int c, float (&v)[8]) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = pe[8 * c + e];
+        });
+    } else if (!(a.ablate & 16))
 #pragma unroll
     for (int t = 0; t < KPE_STEPS; ++t) {
 #pragma unroll
@@ -507,7 +606,12 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
             acc2[m][4 * q + 0] = __uint_as_float(bb[0]); acc2[m][4 * q + 1] = __uint_as_float(bb[1]);
             acc2[m][4 * q + 2] = __uint_as_float(bb[2]); acc2[m][4 * q + 3] = __uint_as_float(bb[3]);
         }
-    if (!(a.ablate & 32))
+    if (PREC == 1) {
+        mfma_split3<8>(acc2, L.sA2, lane, [&](int ch, float (&v)[8]) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = acc1[ch >> 1][8 * (ch & 1) + e];
+        });
+    } else if (!(a.ablate & 32))
 #pragma unroll
     for (int ks = 0; ks < K2_STEPS; ++ks) {
 #pragma unroll
@@ -655,7 +759,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, 2) hav_march_f32_kernel(const M
 
                 f32x16 acc2[4];
                 float hd0, hd1, hd2, hd3;
-                sample_eval<16>(a, L, b, ox, oy, oz, dx, dy, dz, z, acc2, hd0, hd1, hd2, hd3);
+                sample_eval<16, 0>(a, L, b, ox, oy, oz, dx, dy, dz, z, acc2, hd0, hd1, hd2, hd3);
 
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- volume_render_radiance_field (utils/nerf_util.py:28-73) -------------------------------
@@ -840,16 +944,21 @@ __global__ void __launch_bounds__(MARCH_THREADS, 2) hav_march_f32_kernel(const M
 // row; the 16 importance samples per ray live in LDS and are merged with the even coarse depths on the fly.
 // Requires S_c <= 67 when a fine pass is requested (host falls back to the pair kernel otherwise).
 // ------------------------------------------------------------------------------------------------
-template <bool RANDOM>
-__global__ void __launch_bounds__(MARCH_THREADS, 2) hav_march_blk_f32_kernel(const MarchArgs a)
+template <bool RANDOM, int PREC>
+__global__ void __launch_bounds__(MARCH_THREADS, 2) hav_march_blk_kernel(const MarchArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const float* sWFF = smem + OFF_WFT;           // fc_rgbFeat fragments live in the WFT slot for this kernel
+    constexpr int WLDS = PREC == 1 ? LDS3_FLOATS : LDS_FLOATS;     // LDS image: fp32 fragments | split-bf16 fragments
+    const float* sWFF = smem + OFF_WFT;           // PREC 0: fc_rgbFeat fragments live in the WFT slot (PREC 1 streams them from L2)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* s_n = smem + LDS_FLOATS + wave * a.scr_floats;      // [S_f][32] importance samples of this wave's rays
-    {
+    float* s_n = smem + WLDS + wave * a.scr_floats;      // [S_f][32] importance samples of this wave's rays
+    if (PREC == 1) {
+        const float4* src = reinterpret_cast<const float4*>(a.blob + OFF_A1S);
+        float4* dst = reinterpret_cast<float4*>(smem);
+        for (int i = tid; i < LDS3_FLOATS / 4; i += MARCH_THREADS) dst[i] = src[i];
+    } else {
         const float4* src = reinterpret_cast<const float4*>(a.blob);
         float4* dst = reinterpret_cast<float4*>(smem);
         for (int i = tid; i < OFF_WFT / 4; i += MARCH_THREADS) dst[i] = src[i];
@@ -861,7 +970,9 @@ __global__ void __launch_bounds__(MARCH_THREADS, 2) hav_march_blk_f32_kernel(con
 
     const int j = lane & 31, h = lane >> 5;
     LaneCtx L;
-    L.sW1 = smem + OFF_W1PE; L.sW2 = smem + OFF_W2; L.sW4 = reinterpret_cast<const float4*>(smem + OFF_W4);
+    L.sW1 = smem + OFF_W1PE; L.sW2 = smem + OFF_W2;
+    L.sW4 = reinterpret_cast<const float4*>(smem + (PREC == 1 ? (OFF_W4S - OFF_A1S) : OFF_W4));
+    L.sA1 = reinterpret_cast<const uint4*>(smem); L.sA2 = reinterpret_cast<const uint4*>(smem + (OFF_A2S - OFF_A1S));
     L.wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.blob), 0, BLOB_FLOATS * 4, 0x00020000);
     L.lane = lane; L.h = h; L.hoff = h * 16;
 
@@ -922,7 +1033,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, 2) hav_march_blk_f32_kernel(con
             for (int s = 0; s < S; ++s) {
                 f32x16 acc2[4];
                 float hd0, hd1, hd2, hd3;
-                sample_eval<8>(a, L, b, ox, oy, oz, dx, dy, dz, z, acc2, hd0, hd1, hd2, hd3);
+                sample_eval<8, PREC>(a, L, b, ox, oy, oz, dx, dy, dz, z, acc2, hd0, hd1, hd2, hd3);
                 __builtin_amdgcn_sched_barrier(0);
                 // volume_render_radiance_field (utils/nerf_util.py:28-73), one ray per lane, sequential in s
                 float sg = hd3;
@@ -966,11 +1077,33 @@ __global__ void __launch_bounds__(MARCH_THREADS, 2) hav_march_blk_f32_kernel(con
                     og[m][4 * q + 0] = __uint_as_float(bb[0]) * accw; og[m][4 * q + 1] = __uint_as_float(bb[1]) * accw;   // bf * sum_s w_s
                     og[m][4 * q + 2] = __uint_as_float(bb[2]) * accw; og[m][4 * q + 3] = __uint_as_float(bb[3]) * accw;
                 }
+            if (PREC == 1) {          // fragments stream from L2 (once per 32 rays per pass), 8 k-steps in flight
+                float wf[2][16];
 #pragma unroll
-            for (int ks = 0; ks < K2_STEPS; ++ks) {
+                for (int u = 0; u < 16; ++u) wf[0][u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(L.wrs, lane * 4, (OFF_WFF + u * 64) * 4, 0));
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
-                    og[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(sWFF[(ks * 2 + m) * 64 + lane], hsum[ks >> 4][ks & 15], og[m], 0, 0, 0);
+                for (int g = 0; g < 8; ++g) {
+                    if (g + 1 < 8) {
+#pragma unroll
+                        for (int u = 0; u < 16; ++u)
+                            wf[(g + 1) & 1][u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(L.wrs, lane * 4, (OFF_WFF + ((g + 1) * 16 + u) * 64) * 4, 0));
+                    }
+#pragma unroll
+                    for (int kq = 0; kq < 8; ++kq) {
+                        const int ks = g * 8 + kq;
+#pragma unroll
+                        for (int m = 0; m < 2; ++m)
+                            og[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[g & 1][kq * 2 + m], hsum[ks >> 4][ks & 15], og[m], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < K2_STEPS; ++ks) {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+                        og[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(sWFF[(ks * 2 + m) * 64 + lane], hsum[ks >> 4][ks & 15], og[m], 0, 0, 0);
+                }
             }
             if (rayok) {
                 float* rgb = (pass == 0 ? a.out.rgb_coarse : a.out.rgb_fine) + gr * 67;
@@ -1051,11 +1184,20 @@ static bool use_block_kernel(const HavRenderParams* p)
     return p->S_f == 0 || p->S_c <= 67;                   // coarse weights are parked in the 67-float rgb_fine row
 }
 
+static bool use_split_mfma()
+{
+    const char* e = getenv("HAV_MLP");                   // "f32" forces the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)
+    return !(e && e[0] == 'f');
+}
+
 extern "C" const char* hav_render_variant(const HavRenderParams* p)
 {
     if (!p) return "";
     const bool rnd = p->perturb != 0 || p->noise_std > 0.f;
-    if (use_block_kernel(p)) return rnd ? "hav_march_blk_f32_kernel<true>" : "hav_march_blk_f32_kernel<false>";
+    if (use_block_kernel(p)) {
+        if (use_split_mfma()) return rnd ? "hav_march_blk_kernel<true, 1>" : "hav_march_blk_kernel<false, 1>";
+        return rnd ? "hav_march_blk_kernel<true, 0>" : "hav_march_blk_kernel<false, 0>";
+    }
     return rnd ? "hav_march_f32_kernel<true>" : "hav_march_f32_kernel<false>";
 }
 
@@ -1097,9 +1239,10 @@ extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, cons
     const bool random = p->perturb != 0 || p->noise_std > 0.f;
     static bool attr_set = false;
     if (!attr_set) {
-        const void* ks[4] = {(const void*)hav_march_f32_kernel<false>, (const void*)hav_march_f32_kernel<true>,
-                             (const void*)hav_march_blk_f32_kernel<false>, (const void*)hav_march_blk_f32_kernel<true>};
-        for (int i = 0; i < 4; ++i) {
+        const void* ks[6] = {(const void*)hav_march_f32_kernel<false>, (const void*)hav_march_f32_kernel<true>,
+                             (const void*)hav_march_blk_kernel<false, 0>, (const void*)hav_march_blk_kernel<true, 0>,
+                             (const void*)hav_march_blk_kernel<false, 1>, (const void*)hav_march_blk_kernel<true, 1>};
+        for (int i = 0; i < 6; ++i) {
             hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return (int)e;
         }
@@ -1107,14 +1250,20 @@ extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, cons
     }
     if (use_block_kernel(p)) {
         a.scr_floats = ((p->S_f > 0 ? p->S_f : 1) * 32 + 3) & ~3;
-        const size_t ldsb = ((size_t)LDS_FLOATS + (size_t)MARCH_WAVES * a.scr_floats) * sizeof(float);
+        const bool split = use_split_mfma();
+        const size_t ldsb = ((size_t)(split ? LDS3_FLOATS : LDS_FLOATS) + (size_t)MARCH_WAVES * a.scr_floats) * sizeof(float);
         if (ldsb > 160 * 1024) return HAV_EUNSUP;
         const long long nblk = (long long)((p->R + 31) / 32) * p->B;
         int gridb = hav_num_cus();
         const long long needb = (nblk + MARCH_WAVES - 1) / MARCH_WAVES;
         if (needb < gridb) gridb = (int)((needb + 7) / 8 * 8);
-        if (random) hipLaunchKernelGGL(hav_march_blk_f32_kernel<true>, dim3(gridb), dim3(MARCH_THREADS), ldsb, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL(hav_march_blk_f32_kernel<false>, dim3(gridb), dim3(MARCH_THREADS), ldsb, (hipStream_t)stream, a);
+        if (split) {
+            if (random) hipLaunchKernelGGL((hav_march_blk_kernel<true, 1>), dim3(gridb), dim3(MARCH_THREADS), ldsb, (hipStream_t)stream, a);
+            else hipLaunchKernelGGL((hav_march_blk_kernel<false, 1>), dim3(gridb), dim3(MARCH_THREADS), ldsb, (hipStream_t)stream, a);
+        } else {
+            if (random) hipLaunchKernelGGL((hav_march_blk_kernel<true, 0>), dim3(gridb), dim3(MARCH_THREADS), ldsb, (hipStream_t)stream, a);
+            else hipLaunchKernelGGL((hav_march_blk_kernel<false, 0>), dim3(gridb), dim3(MARCH_THREADS), ldsb, (hipStream_t)stream, a);
+        }
         HAV_LAUNCH_CHECK();
         return 0;
     }
