@@ -23,6 +23,11 @@ FLOP_PER_QUERY = 2 * (176 * 128 + 128 * 128 + 128 * 1 + 128 * 64 + 64 * 3)      
 FLOP_PER_FRAME = FLOP_PER_QUERY * Q_PER_RAY * H * W     # 2.7848e12
 BYTES_PER_FRAME = 600 * H * W + 8388608 + 2097152 + 190992   # compulsory HBM bytes
 PEAK_FP32_MFMA = 157.3e12                               # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA = 2500e12                                # MI355X_MICROARCH.md: bf16 MFMA, dense
+DTYPE = {False: "f32 (3 x bf16 split-operand MFMA, fp32 accumulate; fp32-sgemm-class results)", True: "f32"}
+# matrix-core work the kernel actually executes per 32-sample tile: 11 k-chunks x 4 row tiles x 6 products of
+# v_mfma_f32_32x32x16_bf16 (32768 FLOP each), or 352 v_mfma_f32_32x32x2_f32 (4096 FLOP each) in the exact-fp32 mode
+EXEC_FLOP_PER_TILE = {False: 264 * 32768, True: 352 * 4096}
 
 
 def cpu_baseline(sc, rows, threads):
@@ -49,6 +54,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="image rows timed on the CPU (0 = auto, ~15 s)")
     ap.add_argument("--perturb", type=int, default=1, help="stratified jitter on (reference default for inference)")
+    ap.add_argument("--graph", type=int, default=1, help="replay the frame as one hipGraph (0 = eager launches)")
     args = ap.parse_args()
 
     import numpy as np
@@ -61,6 +67,7 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    torch.backends.cudnn.benchmark = True                      # MIOpen: pick the fastest solver per conv shape during warm-up
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -91,10 +98,18 @@ def main():
     poses = [t(synth.frame_pose((rank + world * i) % 64))[None] for i in range(8)]
     perturb = bool(args.perturb)
 
-    def step(i):
-        with torch.no_grad():
-            return tr(ray_batch=rays, background_prior=bg, inv_head_T=poses[i % len(poses)], front_render_cond=front,
-                      left_render_cond=left, right_render_cond=right, mode="validation", fidx=[0], render_full_img=True)
+    data = dict(ray_batch=rays, background_prior=bg, inv_head_T=poses[0], front_render_cond=front, left_render_cond=left,
+                right_render_cond=right, mode="validation", fidx=0, render_full_img=True)
+    if args.graph:
+        from havatar_amd.graph import GraphedForward
+        frame = GraphedForward(tr, data)                       # the whole frame = one hipGraph launch (+ the pose copy)
+
+        def step(i):
+            return frame(inv_head_T=poses[i % len(poses)])
+    else:
+        def step(i):
+            with torch.no_grad():
+                return tr(**{**data, "inv_head_T": poses[i % len(poses)]})
 
     for i in range(args.warmup):
         step(i)
@@ -135,21 +150,28 @@ def main():
             cond_c=poses[0].view(1, -1)), n_ev)
     rm = m
 
+    F32 = os.environ.get("HAVATAR_MLP", "split") == "f32"
     if rank == 0:
         res = {
             "metric": "rendered frames/sec @512^2, 64 samples/ray", "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[os.environ.get("HAVATAR_MLP", "split") == "f32"], "data": "synthetic",
             "config": {"workload": "cfg2: Trainer.forward(render_full_img=True) for one 512x512 frame per GPU per step: tri-plane encoders "
                                    "(P3: 2x StyleGAN_zxc, MIOpen convs + HIP upfirdn2d/fused_bias_act) -> per-frame plane projection -> fused "
                                    "ray march (P5-P12) over 262144 rays x (64 coarse + 48 fine) = 29.36M radiance-MLP queries -> [1,67,512,512]",
                        "phase_ms": {"encoders_P3": round(enc_ms, 3), "plane_prepare": round(prep_ms, 3), "ray_march_kernel": round(kern_ms, 3)},
-                       "rays_per_frame": H * W, "num_coarse": S_C, "num_fine": S_F, "perturb": perturb,
+                       "rays_per_frame": H * W, "num_coarse": S_C, "num_fine": S_F, "perturb": perturb, "hipgraph": bool(args.graph),
                        "parallelism": "frames sharded, %d rank(s), no data-path collective" % world,
                        "kernel": rm.variant(S_C, S_F, perturb=perturb)},
             "roofline": {"bound": "mfma", "achieved": round(FLOP_PER_FRAME / (kern_ms * 1e-3) / 1e12, 3), "peak": PEAK_FP32_MFMA / 1e12,
                          "unit": "TFLOP/s", "frac": round(FLOP_PER_FRAME / (kern_ms * 1e-3) / PEAK_FP32_MFMA, 4), "traffic": None,
                          "kernel_ms": round(kern_ms, 3), "flop_per_launch": FLOP_PER_FRAME,
+                         "note": "achieved = ALGORITHMIC fp32 FLOP of the reference network (94848/query) / kernel time, against the fp32 "
+                                 "MFMA peak; the kernel removes 52% of that work by linearity (DESIGN.md 3.3) and, in split mode, runs the "
+                                 "rest on bf16 MFMA, so frac > 1 is expected",
+                         "mfma_executed_TFLOPs": round(EXEC_FLOP_PER_TILE[F32] * (H * W * Q_PER_RAY // 32) / (kern_ms * 1e-3) / 1e12, 2),
+                         "mfma_executed_frac_of_peak": round(EXEC_FLOP_PER_TILE[F32] * (H * W * Q_PER_RAY // 32) / (kern_ms * 1e-3) /
+                                                             (PEAK_FP32_MFMA if F32 else PEAK_BF16_MFMA), 4),
                          "hbm_algorithmic_bytes_per_launch": BYTES_PER_FRAME,
                          "hbm_achieved_GBps": round(BYTES_PER_FRAME / (kern_ms * 1e-3) / 1e9, 2), "hbm_frac_of_8TBps": round(BYTES_PER_FRAME / (kern_ms * 1e-3) / 8e12, 5)},
         }

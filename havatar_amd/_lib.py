@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libhavatar_hip.so")
 
 HAV_F32, HAV_F16, HAV_BF16, HAV_F64 = 0, 1, 2, 3
+HAV_MLP_SPLIT_BF16, HAV_MLP_F32 = 0, 1
 ABI_VERSION = 1
 
 
@@ -18,7 +19,8 @@ class HavRenderParams(C.Structure):
                 ("plane_res", C.c_int32), ("plane_ch", C.c_int32), ("vol_res", C.c_int32),
                 ("nerf_scale", C.c_float * 3), ("nerf_trans", C.c_float * 3),
                 ("skin_scale", C.c_float * 3), ("skin_trans", C.c_float * 3),
-                ("seed", C.c_uint64), ("rng_offset", C.c_uint64)]
+                ("seed", C.c_uint64), ("rng_offset", C.c_uint64), ("mlp_mode", C.c_int32), ("reserved", C.c_int32),
+                ("rng_counter", C.c_void_p)]
 
 
 class HavMlpWeights(C.Structure):

@@ -321,6 +321,7 @@ struct MarchArgs {
     const float* rays; const float* bg; const float* inv_T; const float* planes; const float* vol; const float* blob;
     const float* t_rand; const float* u_rand; const float* noise_c; const float* noise_f;
     HavRenderOut out;
+    unsigned long long rng_base;   // p.rng_offset (+ *p.rng_counter, read on the device)
     int ablate;             // HAV_ABLATE bit mask (timing experiments only; results are wrong when set)
     float* dbg_zfine;       // optional [B*R, S_fp] dump of the merged fine depths (tests)
     long long NR;           // B*R
@@ -331,6 +332,13 @@ struct MarchArgs {
 };
 
 enum { STREAM_XI = 0, STREAM_ZETA = 1, STREAM_EPS_C = 2, STREAM_EPS_F = 3 };
+
+__device__ __forceinline__ unsigned long long rng_off(const MarchArgs& a)
+{
+    return a.p.rng_counter ? a.p.rng_offset + *a.p.rng_counter : a.p.rng_offset;
+}
+
+__global__ void rng_advance_kernel(unsigned long long* c) { *c += 1ull; }
 
 // Uniform [0,1) for the stratified jitter (xi, zeta): counter-based -- a pure function of (seed, call offset, ray, sample,
 // stream) -- built from two murmur3 finalisers over the mixed counter words.  The jitter only needs equidistribution inside a
@@ -345,14 +353,14 @@ __device__ __forceinline__ float rng_uniform(const MarchArgs& a, long long gr, i
 {
     uint32_t x = fmix32((uint32_t)gr * 0x9E3779B1u + (uint32_t)a.p.seed);
     x = fmix32(x ^ ((uint32_t)((unsigned long long)gr >> 32) * 0x7FEB352Du) ^ ((uint32_t)s * 0x846CA68Bu + (uint32_t)stream * 0x632BE5ABu));
-    x = fmix32(x + (uint32_t)(a.p.seed >> 32) + (uint32_t)a.p.rng_offset * 0x68E31DA4u);
+    x = fmix32(x + (uint32_t)(a.p.seed >> 32) + (uint32_t)rng_off(a) * 0x68E31DA4u);
     return (float)(x >> 8) * (1.0f / 16777216.0f);
 }
 __device__ __forceinline__ float rng_normal(const MarchArgs& a, long long gr, int s, int stream)
 {
     uint32_t o[4];
     philox4x32((uint32_t)gr, (uint32_t)((unsigned long long)gr >> 32), (uint32_t)s,
-               (uint32_t)stream + 16u * (uint32_t)a.p.rng_offset, (uint32_t)a.p.seed, (uint32_t)(a.p.seed >> 32), o);
+               (uint32_t)stream + 16u * (uint32_t)rng_off(a), (uint32_t)a.p.seed, (uint32_t)(a.p.seed >> 32), o);
     const float u1 = ((float)(o[0] >> 8) + 1.0f) * (1.0f / 16777216.0f), u2 = (float)(o[1] >> 8) * (1.0f / 16777216.0f);
     return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
 }
@@ -583,13 +591,20 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = pe[8 * c + e];
         });
-    } else if (!(a.ablate & 16))
+    } else if (!(a.ablate & 16)) {
+        float af[2][4];               // explicit double buffer: the A fragments of k-step t+1 are requested before the MFMAs of step t
 #pragma unroll
-    for (int t = 0; t < KPE_STEPS; ++t) {
+        for (int m = 0; m < 4; ++m) af[0][m] = sW1[m * 64 + lane];
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-            acc1[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(sW1[(t * 4 + m) * 64 + lane], pe[t], acc1[m], 0, 0, 0);
-        if ((t & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t < KPE_STEPS; ++t) {
+            if (t + 1 < KPE_STEPS) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) af[(t + 1) & 1][m] = sW1[((t + 1) * 4 + m) * 64 + lane];
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc1[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t & 1][m], pe[t], acc1[m], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -611,13 +626,20 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = acc1[ch >> 1][8 * (ch & 1) + e];
         });
-    } else if (!(a.ablate & 32))
+    } else if (!(a.ablate & 32)) {
+        float af[2][4];
 #pragma unroll
-    for (int ks = 0; ks < K2_STEPS; ++ks) {
+        for (int m = 0; m < 4; ++m) af[0][m] = sW2[m * 64 + lane];
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-            acc2[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(sW2[(ks * 4 + m) * 64 + lane], acc1[ks >> 4][ks & 15], acc2[m], 0, 0, 0);
-        if ((ks & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        for (int ks = 0; ks < K2_STEPS; ++ks) {
+            if (ks + 1 < K2_STEPS) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) af[(ks + 1) & 1][m] = sW2[((ks + 1) * 4 + m) * 64 + lane];
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc2[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks & 1][m], acc1[ks >> 4][ks & 15], acc2[m], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -1184,10 +1206,12 @@ static bool use_block_kernel(const HavRenderParams* p)
     return p->S_f == 0 || p->S_c <= 67;                   // coarse weights are parked in the 67-float rgb_fine row
 }
 
-static bool use_split_mfma()
+static bool use_split_mfma(const HavRenderParams* p)
 {
-    const char* e = getenv("HAV_MLP");                   // "f32" forces the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)
-    return !(e && e[0] == 'f');
+    const char* e = getenv("HAV_MLP");                   // A/B override: "f32" / "split"
+    if (e && e[0] == 'f') return false;
+    if (e && e[0] == 's') return true;
+    return p->mlp_mode != HAV_MLP_F32;
 }
 
 extern "C" const char* hav_render_variant(const HavRenderParams* p)
@@ -1195,7 +1219,7 @@ extern "C" const char* hav_render_variant(const HavRenderParams* p)
     if (!p) return "";
     const bool rnd = p->perturb != 0 || p->noise_std > 0.f;
     if (use_block_kernel(p)) {
-        if (use_split_mfma()) return rnd ? "hav_march_blk_kernel<true, 1>" : "hav_march_blk_kernel<false, 1>";
+        if (use_split_mfma(p)) return rnd ? "hav_march_blk_kernel<true, 1>" : "hav_march_blk_kernel<false, 1>";
         return rnd ? "hav_march_blk_kernel<true, 0>" : "hav_march_blk_kernel<false, 0>";
     }
     return rnd ? "hav_march_f32_kernel<true>" : "hav_march_f32_kernel<false>";
@@ -1211,6 +1235,7 @@ extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, cons
     if (p->plane_ch != HAV_PC) return HAV_EUNSUP;                 // Trainer hard-codes triPlane_feat_dim=64 (nerf_trainer.py:22)
     if (p->plane_res < 2 || p->vol_res < 2) return HAV_EINVAL;
     if (p->S_c > 256 || p->S_f > 128) return HAV_EUNSUP;
+    if (p->reserved != 0 || (p->mlp_mode != HAV_MLP_SPLIT_BF16 && p->mlp_mode != HAV_MLP_F32)) return HAV_EINVAL;
     if (!out->rgb_coarse || !out->depth_coarse || !out->acc_coarse || !out->weights_max) return HAV_EINVAL;
     if (p->S_f > 0 && (!out->rgb_fine || !out->depth_fine || !out->acc_fine)) return HAV_EINVAL;
     if (p->R == 0) return 0;
@@ -1250,7 +1275,7 @@ extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, cons
     }
     if (use_block_kernel(p)) {
         a.scr_floats = ((p->S_f > 0 ? p->S_f : 1) * 32 + 3) & ~3;
-        const bool split = use_split_mfma();
+        const bool split = use_split_mfma(p);
         const size_t ldsb = ((size_t)(split ? LDS3_FLOATS : LDS_FLOATS) + (size_t)MARCH_WAVES * a.scr_floats) * sizeof(float);
         if (ldsb > 160 * 1024) return HAV_EUNSUP;
         const long long nblk = (long long)((p->R + 31) / 32) * p->B;
@@ -1265,6 +1290,7 @@ extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, cons
             else hipLaunchKernelGGL((hav_march_blk_kernel<false, 0>), dim3(gridb), dim3(MARCH_THREADS), ldsb, (hipStream_t)stream, a);
         }
         HAV_LAUNCH_CHECK();
+        if (p->rng_counter && random) { hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)p->rng_counter); HAV_LAUNCH_CHECK(); }
         return 0;
     }
     const long long npairs = (a.NR + 1) / 2;
@@ -1274,6 +1300,7 @@ extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, cons
     if (random) hipLaunchKernelGGL(hav_march_f32_kernel<true>, dim3(grid), dim3(MARCH_THREADS), lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(hav_march_f32_kernel<false>, dim3(grid), dim3(MARCH_THREADS), lds, (hipStream_t)stream, a);
     HAV_LAUNCH_CHECK();
+    if (p->rng_counter && random) { hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)p->rng_counter); HAV_LAUNCH_CHECK(); }
     return 0;
 }
 

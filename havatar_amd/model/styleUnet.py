@@ -21,6 +21,26 @@ from .op import FusedLeakyReLU, conv2d_gradfix, fused_leaky_relu, upfirdn2d
 _CHANNELS = lambda cm: {4: 512, 8: 512, 16: 512, 32: 512, 64: 256 * cm, 128: 128 * cm, 256: 64 * cm, 512: 32 * cm, 1024: 16 * cm}
 
 
+class _InferenceCache:
+    """Weight-only quantities (scale * W, sum_k W^2) are recomputed every call in the reference; at inference (no autograd)
+    they are cached per module and keyed by the parameter's version, which removes ~70 elementwise launches over multi-MB
+    weights from every frame.  Under autograd the cache is bypassed."""
+
+    def _cached(self, name, param, fn):
+        if torch.is_grad_enabled() and param.requires_grad:
+            return fn()
+        key = (param.data_ptr(), param._version, param.device)
+        c = self.__dict__.get("_icache")
+        if c is None:
+            c = self.__dict__["_icache"] = {}
+        hit = c.get(name)
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                hit = (key, fn())
+            c[name] = hit
+        return hit[1]
+
+
 class PixelNorm(nn.Module):
     def forward(self, input):
         return input * torch.rsqrt(torch.mean(input ** 2, dim=1, keepdim=True) + 1e-8)
@@ -72,7 +92,7 @@ class Blur(nn.Module):
         return upfirdn2d(input, self.kernel, pad=self.pad)
 
 
-class EqualConv2d(nn.Module):
+class EqualConv2d(nn.Module, _InferenceCache):
     def __init__(self, in_channel, out_channel, kernel_size, stride=1, padding=0, bias=True):
         super().__init__()
         self.weight = nn.Parameter(torch.randn(out_channel, in_channel, kernel_size, kernel_size))
@@ -81,10 +101,11 @@ class EqualConv2d(nn.Module):
         self.bias = nn.Parameter(torch.zeros(out_channel)) if bias else None
 
     def forward(self, input):
-        return conv2d_gradfix.conv2d(input, self.weight * self.scale, bias=self.bias, stride=self.stride, padding=self.padding)
+        w = self._cached("w", self.weight, lambda: self.weight * self.scale)
+        return conv2d_gradfix.conv2d(input, w, bias=self.bias, stride=self.stride, padding=self.padding)
 
 
-class EqualLinear(nn.Module):
+class EqualLinear(nn.Module, _InferenceCache):
     def __init__(self, in_dim, out_dim, bias=True, bias_init=0, lr_mul=1, activation=None):
         super().__init__()
         self.weight = nn.Parameter(torch.randn(out_dim, in_dim).div_(lr_mul))
@@ -94,12 +115,14 @@ class EqualLinear(nn.Module):
         self.lr_mul = lr_mul
 
     def forward(self, input):
+        w = self._cached("w", self.weight, lambda: self.weight * self.scale)
+        b = self._cached("b", self.bias, lambda: self.bias * self.lr_mul) if self.bias is not None else None
         if self.activation:
-            return fused_leaky_relu(F.linear(input, self.weight * self.scale), self.bias * self.lr_mul)
-        return F.linear(input, self.weight * self.scale, bias=self.bias * self.lr_mul)
+            return fused_leaky_relu(F.linear(input, w), b)
+        return F.linear(input, w, bias=b)
 
 
-class ModulatedConv2d(nn.Module):
+class ModulatedConv2d(nn.Module, _InferenceCache):
     """y = demod_b,o * conv(x * style_b,i , scale * W)   (style = EqualLinear(w), demod = rsqrt(sum (scale W style)^2 + eps))."""
 
     def __init__(self, in_channel, out_channel, kernel_size, style_dim, demodulate=True, upsample=False, downsample=False,
@@ -125,18 +148,20 @@ class ModulatedConv2d(nn.Module):
 
     def forward(self, input, style):
         B, Cin = input.shape[:2]
-        w = self.scale * self.weight[0]                                   # [Cout,Cin,k,k]
+        w = self._cached("w", self.weight, lambda: self.scale * self.weight[0])          # [Cout,Cin,k,k]
         s = self.modulation(style)                                        # [B,Cin]
         x = input * s.view(B, Cin, 1, 1)
         if self.upsample:
-            out = self.blur(conv2d_gradfix.conv_transpose2d(x, w.transpose(0, 1), padding=0, stride=2))
+            wt = self._cached("wt", self.weight, lambda: (self.scale * self.weight[0]).transpose(0, 1).contiguous())
+            out = self.blur(conv2d_gradfix.conv_transpose2d(x, wt, padding=0, stride=2))
         elif self.downsample:
             out = conv2d_gradfix.conv2d(self.blur(x), w, padding=0, stride=2)
         else:
             out = conv2d_gradfix.conv2d(x, w, padding=self.padding)
         if self.demodulate:
             # sum_{i,ky,kx} (w[o,i] s[b,i])^2 = sum_i s[b,i]^2 * sum_k w[o,i,k]^2
-            d = torch.rsqrt(torch.matmul(s * s, w.pow(2).sum((2, 3)).t()) + self.eps)      # [B,Cout]
+            wsq = self._cached("wsq", self.weight, lambda: (self.scale * self.weight[0]).pow(2).sum((2, 3)).t().contiguous())
+            d = torch.rsqrt(torch.matmul(s * s, wsq) + self.eps)                              # [B,Cout]
             out = out * d.view(B, -1, 1, 1)
         return out
 

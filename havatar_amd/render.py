@@ -46,8 +46,10 @@ class RayMarcher:
         self._blob_key = None
         self.planes_cl = None
         self._planes_key = None
+        self.rng_counter = None
         self.rng_offset = 0
         self.seed = 0x9E3779B97F4A7C15
+        self.mlp_mode = _lib.HAV_MLP_F32 if os.environ.get("HAVATAR_MLP", "split") == "f32" else _lib.HAV_MLP_SPLIT_BF16
 
     # -- constants -----------------------------------------------------------------------------
     def set_mlp(self, W1, b1, W2, b2, Wa, ba, Wf, bf, Wc, bc, force=False):
@@ -115,7 +117,10 @@ class RayMarcher:
             p.nerf_scale[i], p.nerf_trans[i] = self.nerf_scale[i], self.nerf_trans[i]
             p.skin_scale[i], p.skin_trans[i] = self.skin_scale[i], self.skin_trans[i]
         p.seed, p.rng_offset = self.seed, self.rng_offset
-        self.rng_offset += 1
+        p.mlp_mode, p.reserved = self.mlp_mode, 0
+        if self.rng_counter is None or self.rng_counter.device != dev:
+            self.rng_counter = torch.zeros(1, dtype=torch.int64, device=dev)      # device-side call counter (graph-replay safe)
+        p.rng_counter = self.rng_counter.data_ptr()
         t_rand = _chk_f32_cuda("t_rand", t_rand, True)
         u_rand = _chk_f32_cuda("u_rand", u_rand, True)
         noise_c = _chk_f32_cuda("noise_c", noise_c, True)
@@ -150,4 +155,5 @@ class RayMarcher:
     def variant(self, S_c, S_f, perturb=False, noise_std=0.0):
         p = _lib.HavRenderParams()
         p.S_c, p.S_f, p.perturb, p.noise_std = S_c, S_f, int(bool(perturb)), float(noise_std)
+        p.mlp_mode = self.mlp_mode
         return _lib.lib().hav_render_variant(C.byref(p)).decode()

@@ -89,9 +89,20 @@ typedef struct HavRenderParams {
     int32_t vol_res;      /* skinning volume D = H = W (64)                                    */
     float   nerf_scale[3], nerf_trans[3];   /* UniformBoxWarp_new of the NeRF box (util.py:232) */
     float   skin_scale[3], skin_trans[3];   /* ... of the skinning box (nerf_trainer.py:29-34)  */
-    uint64_t seed;        /* Philox key for on-device xi/zeta/eps when the rand pointers are NULL */
-    uint64_t rng_offset;  /* Philox counter base (advance per call)                            */
+    uint64_t seed;        /* key of the on-device xi/zeta/eps streams used when the rand pointers are NULL */
+    uint64_t rng_offset;  /* counter base of the on-device streams (advance per call)          */
+    int32_t mlp_mode;     /* HAV_MLP_SPLIT_BF16 (0, default) or HAV_MLP_F32                    */
+    int32_t reserved;     /* must be 0                                                         */
+    uint64_t* rng_counter; /* optional DEVICE counter: the call uses rng_offset + *rng_counter and increments the counter
+                            * on the stream afterwards, so a hipGraph replay of a captured call draws fresh jitter    */
 } HavRenderParams;
+
+/* How the two dense layers run on the matrix cores.  Both produce fp32-sgemm-class results (parity tests run both):
+ *  HAV_MLP_SPLIT_BF16: each fp32 operand is split exactly into 3 bf16 parts and the 6 leading bf16 x bf16 products are
+ *                      accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (error ~2^-23 relative per product);
+ *  HAV_MLP_F32:        v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fmaf chain. */
+#define HAV_MLP_SPLIT_BF16 0
+#define HAV_MLP_F32        1
 
 /* Radiance MLP parameters in nn.Linear layout (model/nerf_model.py:46-51), device pointers. */
 typedef struct HavMlpWeights {
@@ -139,7 +150,8 @@ typedef struct HavRenderOut {      /* all device pointers, float32; fine pointer
  * u_rand    [B*R,S_f] or NULL                   (zeta= torch.rand at utils/nerf_util.py:95)
  * noise_c   [B*R,S_c] / noise_f [B*R,S_fp] or NULL (eps = torch.randn at utils/nerf_util.py:49-56,
  *                                                UNSCALED standard normals; multiplied by noise_std here)
- * With perturb!=0 and a NULL rand pointer the values come from an on-device Philox4x32-10 stream.
+ * With perturb!=0 and a NULL rand pointer the values come from on-device counter-based streams (a murmur-finalizer hash for
+ * the stratified jitter, Philox4x32-10 + Box-Muller for the density noise).
  */
 int hav_render_rays(const HavRenderParams* p, const float* rays, const float* bg,
                     const float* inv_T, const float* planes_prepared, const float* skin_vol,
