@@ -408,13 +408,35 @@ typedef short bf16x8_t __attribute__((ext_vector_type(8)));
 // remainder representable).  v_perm_b32 picks the upper halves of the two words, so no masking is needed for the packing.
 __device__ __forceinline__ void split3(float v0, float v1, uint32_t& ph, uint32_t& pm, uint32_t& pl)
 {
+    typedef float f2 __attribute__((ext_vector_type(2)));
     const uint32_t u0 = __float_as_uint(v0), u1 = __float_as_uint(v1);
     ph = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
-    const float r0 = v0 - __uint_as_float(u0 & 0xFFFF0000u), r1 = v1 - __uint_as_float(u1 & 0xFFFF0000u);
-    const uint32_t a0 = __float_as_uint(r0), a1 = __float_as_uint(r1);
+    const f2 v = {v0, v1};
+    const f2 t = {__uint_as_float(u0 & 0xFFFF0000u), __uint_as_float(u1 & 0xFFFF0000u)};
+    const f2 r = v - t;                                     // one v_pk_add_f32 (exact)
+    const uint32_t a0 = __float_as_uint(r.x), a1 = __float_as_uint(r.y);
     pm = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
-    const float q0 = r0 - __uint_as_float(a0 & 0xFFFF0000u), q1 = r1 - __uint_as_float(a1 & 0xFFFF0000u);
-    pl = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+    const f2 t2 = {__uint_as_float(a0 & 0xFFFF0000u), __uint_as_float(a1 & 0xFFFF0000u)};
+    const f2 q = r - t2;
+    pl = __builtin_amdgcn_perm(__float_as_uint(q.y), __float_as_uint(q.x), 0x07060302u);
+}
+
+// relu of the 4 accumulator tiles of a layer, one instruction per value.  fmaxf(x, 0) on an MFMA result costs two (the
+// compiler first canonicalises the operand with v_max x,x; v_med3(x,0,inf) is folded back to the same pair).  The v_max is
+// therefore issued from inline asm -- and because the compiler pads NO wait states between an MFMA and an asm statement that
+// reads its result (measured: ~1 % of rays corrupted, run to run, with a bare asm v_max), the first statement carries the
+// XDL-write -> VALU-read wait states itself (24 >= the 16-pass requirement) and ties all four tiles to it.
+__device__ __forceinline__ void relu_tiles(f32x16 (&acc)[4])
+{
+    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float x = acc[m][r], y;
+            asm volatile("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
+            acc[m][r] = y;
+        }
 }
 
 // acc[0..3] += W . x over NCH 16-wide k chunks with both operands split hi/mid/lo: the six products whose magnitude is
@@ -423,11 +445,20 @@ __device__ __forceinline__ void split3(float v0, float v1, uint32_t& ph, uint32_
 // class.  The A fragments of group g+1 (one row tile of one chunk: 3 x ds_read_b128) are requested before the six MFMAs of
 // group g are issued (explicit register double buffer: under this kernel's register pressure the compiler otherwise
 // re-uses one buffer and every group waits out a full LDS round trip).
+// WAR hazard on gfx950 (found the hard way, ROCm 7.2): v_mfma_f32_32x32x16_bf16 keeps reading its 4-VGPR A/B operands after
+// issue (the second half of the output columns re-reads them), the compiler does not know, and happily lets the very next
+// VALU instruction recycle an operand register -- ~1 % of rays came out wrong, columns 16-31 of a tile, run to run.
+// KEEP() extends an operand's live range (no instruction is emitted) until the FOLLOWING MFMA has issued, i.e. >= 32 cycles.
+// The accumulator rides along as an in/out operand so that the (otherwise freely movable) empty asm stays between the two
+// MFMAs it separates: the compiler does reorder register-only MFMAs across a plain asm volatile.
+#define KEEP(acc, x) asm volatile("" : "+v"(acc) : "v"(x))
+
 template <int NCH, typename GetV>
 __device__ __forceinline__ void mfma_split3(f32x16 (&acc)[4], const uint4* frag /* [NCH][4 m][3 parts][64 lanes] */, int lane, GetV getv)
 {
     uint4 A[2][3];
     uint4 bh, bm, bl;
+    bf16x8_t pa, pb;                  // operands of the previous group's last MFMA
 #pragma unroll
     for (int q = 0; q < 3; ++q) A[0][q] = frag[q * 64 + lane];
 #pragma unroll
@@ -439,22 +470,30 @@ __device__ __forceinline__ void mfma_split3(f32x16 (&acc)[4], const uint4* frag 
             split3(v[0], v[1], bh.x, bm.x, bl.x); split3(v[2], v[3], bh.y, bm.y, bl.y);
             split3(v[4], v[5], bh.z, bm.z, bl.z); split3(v[6], v[7], bh.w, bm.w, bl.w);
         }
-        if (g + 1 < NCH * 4) {
-#pragma unroll
-            for (int q = 0; q < 3; ++q) A[(g + 1) & 1][q] = frag[((g + 1) * 3 + q) * 64 + lane];
-        }
         const bf16x8_t xh = __builtin_bit_cast(bf16x8_t, bh), xm = __builtin_bit_cast(bf16x8_t, bm), xl = __builtin_bit_cast(bf16x8_t, bl);
         const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, A[g & 1][0]), am = __builtin_bit_cast(bf16x8_t, A[g & 1][1]);
         const bf16x8_t al = __builtin_bit_cast(bf16x8_t, A[g & 1][2]);
         acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh, acc[m], 0, 0, 0);
+        if (g > 0) { KEEP(acc[m], pa); KEEP(acc[m], pb); }
+        if (g + 1 < NCH * 4) {        // next group's fragments go into the buffer whose last reader (group g-1) is long done
+#pragma unroll
+            for (int q = 0; q < 3; ++q) A[(g + 1) & 1][q] = frag[((g + 1) * 3 + q) * 64 + lane];
+        }
         acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl, acc[m], 0, 0, 0);
+        KEEP(acc[m], al);
         acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, xm, acc[m], 0, 0, 0);
+        KEEP(acc[m], xl);
         acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, xh, acc[m], 0, 0, 0);
         acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xm, acc[m], 0, 0, 0);
+        KEEP(acc[m], am);
         acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh, acc[m], 0, 0, 0);
+        KEEP(acc[m], xm);
+        pa = ah; pb = xh;
         __builtin_amdgcn_sched_barrier(0);
     }
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[3]) : "v"(pa), "v"(pb));      // the last MFMA's operands outlive it by 32 wait states
 }
+#undef KEEP
 
 // PREC = 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  PREC = 1: split-operand bf16 MFMA (3 x bf16 per operand, 6 products).
 template <int GQ, int PREC>
@@ -587,6 +626,7 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
     __builtin_amdgcn_sched_barrier(0);
 
     if (PREC == 1) {
+        if (!(a.ablate & 16))
         mfma_split3<3>(acc1, L.sA1, lane, [&](int c, float (&v)[8]) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = pe[8 * c + e];
@@ -606,10 +646,7 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc1[m][r] = fmaxf(acc1[m][r], 0.f);
+    relu_tiles(acc1);
 
     __builtin_amdgcn_sched_barrier(0);
     // ---- layer 2: 128 -> 128, relu; B operands are layer-1 accumulator registers, A fragments from LDS ------
@@ -622,6 +659,7 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
             acc2[m][4 * q + 2] = __uint_as_float(bb[2]); acc2[m][4 * q + 3] = __uint_as_float(bb[3]);
         }
     if (PREC == 1) {
+        if (!(a.ablate & 32))
         mfma_split3<8>(acc2, L.sA2, lane, [&](int ch, float (&v)[8]) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = acc1[ch >> 1][8 * (ch & 1) + e];
@@ -641,23 +679,27 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[m][r] = fmaxf(acc2[m][r], 0.f);
+    relu_tiles(acc2);
 
     __builtin_amdgcn_sched_barrier(0);
     // ---- head rows rgb(3, folded fc_rgb o fc_rgbFeat) + alpha: 4 dot products over the 128 hidden units.
     // Each lane holds 64 of its sample's hidden units; the 4 weights per unit are one broadcast ds_read_b128.
-    hd0 = 0.f; hd1 = 0.f; hd2 = 0.f; hd3 = 0.f;
+    {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 hA = {0.f, 0.f}, hB = {0.f, 0.f};                 // packed FMAs: (rgb0, rgb1) and (rgb2, alpha)
+        if (!(a.ablate & 64))
 #pragma unroll
-    for (int mp = 0; mp < 4; ++mp)
+        for (int mp = 0; mp < 4; ++mp)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float4 w4 = sW4[(mp * 16 + r) * 2 + h];
-            const float v = acc2[mp][r];
-            hd0 = fmaf(v, w4.x, hd0); hd1 = fmaf(v, w4.y, hd1); hd2 = fmaf(v, w4.z, hd2); hd3 = fmaf(v, w4.w, hd3);
-        }
+            for (int r = 0; r < 16; ++r) {
+                const float4 w4 = sW4[(mp * 16 + r) * 2 + h];
+                const float v = acc2[mp][r];
+                const f2 vv = {v, v}, wA = {w4.x, w4.y}, wB = {w4.z, w4.w};
+                hA = __builtin_elementwise_fma(vv, wA, hA);
+                hB = __builtin_elementwise_fma(vv, wB, hB);
+            }
+        hd0 = hA.x; hd1 = hA.y; hd2 = hB.x; hd3 = hB.y;
+    }
     hd0 += __shfl_xor(hd0, 32, 64); hd1 += __shfl_xor(hd1, 32, 64);
     hd2 += __shfl_xor(hd2, 32, 64); hd3 += __shfl_xor(hd3, 32, 64);
     {
@@ -1068,10 +1110,11 @@ __global__ void __launch_bounds__(MARCH_THREADS, 2) hav_march_blk_kernel(const M
                 const float alpha = 1.0f - expf(-sg * (dist * dn));
                 const float wgt = alpha * T;                                   // :60, exclusive product
                 T = T * ((1.0f - alpha) + 1e-10f);
+                {
+                    const f32x16 wv = {wgt, wgt, wgt, wgt, wgt, wgt, wgt, wgt, wgt, wgt, wgt, wgt, wgt, wgt, wgt, wgt};
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) hsum[m][r] = fmaf(wgt, acc2[m][r], hsum[m][r]);
+                    for (int m = 0; m < 4; ++m) hsum[m] = __builtin_elementwise_fma(wv, acc2[m], hsum[m]);   // v_pk_fma_f32
+                }
                 c0 = fmaf(wgt, 1.0f / (1.0f + expf(-hd0)), c0);               // sigmoid on rgb only (:45-46)
                 c1 = fmaf(wgt, 1.0f / (1.0f + expf(-hd1)), c1);
                 c2 = fmaf(wgt, 1.0f / (1.0f + expf(-hd2)), c2);

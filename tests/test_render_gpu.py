@@ -109,6 +109,33 @@ def test_bitwise_reproducible_and_ray_order_invariant():
         assert np.array_equal(a[k][:, perm], c[k]), k
 
 
+@pytest.mark.parametrize("mlp", MLP_MODES)
+def test_full_occupancy_runs_are_bitwise_identical(mlp):
+    """Six launches of a 256x256 frame (every CU busy, thousands of tiles per SIMD) give bit-identical outputs.
+    This is the regression test for the gfx950 MFMA operand WAR hazard: without the operand keep-alives
+    ~1 % of the rays of the split-bf16 kernel differed from run to run, in columns 16-31 of a tile."""
+    import torch
+    from havatar_amd import _lib
+    from havatar_amd.render import RayMarcher
+    N = 256
+    sc = synth.scene(8, 8, "primary")
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
+    rm = RayMarcher(sc["nerf_scale"], sc["nerf_trans"], sc["skin_scale"], sc["skin_trans"])
+    rm.mlp_mode = _lib.HAV_MLP_F32 if mlp == "f32" else _lib.HAV_MLP_SPLIT_BF16
+    rm.set_mlp(*[t(sc["mlp"][k]) for k in ("W1", "b1", "W2", "b2", "Wa", "ba", "Wf", "bf", "Wc", "bc")])
+    rm.set_triplane(t(sc["planes"]))
+    rays = t(synth.camera_rays(N, N))[None]
+    bg = torch.ones(1, N * N, 3, device=dev)
+    args = (rays, bg, t(sc["inv_T"]), t(sc["vol"]), 64, 16)
+    ref = rm.render(*args)
+    for _ in range(5):
+        o = rm.render(*args)
+        torch.cuda.synchronize()
+        for a, b in zip(ref, o):
+            assert torch.equal(a, b)
+
+
 def test_background_linearity_and_ranges():
     """rgb(bg) - rgb(0) == (1-acc)*bg on the 3 colour channels, features unaffected; 0<=acc<=1+eps; sigmoid range."""
     sc = synth.scene(16, 16, "stress")
