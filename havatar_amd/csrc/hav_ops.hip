@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(256) ufd_generic_kernel(T* __restrict__ out, c
 // input footprint is staged once in LDS (coalesced rows), each wave then writes 64-wide row
 // segments (256 B per wave-store for f32).
 template <int UP, int DOWN, int KH, int KW> struct UfdTile {
-    static constexpr int TH = 16, TW = 64;
+    static constexpr int TH = (DOWN == 1) ? 32 : 16, TW = 64, SR = TH / 4;   // SR output rows per thread
     static constexpr int IH = ((TH - 1) * DOWN + KH - 1) / UP + 2;
     static constexpr int IW = ((TW - 1) * DOWN + KW - 1) / UP + 2;
     static constexpr int IWP = IW | 1;    // odd leading dimension: column walks spread over LDS banks
@@ -243,38 +243,71 @@ __global__ void __launch_bounds__(256) ufd_tiled_kernel(T* __restrict__ out, con
     const int Y0 = oy0 * DOWN - a.py0, X0 = ox0 * DOWN - a.px0;
     const int iy_min = floor_div(Y0, UP), ix_min = floor_div(X0, UP);
     const T* plane = in + m * (int64_t)a.in_h * a.in_w;
-    for (int idx = tid; idx < TL::IH * TL::IW; idx += 256) {
-        const int r = idx / TL::IW, c = idx - r * TL::IW;
-        const int iy = iy_min + r, ix = ix_min + c;
-        CT v = (CT)0;
-        if (iy >= 0 && iy < a.in_h && ix >= 0 && ix < a.in_w) v = ld_as<T, CT>(plane + (int64_t)iy * a.in_w + ix);
-        s_in[r * TL::IWP + c] = v;
+    // staging: one tile row per wave per step, lane = column (no index division, row test is wave-uniform)
+    const int lx = tid & 63, sy = tid >> 6;
+    // every global load of the thread is issued before the first LDS write (the staging is latency-bound otherwise:
+    // one round trip per tile row instead of one per tile)
+    constexpr int RPW = (TL::IH + 3) / 4, NCH = (TL::IW + 63) / 64;
+    CT stg[RPW][NCH];
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) {
+        const int r = sy + 4 * q, iy = iy_min + r;
+        const bool row_ok = r < TL::IH && iy >= 0 && iy < a.in_h;
+        const T* src = plane + (int64_t)iy * a.in_w + ix_min;
+#pragma unroll
+        for (int h = 0; h < NCH; ++h) {
+            const int c = h * 64 + lx, ix = ix_min + c;
+            stg[q][h] = (CT)0;
+            if (row_ok && c < TL::IW && ix >= 0 && ix < a.in_w) stg[q][h] = ld_as<T, CT>(src + c);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) {
+        const int r = sy + 4 * q;
+#pragma unroll
+        for (int h = 0; h < NCH; ++h) {
+            const int c = h * 64 + lx;
+            if (r < TL::IH && c < TL::IW) s_in[r * TL::IWP + c] = stg[q][h];
+        }
     }
     __syncthreads();
 
-    const int lx = tid & 63;
+    // Each thread produces a vertical strip of SR outputs (rows SR*sy .. SR*sy+SR-1 of column lx): a staged input value is
+    // read from LDS once and feeds every output row it contributes to, the FIR lives in registers, lanes walk consecutive
+    // columns (conflict-free ds_read_b32, 256-B row-segment stores). Per output the tap order stays (i asc, j asc).
+    constexpr int SR = TL::SR;
     const int ox = ox0 + lx;
-    const int Xb = lx * DOWN + X0 - ix_min * UP;      // zero-stuffed x of tap j=0, relative to the tile origin (>= 0)
-    T* oplane = out + m * (int64_t)a.out_h * a.out_w;
+    const int Xb = lx * DOWN + X0 - ix_min * UP;        // zero-stuffed x of tap j=0, relative to the tile origin (>= 0)
+    const int Yb = (SR * sy) * DOWN + Y0 - iy_min * UP;  // zero-stuffed y of tap i=0 of this strip's first row
+    CT kreg[KH * KW];
 #pragma unroll
-    for (int rr = 0; rr < TL::TH / 4; ++rr) {
-        const int ly = (tid >> 6) + rr * 4;
-        const int oy = oy0 + ly;
-        const int Yb = ly * DOWN + Y0 - iy_min * UP;
-        CT v = (CT)0;
+    for (int q = 0; q < KH * KW; ++q) kreg[q] = s_k[q];
+    CT acc[SR];
 #pragma unroll
-        for (int i = 0; i < KH; ++i) {
-            const int Y = Yb + i;
-            if (UP > 1 && (Y % UP) != 0) continue;
-            const int r = Y / UP;
+    for (int q = 0; q < SR; ++q) acc[q] = (CT)0;
+    constexpr int NR = (SR - 1) * DOWN + KH;             // zero-stuffed rows touched by the strip
 #pragma unroll
-            for (int j = 0; j < KW; ++j) {
-                const int X = Xb + j;
-                if (UP > 1 && (X % UP) != 0) continue;
-                v += s_in[r * TL::IWP + X / UP] * s_k[i * KW + j];
+    for (int rr = 0; rr < NR; ++rr) {
+        const int Y = Yb + rr;
+        if (UP > 1 && (Y % UP) != 0) continue;
+        const CT* row = s_in + (Y / UP) * TL::IWP;
+#pragma unroll
+        for (int j = 0; j < KW; ++j) {
+            const int X = Xb + j;
+            if (UP > 1 && (X % UP) != 0) continue;
+            const CT v = row[X / UP];
+#pragma unroll
+            for (int q = 0; q < SR; ++q) {
+                const int i = rr - q * DOWN;            // tap row of output q that sees zero-stuffed row rr
+                if (i >= 0 && i < KH) acc[q] += v * kreg[i * KW + j];
             }
         }
-        if (oy < a.out_h && ox < a.out_w) st_as<T, CT>(oplane + (int64_t)oy * a.out_w + ox, v);
+    }
+    T* oplane = out + m * (int64_t)a.out_h * a.out_w;
+#pragma unroll
+    for (int q = 0; q < SR; ++q) {
+        const int oy = oy0 + SR * sy + q;
+        if (oy < a.out_h && ox < a.out_w) st_as<T, CT>(oplane + (int64_t)oy * a.out_w + ox, acc[q]);
     }
 }
 

@@ -179,3 +179,26 @@ def test_ops_full_size_properties():
     assert torch.equal(y, torch.where(t > 0, t, t * 0.2) * S2)
     gate = fused.fused_bias_act(torch.ones_like(a), a.new_empty(0), y, 3, 1, 0.2, S2)
     assert torch.equal(gate, torch.where(t > 0, torch.full_like(t, S2), torch.full_like(t, 0.2 * S2)))
+
+
+def test_gen_rays_device_matches_reference_and_oracle():
+    """next-1 (SURVEY 8(f)): hav_gen_rays vs dataloader/data_util.py::get_rays of the reference (tests/golden/get_rays.npz)."""
+    import ctypes as C
+    from havatar_amd import _lib
+    from oracle import oracle
+    g = np.load(os.path.join(GOLDEN, "get_rays.npz"))
+    H, W = int(g["H"]), int(g["W"])
+    out = torch.empty(H * W, 8, device=DEV)
+    intr = (C.c_float * 4)(*[float(v) for v in g["intr"]])
+    c2w = (C.c_float * 12)(*[float(v) for v in g["c2w"].reshape(-1)])
+    rc = _lib.lib().hav_gen_rays(C.c_void_p(out.data_ptr()), H, W, intr, c2w, 3.4, 6.0, 0, H,
+                                 C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    r = out.cpu().numpy()
+    assert linf(r[:, 0:3].reshape(H, W, 3), g["rays_o"]) == 0.0
+    assert linf(r[:, 3:6].reshape(H, W, 3), g["rays_d"]) <= 3e-7
+    assert linf(r, oracle.gen_rays(H, W, g["intr"], g["c2w"], 3.4, 6.0)) <= 3e-7
+    part = torch.empty(2 * W, 8, device=DEV)          # row range
+    assert _lib.lib().hav_gen_rays(C.c_void_p(part.data_ptr()), H, W, intr, c2w, 3.4, 6.0, 3, 5,
+                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    assert torch.equal(part, out[3 * W:5 * W])
