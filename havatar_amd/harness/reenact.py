@@ -1,0 +1,124 @@
+"""H1 -- reenactment harness (reference: avatarHD_reenactment.py:103-172).
+
+    python avatarHD_reenactment.py --config <yml> --ckpt <pth> --savedir <dir> --split <split.json>
+
+Same flags, same checkpoint keys (`nerf_render`, `latent_codes`, `g_ema`), same per-frame sequence:
+test-mode frame (B=1) -> `Trainer(**inp)` (validation mode, full image) -> `SWGAN_unet(styles=[style], condition_img=render[:, 3:])`
+-> clip(x*255, 0, 255) uint8 -> `<savedir>/rgb/<fidx>_<view:02d>.png`.
+What is different by design: the frame is one hipGraph launch per stage when shapes are static (HAVATAR_GRAPH=0 disables), and
+with more than one process (torchrun) the frames of the split are dealt round-robin to the ranks (no data-path collective).
+"""
+import argparse
+import os
+
+import numpy as np
+import torch
+import yaml
+
+from ..dataloader import imgio
+from ..dataloader.dataloaderSR import Loader
+from ..frames import shard_frames
+from ..graph import GraphedForward
+from ..model.nerf_trainer import Trainer
+from ..model.styleUnet import SWGAN_unet
+from ..utils.cfgnode import CfgNode
+from ..utils.training_util import load_partial_state_dict
+
+
+class styleUnet_args:
+    """The generator hyper-parameters the reference hard-codes in the script (avatarHD_reenactment.py:17-45); only the three the
+    inference path reads are kept."""
+    latent = 64
+    n_mlp = 4
+    channel_multiplier = 2
+
+
+su_args = styleUnet_args()
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument("--config", type=str, default="config/singleview_512_HD_base.yml", help="Path to (.yml) config file.")
+    p.add_argument("--ckpt", type=str, default="", help="Path to load saved checkpoint from.")
+    p.add_argument("--savedir", type=str, default="./renders/", help="Save images to this directory, if specified.")
+    p.add_argument("--split", type=str, default=None, help="Split file (json) listing the frames to render.")
+    return p.parse_args(argv)
+
+
+def build_models(cfg, checkpoint, device):
+    render_size, gen_size = cfg.models.StyleUnet.inp_size, cfg.models.StyleUnet.out_size
+    nerf_render = Trainer(cfg, 0).requires_grad_(False).to(device)
+    img_trans = SWGAN_unet(inp_size=render_size, inp_ch=cfg.models.StyleUnet.inp_ch, out_size=gen_size, out_ch=3,
+                           style_dim=su_args.latent, c_dim=0, n_mlp=su_args.n_mlp,
+                           channel_multiplier=su_args.channel_multiplier).to(device)
+    load_partial_state_dict(nerf_render, checkpoint["nerf_render"], except_keys=["latent_codes"])
+    nerf_render.latent_codes = checkpoint["latent_codes"].to(device)
+    img_trans.load_state_dict(checkpoint["g_ema"])
+    nerf_render.headpose_skin_net.fix_canonical_W()
+    return nerf_render.eval(), img_trans.eval()
+
+
+def frame_inputs(idx, batch, device):
+    """The dict the reference builds per frame (:151-159)."""
+    rays = batch["mv_rays"]
+    return {"mode": "validation", "fidx": idx, "render_full_img": True,
+            "ray_batch": rays[..., :-3].to(device), "background_prior": rays[..., -3:].to(device),
+            "front_render_cond": batch["front_render_cond"].permute(0, 3, 1, 2).to(device),
+            "left_render_cond": batch["left_render_cond"].permute(0, 3, 1, 2).to(device),
+            "right_render_cond": batch["right_render_cond"].permute(0, 3, 1, 2).to(device),
+            "inv_head_T": batch["inv_head_T"].to(device)}
+
+
+def to_png_array(gen_img):
+    """[1,3,H,W] float -> uint8 [H,W,3] RGB exactly as :164 (truncating cast after the clip)."""
+    return np.clip(gen_img.permute(0, 2, 3, 1).detach().cpu().numpy()[0] * 255, 0, 255).astype(np.uint8)
+
+
+def main(argv=None, device=None, style=None):
+    args = parse_args(argv)
+    os.makedirs(os.path.join(args.savedir, "rgb"), exist_ok=True)
+    with open(args.config, "r") as f:
+        cfg = CfgNode(yaml.load(f, Loader=yaml.FullLoader))
+    seed = cfg.experiment.randomseed
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    if device is None:
+        device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))       # the reference is GPU-only as well (:133)
+    device = torch.device(device)
+    if device.type == "cuda":
+        torch.cuda.set_device(device)
+    print(args.ckpt)
+    checkpoint = torch.load(args.ckpt, map_location="cpu")
+    nerf_render, img_trans = build_models(cfg, checkpoint, device)
+    if style is None:
+        style = torch.mean(torch.randn(1000, 1, su_args.latent), dim=0)            # :147, after the constructors consumed the RNG
+    style = style.to(device)
+    val_loader = Loader(split_file=args.split, mode="test", batch_size=1, options=cfg, down_sample=cfg.dataset.down_sample)
+    mine = set(shard_frames(len(val_loader.dataset), rank, world))
+    use_graph = device.type == "cuda" and os.environ.get("HAVATAR_GRAPH", "1") != "0"
+    graphed, written = None, []
+    with torch.no_grad():
+        for n, (idx, val_batch) in enumerate(val_loader):
+            if n not in mine:
+                continue
+            name, k = str(int(val_batch["fidx"][0])), int(val_batch["vidx"][0])
+            inp = frame_inputs(idx, val_batch, device)
+            if use_graph:
+                tens = {k_: v for k_, v in inp.items() if torch.is_tensor(v) and k_ != "fidx"}
+                if graphed is None:
+                    fixed = {k_: v for k_, v in inp.items() if k_ not in tens}
+                    graphed = GraphedForward(lambda **kw: nerf_render(**kw, **fixed), tens)
+                render, _, _ = graphed(**tens)
+            else:
+                render, _, _ = nerf_render(**inp)
+            gen_img = img_trans(styles=[style], condition_img=render[:, 3:])
+            path = os.path.join(args.savedir, "rgb", f"{name}_{k:02d}.png")
+            imgio.imwrite_rgb(path, to_png_array(gen_img))
+            written.append(path)
+    print("Done!")
+    return written
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,226 @@
+"""H2 -- stage-one training harness (reference: train_avatar.py:30-319).
+
+    python train_avatar.py --logdir <dir> --datadir <dir with sv_v31_all.json> --config <yml> [--ckpt <ckpt>]
+
+Same flags, loss formula, optimiser / learning-rate schedule and checkpoint keys (`iter`, `optimizer_state_dict`, `loss`, `psnr`,
+`trainer_state_dict`).  The step runs `Trainer(**inp)` in train mode; with autograd on, the Trainer takes the PyTorch statement
+of the path (the fused HIP kernel is forward-only), while the encoders' custom ops are the HIP kernels with their
+first/second-order autograd.  Validation frames are rendered through the fused kernel (no-grad).
+LPIPS (patch_rgb) needs the `lpips` package and its VGG weights; when they are absent the harness refuses to start unless
+`--percep none` is given, which drops that one term and says so.
+"""
+import argparse
+import datetime
+import os
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+import yaml
+
+from ..dataloader import imgio
+from ..dataloader.dataloader import Loader
+from ..model.nerf_trainer import Trainer
+from ..utils.cfgnode import CfgNode
+from ..utils.training_util import mse2psnr
+
+
+def lpips_loss(img0, img1, lpips_fn):
+    """[B,H,W,3] in [0,1] -> mean LPIPS (train_avatar.py:24-29)."""
+    img0 = img0.permute(0, 3, 1, 2) * 2.0 - 1.0
+    img1 = img1.permute(0, 3, 1, 2) * 2.0 - 1.0
+    return lpips_fn.forward(img0, img1).mean()
+
+
+def skin_weight_smoothness(trainer):
+    """Mean absolute 6-neighbour difference of the second blend-weight channel (train_avatar.py:123-129)."""
+    vol = trainer.headpose_skin_net.canonical_Wvolume()[0, 1]
+    core = vol[1:-1, 1:-1, 1:-1]
+    nbrs = [vol[:-2, 1:-1, 1:-1], vol[2:, 1:-1, 1:-1], vol[1:-1, 2:, 1:-1], vol[1:-1, :-2, 1:-1], vol[1:-1, 1:-1, 2:], vol[1:-1, 1:-1, :-2]]
+    return torch.mean(sum(torch.abs(core - v) for v in nbrs) / 6.0)
+
+
+def step_inputs(idx, batch, device):
+    """train_avatar.py:108-121: mv_rays [B,R,12] = rays(8) | background(3) | mask(1)."""
+    mv_rays = batch["mv_rays"].to(device)
+    inp = {"mode": "train", "fidx": idx, "render_full_img": False,
+           "ray_batch": mv_rays[..., :-4], "background_prior": mv_rays[..., -4:-1],
+           "front_render_cond": batch["front_render_cond"].permute(0, 3, 1, 2).to(device),
+           "left_render_cond": batch["left_render_cond"].permute(0, 3, 1, 2).to(device),
+           "right_render_cond": batch["right_render_cond"].permute(0, 3, 1, 2).to(device),
+           "inv_head_T": batch["inv_head_T"].to(device)}
+    return inp, batch["mv_rays_gt_color"].to(device), mv_rays[..., -1:]
+
+
+def training_loss(trainer, cfg, inp, target, ray_mask, rgb_loss_func, percep_loss_fn=None):
+    """One forward of the step and its scalar loss (train_avatar.py:121-146).  Returns (loss, parts, psnr)."""
+    rgb_coarse, _, acc_coarse, weights, rgb_fine, _, acc_fine, latent_code_loss = trainer(**inp)
+    sw_grad_loss = skin_weight_smoothness(trainer)
+    parts = {"coarse_loss": rgb_loss_func(rgb_coarse[..., :3], target[..., :3]),
+             "mask_coarse_loss": F.binary_cross_entropy(acc_coarse.clip(1e-3, 1.0 - 1e-3), ray_mask)}
+    if rgb_fine is not None:
+        parts["fine_loss"] = rgb_loss_func(rgb_fine[..., :3], target[..., :3])
+        parts["mask_fine_loss"] = F.binary_cross_entropy(acc_fine.clip(1e-3, 1.0 - 1e-3), ray_mask)
+    if percep_loss_fn is not None:
+        patch = rgb_coarse[..., :3] if rgb_fine is None else rgb_fine[..., :3]
+        s = int(patch.shape[1] ** 0.5)
+        parts["patch_percep_loss"] = lpips_loss(patch.reshape(patch.shape[0], s, s, 3), target[..., :3].reshape(patch.shape[0], s, s, 3),
+                                                percep_loss_fn)
+    mw = cfg.experiment.mask_weight
+    loss = parts["coarse_loss"] + mw * parts["mask_coarse_loss"] + (parts["patch_percep_loss"] * 0.05 if percep_loss_fn is not None else 0.0)
+    if rgb_fine is not None:
+        loss = loss + (parts["fine_loss"] + mw * parts["mask_fine_loss"])
+    loss = loss + latent_code_loss + sw_grad_loss * 1e-4
+    parts.update(code_loss=latent_code_loss, sw_grad_loss=sw_grad_loss)
+    best = rgb_coarse if rgb_fine is None else rgb_fine
+    psnr = mse2psnr(F.mse_loss(best[..., :3], target[..., :3]).item())
+    return loss, parts, psnr
+
+
+def learning_rate(cfg, i):
+    """train_avatar.py:153-154: exponential decay per 1000*lr_decay steps, floored at 5e-5."""
+    return max(cfg.optimizer.lr * (cfg.scheduler.lr_decay_factor ** (i / (cfg.scheduler.lr_decay * 1000))), 5e-5)
+
+
+def validate(trainer, cfg, val_batch, img_h, img_w, device, rgb_loss_func):
+    """Full-frame validation render in chunks of nerf.validation.chunksize rays (train_avatar.py:183-216)."""
+    _, batch = val_batch
+    rays = batch["mv_rays"][0].reshape(-1, batch["mv_rays"][0].shape[-1])
+    inp = {"mode": "validation", "fidx": None, "render_full_img": False,
+           "front_render_cond": batch["front_render_cond"].permute(0, 3, 1, 2).to(device),
+           "left_render_cond": batch["left_render_cond"].permute(0, 3, 1, 2).to(device),
+           "right_render_cond": batch["right_render_cond"].permute(0, 3, 1, 2).to(device),
+           "inv_head_T": batch["inv_head_T"].to(device)}
+    n, group = rays.shape[0], cfg.nerf.validation.chunksize
+    coarse, fine = [], []
+    for s in range(0, n, group):
+        inp.update(ray_batch=rays[s:s + group][..., :-3].to(device).unsqueeze(0),
+                   background_prior=rays[s:s + group][..., -3:].to(device).unsqueeze(0))
+        rgb_c, _, _, _, rgb_f, _, _, _ = trainer(**inp)
+        coarse.append(rgb_c[0][..., :3].detach().cpu())
+        if rgb_f is not None:
+            fine.append(rgb_f[0][..., :3].detach().cpu())
+    views = n // (img_h * img_w)
+    target = batch["mv_rays_gt_color"][0].reshape(views, img_h, img_w, 3)
+    img = torch.cat(fine if fine else coarse, 0).reshape(views, img_h, img_w, 3)
+    loss = rgb_loss_func(img, target)
+    return img, target, loss.item(), mse2psnr(F.mse_loss(img, target).item())
+
+
+class _NullWriter:
+    def add_scalar(self, *a, **k):
+        pass
+
+    add_image = add_scalar
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument("--logdir", type=str, required=True)
+    p.add_argument("--datadir", type=str, required=True)
+    p.add_argument("--config", type=str, default="config/singleview_512_base.yml", help="Path to (.yml) config file.")
+    p.add_argument("--ckpt", type=str, default="", help="Path to load saved checkpoint from.")
+    p.add_argument("--percep", type=str, default="lpips", choices=["lpips", "none"], help="'none' drops the LPIPS patch term (no lpips package / weights)")
+    p.add_argument("--max-steps", type=int, default=0, help="stop after this many optimisation steps (0 = experiment.train_iters)")
+    return p.parse_args(argv)
+
+
+def main(argv=None, device=None):
+    args = parse_args(argv)
+    now = datetime.datetime.now()
+    with open(args.config, "r") as f:
+        cfg = CfgNode(yaml.load(f, Loader=yaml.FullLoader))
+    seed = cfg.experiment.randomseed
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    device = torch.device(device if device is not None else "cuda")
+    percep_loss_fn = None
+    if cfg.experiment.patch_rgb and args.percep == "lpips":
+        try:
+            import lpips
+        except ImportError as e:
+            raise RuntimeError("experiment.patch_rgb needs the `lpips` package (VGG weights); install it or pass --percep none") from e
+        percep_loss_fn = lpips.LPIPS(net="vgg").to(device)
+    elif cfg.experiment.patch_rgb:
+        print("[train] --percep none: the 0.05 * LPIPS(patch) term of the reference loss is dropped")
+    rgb_loss_func = F.mse_loss if cfg.experiment.rgb_loss == "mse" else F.l1_loss
+    split = os.path.join(args.datadir, "sv_v31_all.json")
+    workers = int(os.environ.get("HAVATAR_WORKERS", 8))
+    train_loader = Loader(split_file=split, mode="train", batch_size=2, num_workers=workers, down_sample=cfg.dataset.down_sample,
+                          options=cfg, white_bg=True)
+    val_loader = Loader(split_file=split, shuffle=True, mode="val", batch_size=1, num_workers=min(workers, 1), down_sample=1.0,
+                        options=cfg, white_bg=True)
+    val_data = enumerate(val_loader)
+    trainer = Trainer(cfg, len(train_loader.dataset)).to(device)
+    optimizer = getattr(torch.optim, cfg.optimizer.type)([{"params": list(trainer.parameters())}], lr=cfg.optimizer.lr)
+    os.makedirs(args.logdir, exist_ok=True)
+    try:
+        from torch.utils.tensorboard import SummaryWriter
+        writer = SummaryWriter(args.logdir)
+    except Exception:  # tensorboard is optional here
+        writer = _NullWriter()
+    with open(os.path.join(args.logdir, "config_%s.tar.yml" % now.strftime("%Y_%m_%d_%H_%M_%S")), "w") as f:
+        f.write(cfg.dump())
+    start_iter = -1
+    if len(args.ckpt) > 0:
+        assert os.path.exists(args.ckpt)
+        checkpoint = torch.load(args.ckpt, map_location="cpu")
+        trainer.load_state_dict(checkpoint["trainer_state_dict"])
+        optimizer.load_state_dict(checkpoint["optimizer_state_dict"])
+        start_iter = checkpoint["iter"]
+    elif trainer.headpose_skin_net is not None:
+        trainer.headpose_skin_net.pretrain_wc(num_iter=int(os.environ.get("HAVATAR_PRETRAIN_WC", 3000)), vol_thr=cfg.models.coarse.Head_bounding)
+    i, steps_done = start_iter, 0
+    loss, psnr = None, None
+    while i < cfg.experiment.train_iters:
+        trainer.train()
+        t0 = time.time()
+        for idx, batch in train_loader:
+            i += 1
+            inp, target, ray_mask = step_inputs(idx, batch, device)
+            loss, parts, psnr = training_loss(trainer, cfg, inp, target, ray_mask, rgb_loss_func, percep_loss_fn)
+            loss.backward()
+            optimizer.step()
+            optimizer.zero_grad()
+            lr_new = learning_rate(cfg, i)
+            for g in optimizer.param_groups:
+                g["lr"] = lr_new
+            if i % cfg.experiment.print_every == 0 or i == cfg.experiment.train_iters - 1:
+                print("[TRAIN] Iter: %d Loss: %.06f PSNR: %.06f LatentReg: %.04f e-5 LR: %.02f e-5 TIME: %.02f" % (
+                    i, loss.item(), psnr, 1e5 * parts["code_loss"].item(), 1e5 * lr_new, (time.time() - t0) / cfg.experiment.print_every))
+                t0 = time.time()
+            for k, v in parts.items():
+                writer.add_scalar("train/" + k, v.item(), i)
+            writer.add_scalar("train/psnr", psnr, i)
+            if i == start_iter + 1 or i % cfg.experiment.validate_every == 0:
+                trainer.eval()
+                with torch.no_grad():
+                    try:
+                        vb = next(val_data)
+                    except StopIteration:
+                        val_data = enumerate(val_loader)
+                        vb = next(val_data)
+                    img, target_img, vloss, vpsnr = validate(trainer, cfg, vb[1], val_loader.dataset.img_h, val_loader.dataset.img_w, device, rgb_loss_func)
+                writer.add_scalar("validation/psnr", vpsnr, i)
+                imgio.imwrite_rgb(os.path.join(args.logdir, "val_%05d.png" % i),
+                                  (torch.cat([img[0], target_img[0]], 1).clamp(0, 1) * 255).round().byte().numpy())
+                print("Validation loss: %06f Validation PSNR: %06f" % (vloss, vpsnr))
+                trainer.train()
+            if i % cfg.experiment.save_every == 0 or i == cfg.experiment.train_iters - 1 or i == start_iter + 1:
+                torch.save({"iter": i, "optimizer_state_dict": optimizer.state_dict(), "loss": loss, "psnr": psnr,
+                            "trainer_state_dict": trainer.state_dict()}, os.path.join(args.logdir, "checkpoint" + str(i).zfill(5) + ".ckpt"))
+                trainer.headpose_skin_net.visualize_motion_weight_vol(os.path.join(args.logdir, "vis_motionWeightVol" + str(i).zfill(5) + ".obj"))
+                print("================== Saved Checkpoint =================")
+            steps_done += 1
+            if (args.max_steps and steps_done >= args.max_steps) or i >= cfg.experiment.train_iters:
+                print("Done!")
+                return i
+    print("Done!")
+    return i
+
+
+if __name__ == "__main__":
+    np.random.seed(999)
+    torch.random.manual_seed(999)
+    main()

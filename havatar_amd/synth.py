@@ -259,3 +259,77 @@ def cond_images(B=1, res=256, seed=60):
         img[:, 6] = (img[:, 6] > 0.45).astype(np.float64)
         out.append(img.astype(np.float32))
     return out
+
+
+def write_dataset(root, n_frames=2, img_res=128, focal=1.7, cam_dist=5.0, seed=60, views=("0",)):
+    """A tiny synthetic dataset in the reference's on-disk layout (split file `sv_v31_all.json` + PNGs, see
+    havatar_amd/dataloader/_base.py) for the harness tests and demos: pinhole camera of SURVEY 8(d), per-frame head pose
+    `frame_pose(k)`, 256^2 3DMM condition renders from `cond_images`, a shaded-disc photograph and its mask per view.
+    Returns the split-file path."""
+    import json
+    import os
+
+    from .dataloader import imgio
+    os.makedirs(root, exist_ok=True)
+    c2w = [[1.0, 0.0, 0.0, 0.0], [0.0, -1.0, 0.0, 0.0], [0.0, 0.0, -1.0, cam_dist], [0.0, 0.0, 0.0, 1.0]]
+    yy, xx = np.meshgrid(np.arange(img_res), np.arange(img_res), indexing="ij")
+    frames = []
+    for k in range(n_frames):
+        inst = os.path.join(root, "frame_%04d" % k)
+        os.makedirs(inst, exist_ok=True)
+        for name, img in zip(("front", "left", "right"), cond_images(1, 256, seed + 10 * k)):
+            m = img[0, 6][..., None]
+            render = np.floor(img[0, 0:3].transpose(1, 2, 0) * m * 255 + 0.5).astype(np.uint8)
+            normal = np.floor((0.02 + 0.98 * img[0, 3:6].transpose(1, 2, 0)) * m * 255 + 0.5).astype(np.uint8)
+            imgio.imwrite_rgb(os.path.join(inst, "ortho_%s_render_256_baseGama.png" % name), render)
+            imgio.imwrite_rgb(os.path.join(inst, "ortho_%s_normal_256_baseGama.png" % name), normal)
+        R = euler_deg_to_R(20.0 * math.sin(2.0 * math.pi * k / 64.0), -8.0, 3.0)
+        head = np.eye(4)
+        head[:3, :3], head[:3, 3] = R.T, (0.02, -0.03, 0.01)      # stored for row vectors p.T ("right-multiplied", dataloader.py:203)
+        infos = []
+        for v in views:
+            cx, cy, rad = img_res * (0.5 + 0.02 * k), img_res * 0.48, img_res * 0.3
+            d2 = ((xx - cx) ** 2 + (yy - cy) ** 2) / rad ** 2
+            mask = (d2 < 1.0)
+            shade = np.sqrt(np.clip(1.0 - d2, 0.0, 1.0))
+            photo = np.stack([0.8 * shade, 0.6 * shade + 0.1, 0.5 * shade + 0.2], -1) * mask[..., None]
+            fp, mp = os.path.join(inst, "img_%s.png" % v), os.path.join(inst, "mask_%s.png" % v)
+            imgio.imwrite_rgb(fp, np.floor(photo * 255 + 0.5).astype(np.uint8))
+            imgio.imwrite_rgb(mp, np.repeat((mask * 255).astype(np.uint8)[..., None], 3, -1))
+            infos.append({"view_name": v, "transform_matrix": c2w, "transform_matrix_ori": c2w, "file_path": fp, "mask_path": mp})
+        frames.append({"fidx": k, "inst_dir": inst, "head_transformation": head.tolist(), "mutiview_info_ls": infos})
+    meta = {"img_res": img_res, "mutiview_intr_ls": [[focal * img_res, focal * img_res, 0.5, 0.5] for _ in views], "frames": frames}
+    path = os.path.join(root, "sv_v31_all.json")
+    with open(path, "w") as f:
+        json.dump(meta, f)
+    return path
+
+
+def harness_config(render_size=32, gen_size=128, img_res=128, perturb=False, noise_std=0.0, rays=256):
+    """Config dict (the reference's YAML layout) for the harness tests / demos: a `img_res` dataset rendered at
+    `render_size` (down_sample = render_size / img_res), stage-two output `gen_size`, deterministic sampling by default."""
+    import copy
+    import os
+
+    import yaml
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "config", "hd_base.yml")) as f:
+        cfg = copy.deepcopy(yaml.safe_load(f))
+    cfg["dataset"].update(down_sample=render_size / img_res, num_random_rays=rays)
+    cfg["models"]["StyleUnet"].update(inp_size=render_size, out_size=gen_size)
+    cfg["models"]["coarse"]["Head_bounding"] = [[-1.2, 1.2], [-1.6, 1.0], [-1.6, 1.2]]
+    cfg["experiment"].update(train_iters=4, validate_every=1000, save_every=1000, print_every=1, mask_weight=0.01, rgb_loss="mse",
+                             patch_rgb=False)
+    cfg["optimizer"] = {"type": "Adam", "lr": 5.0e-4}
+    cfg["scheduler"] = {"lr_decay": 250, "lr_decay_factor": 0.1}
+    for mode in ("train", "validation"):
+        cfg["nerf"][mode].update(perturb=bool(perturb), radiance_field_noise_std=float(noise_std) if mode == "train" else 0.0)
+    return cfg
+
+
+def zero_noise_weights(state_dict):
+    """Set every NoiseInjection strength to 0 (in place): the generators' per-call random noise then has no effect, which
+    makes a harness run reproducible without pinning RNG streams."""
+    for k in state_dict:
+        if k.endswith("noise.weight"):
+            state_dict[k].zero_()
+    return state_dict

@@ -22,3 +22,10 @@ class CfgNode(dict):
     def load_yaml(cls, path):
         with open(path, "r") as f:
             return cls(yaml.load(f, Loader=yaml.FullLoader))
+
+    def to_dict(self):
+        return {k: (v.to_dict() if isinstance(v, CfgNode) else v) for k, v in self.items()}
+
+    def dump(self, **kwargs):
+        """YAML text of the node (reference utils/cfgnode.py:167-187), written next to the logs by the training harness."""
+        return yaml.safe_dump(self.to_dict(), **kwargs)

@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Golden vectors for the harness rows H1 / H2: run the REFERENCE modules (imported from /root/reference, build
+container only) through the per-frame sequence of avatarHD_reenactment.py:147-166 and the per-step sequence of
+train_avatar.py:106-148 and store the results in tests/golden/harness.npz.
+
+What is the reference here and what is not: `Trainer`, `SWGAN_unet`, autograd through them and the RNG stream are the
+reference's.  The two scripts themselves cannot be imported (top-level `import cv2`, `lpips`, tensorboard, and their body is
+`main()`), so the frames are read by this repo's dataset reader (cv2-free; its rays are pinned separately by
+tests/golden/get_rays.npz) and the loss expression of train_avatar.py:121-146 is evaluated by
+havatar_amd.harness.train.training_loss applied to the REFERENCE trainer object.
+Weights are key-derived (synth.fill_state_dict), noise strengths zeroed so that unpinned per-call noise cannot matter."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "oracle"))
+from gen_golden import import_reference  # noqa: E402
+
+
+def main():
+    from havatar_amd import synth
+    from havatar_amd.dataloader.dataloader import Loader as TrainLoader
+    from havatar_amd.dataloader.dataloaderSR import Loader as SRLoader
+    from havatar_amd.harness import reenact, train
+    torch, Trainer, _ = import_reference()
+    from model.styleUnet import SWGAN_unet
+    from utils.cfgnode import CfgNode
+    from utils.training_util import load_partial_state_dict
+    out = {}
+    tmp = tempfile.mkdtemp()
+    split = synth.write_dataset(tmp, n_frames=2, img_res=128)
+
+    # ---------------- H1: reenactment -------------------------------------------------------------------------------
+    cfg = CfgNode(synth.harness_config())
+    seed = cfg.experiment.randomseed
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    nerf_render = Trainer(cfg, 0).requires_grad_(False)
+    img_trans = SWGAN_unet(inp_size=32, inp_ch=cfg.models.StyleUnet.inp_ch, out_size=128, out_ch=3, style_dim=64, c_dim=0, n_mlp=4,
+                           channel_multiplier=2)
+    # the checkpoint a user would hand over: key-derived weights, built on throw-away twins so the RNG stream above is untouched
+    g = torch.Generator()
+    rng_state = torch.get_rng_state()
+    tw = synth.fill_state_dict(Trainer(cfg, 3))
+    sw = synth.fill_state_dict(SWGAN_unet(inp_size=32, inp_ch=cfg.models.StyleUnet.inp_ch, out_size=128, out_ch=3, style_dim=64, c_dim=0,
+                                          n_mlp=4, channel_multiplier=2), seed=1)
+    torch.set_rng_state(rng_state)
+    ckpt = {"nerf_render": synth.zero_noise_weights({k: v.clone() for k, v in tw.state_dict().items()}),
+            "latent_codes": tw.state_dict()["latent_codes"].clone(),
+            "g_ema": synth.zero_noise_weights({k: v.clone() for k, v in sw.state_dict().items()})}
+    load_partial_state_dict(nerf_render, ckpt["nerf_render"], except_keys=["latent_codes"])
+    nerf_render.latent_codes = ckpt["latent_codes"]
+    img_trans.load_state_dict(ckpt["g_ema"])
+    nerf_render.headpose_skin_net.fix_canonical_W()
+    nerf_render.eval(); img_trans.eval()
+    style = torch.mean(torch.randn(1000, 1, 64), dim=0)
+    out["h1_style"] = style.numpy()
+    loader = SRLoader(split_file=split, mode="test", batch_size=1, options=cfg, down_sample=cfg.dataset.down_sample)
+    with torch.no_grad():
+        for idx, batch in loader:
+            inp = reenact.frame_inputs(idx, batch, "cpu")
+            render, mask, _ = nerf_render(**inp)
+            gen = img_trans(styles=[style], condition_img=render[:, 3:])
+            k = int(batch["fidx"][0])
+            out["h1_render_%d" % k] = render.numpy()
+            out["h1_mask_%d" % k] = mask.numpy()
+            out["h1_gen_%d" % k] = gen.numpy()
+            out["h1_png_%d" % k] = reenact.to_png_array(gen)
+            print("H1 frame", k, "render", tuple(render.shape), "acc", float(mask.min()), float(mask.max()), "gen range",
+                  float(gen.min()), float(gen.max()))
+
+    # ---------------- H2: one training step ------------------------------------------------------------------------
+    for tag, perturb, noise in (("det", False, 0.0), ("rnd", True, 0.1)):
+        cfg = CfgNode(synth.harness_config(perturb=perturb, noise_std=noise))
+        np.random.seed(7)
+        tl = TrainLoader(split_file=split, mode="train", batch_size=2, num_workers=0, down_sample=cfg.dataset.down_sample, options=cfg,
+                         white_bg=True, shuffle=False)
+        idx, batch = next(iter(tl))
+        torch.manual_seed(5)          # pins the construction-time random StyleGAN_zxc.zero_noise[0] (not in the state_dict, SURVEY B-3)
+        trainer = synth.fill_state_dict(Trainer(cfg, len(tl.dataset)))
+        trainer.train()
+        inp, target, ray_mask = train.step_inputs(idx, batch, "cpu")
+        torch.manual_seed(123)
+        loss, parts, psnr = train.training_loss(trainer, cfg, inp, target, ray_mask, torch.nn.functional.mse_loss)
+        trainer.model_coarse.triPlane_embeddings.retain_grad()
+        loss.backward()
+        if tag == "det":
+            out["h2_mv_rays"] = batch["mv_rays"].numpy()
+            out["h2_target"] = batch["mv_rays_gt_color"].numpy()
+            out["h2_fidx"] = idx.numpy()
+        out["h2_%s_loss" % tag] = np.array(loss.item())
+        out["h2_%s_psnr" % tag] = np.array(psnr)
+        for k, v in parts.items():
+            out["h2_%s_part_%s" % (tag, k)] = np.array(v.item())
+        params = dict(trainer.named_parameters())
+        gp = trainer.model_coarse.triPlane_embeddings.grad
+        out["h2_%s_grad_planes_slice" % tag] = gp[:, :, ::8, ::16, ::16].numpy()
+        out["h2_%s_grad_planes_cks" % tag] = np.array([gp.double().sum().item(), gp.double().abs().sum().item(), gp.double().abs().max().item()])
+        names = ["model_coarse.layers_xyz.0.weight", "model_coarse.layers_xyz.1.weight", "model_coarse.fc_alpha.weight",
+                 "model_coarse.fc_rgbFeat.weight", "model_coarse.fc_rgb.weight", "latent_codes"]
+        # weights only: a conv bias in front of InstanceNorm3d(affine=False) has an identically-zero gradient (rounding noise in fp32)
+        names += [n for n in params if n.startswith("headpose_skin_net.") and n.endswith(".weight") and params[n].grad is not None][-2:]
+        names += [n for n in params if n.startswith("model_coarse.XY_gen.") and params[n].grad is not None and params[n].dim() == 4][:1]
+        out["h2_%s_grad_names" % tag] = np.array(names)
+        for n in names:
+            gr = params[n].grad
+            out["h2_%s_grad_%s" % (tag, n)] = gr.numpy() if gr.numel() <= 32768 else gr.reshape(-1)[:: max(1, gr.numel() // 4096)].numpy()
+            out["h2_%s_gradcks_%s" % (tag, n)] = np.array([gr.double().sum().item(), gr.double().abs().sum().item()])
+        n_with = sum(p.grad is not None for p in params.values())
+        print("H2", tag, "loss %.6f psnr %.3f" % (loss.item(), psnr), {k: round(v.item(), 6) for k, v in parts.items()}, "params with grad", n_with, "/", len(params))
+    path = os.path.join(REPO, "tests", "golden", "harness.npz")
+    np.savez_compressed(path, **out)
+    print("harness.npz", os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -16,6 +16,11 @@ for pass in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY 
   n=$(echo $pass | tr ' ' '_' | cut -c1-40)
   rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/pmc_$n -o pmc -- $BENCH > $OUT/pmc_$n.log 2>&1
 done
+# calibration of the memory-side counters on a launch of known size (MI355X_MICROARCH.md, HBM section)
+for pass in "FETCH_SIZE" "WRITE_SIZE"; do
+  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/calib_$pass -o pmc -- python tools/bench_ops.py --calib > $OUT/calib_$pass.log 2>&1
+done
+grep -h -m1 calib_kernel $OUT/calib_FETCH_SIZE.log > $OUT/calib.json
 python tools/prof_summary.py $OUT > $OUT/summary.txt 2>&1
 cp $OUT/kt/kt_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
 # keep only the compact artefacts (gpurun copies back <= 64 MiB)
