@@ -87,6 +87,7 @@ def main(argv=None, device=None, style=None):
         device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))       # the reference is GPU-only as well (:133)
     device = torch.device(device)
     if device.type == "cuda":
+        device = torch.device("cuda", device.index if device.index is not None else torch.cuda.current_device())
         torch.cuda.set_device(device)
     print(args.ckpt)
     checkpoint = torch.load(args.ckpt, map_location="cpu")
