@@ -151,7 +151,25 @@ def main():
     rm = m
 
     F32 = os.environ.get("HAVATAR_MLP", "split") == "f32"
+
+    def pmc_traffic(kernel):
+        """HBM-side bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (profiles/*_pmc.json, written by
+        tools/profile.sh: FETCH_SIZE and WRITE_SIZE in separate passes, scaled by the factors calibrated in the same run on a
+        streaming launch of known size -- MI355X_MICROARCH.md, HBM section).  None when no profile of this kernel is committed."""
+        import glob
+        for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc.json")), reverse=True):
+            try:
+                d = json.load(open(f))
+                k, cal = d[kernel.split("(")[0].strip()], d["calibration"]
+                return {"bytes": int(k["FETCH_SIZE"] * cal["read_bytes_per_FETCH_KB"] + k["WRITE_SIZE"] * cal["write_bytes_per_WRITE_KB"]),
+                        "read": int(k["FETCH_SIZE"] * cal["read_bytes_per_FETCH_KB"]), "write": int(k["WRITE_SIZE"] * cal["write_bytes_per_WRITE_KB"]),
+                        "source": "profiles/" + os.path.basename(f)}
+            except (KeyError, OSError, ValueError):
+                continue
+        return None
+
     if rank == 0:
+        traffic = pmc_traffic(rm.variant(S_C, S_F, perturb=perturb))
         res = {
             "metric": "rendered frames/sec @512^2, 64 samples/ray", "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
@@ -164,7 +182,8 @@ def main():
                        "parallelism": "frames sharded, %d rank(s), no data-path collective" % world,
                        "kernel": rm.variant(S_C, S_F, perturb=perturb)},
             "roofline": {"bound": "mfma", "achieved": round(FLOP_PER_FRAME / (kern_ms * 1e-3) / 1e12, 3), "peak": PEAK_FP32_MFMA / 1e12,
-                         "unit": "TFLOP/s", "frac": round(FLOP_PER_FRAME / (kern_ms * 1e-3) / PEAK_FP32_MFMA, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(FLOP_PER_FRAME / (kern_ms * 1e-3) / PEAK_FP32_MFMA, 4),
+                         "traffic": traffic["bytes"] if traffic else None, "traffic_detail": traffic,
                          "kernel_ms": round(kern_ms, 3), "flop_per_launch": FLOP_PER_FRAME,
                          "note": "achieved = ALGORITHMIC fp32 FLOP of the reference network (94848/query) / kernel time, against the fp32 "
                                  "MFMA peak; the kernel removes 52% of that work by linearity (DESIGN.md 3.3) and, in split mode, runs the "

@@ -44,11 +44,12 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("HAVATAR_LIB", LIB_PATH)      # kernel experiments: an alternative build of the SAME library
+    if not os.path.exists(path):
         raise HavatarLibraryError(
-            f"{LIB_PATH} is missing: build it with `python -m havatar_amd.build` "
+            f"{path} is missing: build it with `python -m havatar_amd.build` "
             "(or __graft_entry__.build()). There is no fallback path.")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     L.hav_abi_version.restype = C.c_int
     if L.hav_abi_version() != ABI_VERSION:
         raise HavatarLibraryError(f"ABI mismatch: library {L.hav_abi_version()} vs binding {ABI_VERSION}")

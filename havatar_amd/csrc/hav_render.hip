@@ -713,7 +713,9 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
 // ------------------------------------------------------------------------------------------------
 // the kernel
 // ------------------------------------------------------------------------------------------------
+#ifndef MARCH_THREADS
 #define MARCH_THREADS 512
+#endif
 #define MARCH_WAVES (MARCH_THREADS / 64)
 #define RACC_N 136  // 0..127 composited hidden units | 128..130 rgb | 131 depth | 132 acc | 133 wmax
 #define R_RGB 128
@@ -734,7 +736,7 @@ __device__ __forceinline__ float dpp_xor4(float v)
 // RANDOM=false: perturb == 0 and noise_std == 0 (deterministic rendering, the parity configuration); the random-number
 // paths (injected tensors or Philox) are compiled out.
 template <bool RANDOM>
-__global__ void __launch_bounds__(MARCH_THREADS, 2) hav_march_f32_kernel(const MarchArgs a)
+__global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_f32_kernel(const MarchArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const float* sW1 = smem + OFF_W1PE;
@@ -1009,7 +1011,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, 2) hav_march_f32_kernel(const M
 // Requires S_c <= 67 when a fine pass is requested (host falls back to the pair kernel otherwise).
 // ------------------------------------------------------------------------------------------------
 template <bool RANDOM, int PREC>
-__global__ void __launch_bounds__(MARCH_THREADS, 2) hav_march_blk_kernel(const MarchArgs a)
+__global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_blk_kernel(const MarchArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int WLDS = PREC == 1 ? LDS3_FLOATS : LDS_FLOATS;     // LDS image: fp32 fragments | split-bf16 fragments
