@@ -60,6 +60,10 @@ def lib():
     L.hav_upfirdn2d.restype = i32
     L.hav_upfirdn2d_out_size.argtypes = [i32] * 12 + [C.POINTER(i32), C.POINTER(i32)]
     L.hav_upfirdn2d_out_size.restype = i32
+    L.hav_style_demod.argtypes = [vp, vp, vp, vp, vp, vp, f32, i32, i32, i32, i32, vp]
+    L.hav_style_demod.restype = i32
+    L.hav_styled_epilogue.argtypes = [vp, vp, vp, vp, vp, vp, f32, f32, i32, i32, i64, i32, vp]
+    L.hav_styled_epilogue.restype = i32
     L.hav_mlp_blob_bytes.restype = i64
     L.hav_mlp_pack.argtypes = [vp, C.POINTER(HavMlpWeights), vp]
     L.hav_mlp_pack.restype = i32

@@ -145,6 +145,135 @@ extern "C" int hav_fused_bias_act(void* out, const void* x, const void* b, const
 }
 
 // ================================================================================================
+// StyleGAN2 block glue (model/styleUnet.py: ModulatedConv2d / NoiseInjection / FusedLeakyReLU).  In the reference these are
+// ~10 tiny ATen launches per styled convolution (EqualLinear, bias, square, matmul, +eps, rsqrt, 3 broadcasts, bias-act); at
+// ~4.5 us per launch on this GPU they cost as much as the convolution itself at 32^2..64^2.  Two kernels replace them.
+// ================================================================================================
+// (a) style + demodulation vectors of one modulated convolution:
+//     s[b,i] = <style[b,:], mod_w[i,:]> + mod_b[i]                  (EqualLinear with its scale / lr_mul folded into mod_w, mod_b)
+//     d[b,o] = rsqrt(sum_i s[b,i]^2 * wsq[i,o] + eps)               (wsq[i,o] = sum_k (scale*W[o,i,k])^2), optional
+// Grid = (ceil(Cout/16), B): every workgroup recomputes s (32 K MACs, L2-resident weights) into LDS, then produces 16 outputs with
+// the i range split over 64 thread slices (all loads of a thread independent and in flight together: one memory round trip
+// instead of Cin/4), reduced through LDS.  Workgroup x = 0 also writes s.
+#define SD_OT 16
+#define SD_SL 64
+__global__ void __launch_bounds__(SD_OT * SD_SL) style_demod_kernel(float* __restrict__ s_out, float* __restrict__ d_out,
+                                                                    const float* __restrict__ style, const float* __restrict__ mod_w,
+                                                                    const float* __restrict__ mod_b, const float* __restrict__ wsq,
+                                                                    float eps, int D, int Cin, int Cout)
+{
+    extern __shared__ float s_sq[];                 // [Cin] s^2, then [SD_SL][SD_OT] partial sums
+    float* s_part = s_sq + Cin;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const float* st = style + (size_t)b * D;
+    for (int i = tid; i < Cin; i += blockDim.x) {
+        const float* w = mod_w + (size_t)i * D;
+        float acc = 0.f;
+        for (int k = 0; k < D; ++k) acc = fmaf(st[k], w[k], acc);
+        const float v = acc + (mod_b ? mod_b[i] : 0.f);
+        if (blockIdx.x == 0) s_out[(size_t)b * Cin + i] = v;
+        s_sq[i] = v * v;
+    }
+    if (!d_out) return;
+    __syncthreads();
+    const int oi = tid & (SD_OT - 1), sl = tid / SD_OT;
+    const int o = blockIdx.x * SD_OT + oi;
+    float acc = 0.f;
+    if (o < Cout) {
+#pragma unroll 8
+        for (int i = sl; i < Cin; i += SD_SL) acc = fmaf(s_sq[i], wsq[(size_t)i * Cout + o], acc);
+    }
+    s_part[sl * SD_OT + oi] = acc;
+    __syncthreads();
+    if (tid < SD_OT && o < Cout) {
+        float t = 0.f;
+        for (int q = 0; q < SD_SL; ++q) t += s_part[q * SD_OT + tid];
+        d_out[(size_t)b * Cout + o] = rsqrtf(t + eps);
+    }
+}
+
+extern "C" int hav_style_demod(float* s_out, float* d_out, const float* style, const float* mod_w, const float* mod_b,
+                               const float* wsq, float eps, int B, int D, int Cin, int Cout, void* stream)
+{
+    if (!s_out || !style || !mod_w || B < 1 || D < 1 || Cin < 1) return HAV_EINVAL;
+    if (d_out && (!wsq || Cout < 1)) return HAV_EINVAL;
+    const size_t lds = ((size_t)Cin + SD_OT * SD_SL) * sizeof(float);
+    if (lds > 64 * 1024) return HAV_EUNSUP;
+    const int gx = d_out ? (Cout + SD_OT - 1) / SD_OT : 1;
+    hipLaunchKernelGGL(style_demod_kernel, dim3(gx, B), dim3(SD_OT * SD_SL), lds, (hipStream_t)stream, s_out, d_out, style, mod_w, mod_b,
+                       wsq, eps, D, Cin, Cout);
+    HAV_LAUNCH_CHECK();
+    return 0;
+}
+
+// (b) epilogue of a styled convolution, one pass over the activation:
+//     y[b,c,p] = lrelu_{0.2}( (x[b,c,p] * d[b,c]  +  nw * noise[b?,p])  +  bias[c] ) * sqrt(2)
+// with the reference's operation order and roundings (product, product, sum, sum: no FMA contraction), so the result equals the
+// unfused ATen sequence bit for bit.  d / noise / bias are optional.  nw is read from device memory (it is a parameter).
+// individually rounded product / sum: opaque to the compiler's FMA contraction (hipcc contracts x*y+z across __fmul_rn/__fadd_rn)
+__device__ __forceinline__ float mul_rn(float a, float b) { float r; asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float add_rn(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+template <int VEC>
+__global__ void __launch_bounds__(256) styled_epilogue_kernel(float* __restrict__ out, const float* __restrict__ x,
+                                                              const float* __restrict__ d, const float* __restrict__ noise,
+                                                              const float* __restrict__ nw_ptr, const float* __restrict__ bias,
+                                                              float slope, float gain, int64_t total_v, int C, int64_t HW,
+                                                              int noise_batched)
+{
+    const float nw = (noise && nw_ptr) ? *nw_ptr : 0.f;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total_v; v += stride) {
+        const int64_t e = v * VEC;
+        const int64_t plane = e / HW, p = e - plane * HW;          // plane = b*C + c  (HW % VEC == 0: a vector never straddles planes)
+        const int c = (int)(plane % C);
+        const int64_t b = plane / C;
+        float xv[VEC], nv[VEC];
+        if (VEC == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(x + e);
+            xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+            if (noise) {
+                const float4 n4 = *reinterpret_cast<const float4*>(noise + (noise_batched ? b * HW : 0) + p);
+                nv[0] = n4.x; nv[1] = n4.y; nv[2] = n4.z; nv[3] = n4.w;
+            }
+        } else {
+            xv[0] = x[e];
+            if (noise) nv[0] = noise[(noise_batched ? b * HW : 0) + p];
+        }
+        const float dd = d ? d[plane] : 1.f, bb = bias ? bias[c] : 0.f;
+        float yv[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            float t = d ? mul_rn(xv[q], dd) : xv[q];
+            if (noise) t = add_rn(t, mul_rn(nw, nv[q]));
+            t = add_rn(t, bb);
+            yv[q] = mul_rn(t > 0.f ? t : mul_rn(t, slope), gain);
+        }
+        if (VEC == 4) *reinterpret_cast<float4*>(out + e) = make_float4(yv[0], yv[1], yv[2], yv[3]);
+        else out[e] = yv[0];
+    }
+}
+
+extern "C" int hav_styled_epilogue(float* out, const float* x, const float* d, const float* noise, const float* noise_weight,
+                                   const float* bias, float slope, float gain, int B, int C, int64_t HW, int noise_batched,
+                                   void* stream)
+{
+    if (!out || !x || B < 1 || C < 1 || HW < 1) return HAV_EINVAL;
+    const int64_t total = (int64_t)B * C * HW;
+    const bool vec = (HW % 4 == 0) && (((uintptr_t)out | (uintptr_t)x | (uintptr_t)noise) % 16 == 0);
+    const int64_t total_v = vec ? total / 4 : total;
+    int64_t blocks = (total_v + 255) / 256;
+    const int64_t cap = (int64_t)hav_num_cus() * 16;
+    if (blocks > cap) blocks = cap;
+    if (vec) hipLaunchKernelGGL(styled_epilogue_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, x, d, noise,
+                                noise_weight, bias, slope, gain, total_v, C, HW, noise_batched);
+    else hipLaunchKernelGGL(styled_epilogue_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, x, d, noise,
+                            noise_weight, bias, slope, gain, total_v, C, HW, noise_batched);
+    HAV_LAUNCH_CHECK();
+    return 0;
+}
+
+// ================================================================================================
 // upfirdn2d
 // ================================================================================================
 struct UfdArgs {

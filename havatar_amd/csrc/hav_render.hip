@@ -323,6 +323,7 @@ struct MarchArgs {
     HavRenderOut out;
     unsigned long long rng_base;   // p.rng_offset (+ *p.rng_counter, read on the device)
     int ablate;             // HAV_ABLATE bit mask (timing experiments only; results are wrong when set)
+    int stagger;            // start-up delay per wave index, in units of 64 cycles (phase de-synchronisation of the CU's 8 waves)
     float* dbg_zfine;       // optional [B*R, S_fp] dump of the merged fine depths (tests)
     long long NR;           // B*R
     int S_fp;               // ceil(S_c/2) + S_f, 0 if no fine pass
@@ -341,34 +342,45 @@ __device__ __forceinline__ unsigned long long rng_off(const MarchArgs& a)
 __global__ void rng_advance_kernel(unsigned long long* c) { *c += 1ull; }
 
 // Uniform [0,1) for the stratified jitter (xi, zeta): counter-based -- a pure function of (seed, call offset, ray, sample,
-// stream) -- built from two murmur3 finalisers over the mixed counter words.  The jitter only needs equidistribution inside a
-// bin, and this is ~25 integer ops where Philox4x32-10 (kept for the Gaussian density noise below) is ~120; the block
-// kernel evaluates one such number per sample on the critical VALU path.
+// stream): murmur3's finaliser (a bijective avalanche mixer) over [hashed ray key] ^ [sample/stream/call counter word].  The
+// jitter only needs equidistribution inside a bin (tests/test_host_logic.py checks moments, bin counts and lag correlations of
+// this formula), and one draw is ~10 integer ops where Philox4x32-10 (kept for the Gaussian density noise below) is ~120; the
+// block kernel evaluates one such number per sample on the critical VALU path.
 __device__ __forceinline__ uint32_t fmix32(uint32_t x)
 {
     x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
     return x;
 }
-__device__ __forceinline__ float rng_uniform(const MarchArgs& a, long long gr, int s, int stream)
+// per-ray part of the key: two multiplies + one finaliser, hoisted out of the sample loops by the callers
+struct RKey { uint32_t ray, call, off; };          // hashed ray key | wave-uniform call key | call counter (read from memory ONCE per kernel)
+__device__ __forceinline__ uint32_t rng_call_off(const MarchArgs& a) { return (uint32_t)rng_off(a); }
+__device__ __forceinline__ RKey rng_ray_key(const MarchArgs& a, long long gr, uint32_t call_off)
 {
-    uint32_t x = fmix32((uint32_t)gr * 0x9E3779B1u + (uint32_t)a.p.seed);
-    x = fmix32(x ^ ((uint32_t)((unsigned long long)gr >> 32) * 0x7FEB352Du) ^ ((uint32_t)s * 0x846CA68Bu + (uint32_t)stream * 0x632BE5ABu));
-    x = fmix32(x + (uint32_t)(a.p.seed >> 32) + (uint32_t)rng_off(a) * 0x68E31DA4u);
+    RKey k;
+    k.ray = fmix32((uint32_t)gr * 0x9E3779B1u + (uint32_t)a.p.seed) ^ ((uint32_t)((unsigned long long)gr >> 32) * 0x7FEB352Du);
+    k.call = (uint32_t)(a.p.seed >> 32) + call_off * 0x68E31DA4u;
+    k.off = call_off;
+    return k;
+}
+__device__ __forceinline__ float rng_uniform(const MarchArgs& a, const RKey& k, int s, int stream)
+{
+    const uint32_t x = fmix32(k.ray ^ ((uint32_t)s * 0x846CA68Bu + (uint32_t)stream * 0x632BE5ABu + k.call));
     return (float)(x >> 8) * (1.0f / 16777216.0f);
 }
-__device__ __forceinline__ float rng_normal(const MarchArgs& a, long long gr, int s, int stream)
+__device__ __forceinline__ float rng_normal(const MarchArgs& a, const RKey& k, long long gr, int s, int stream)
 {
     uint32_t o[4];
     philox4x32((uint32_t)gr, (uint32_t)((unsigned long long)gr >> 32), (uint32_t)s,
-               (uint32_t)stream + 16u * (uint32_t)rng_off(a), (uint32_t)a.p.seed, (uint32_t)(a.p.seed >> 32), o);
+               (uint32_t)stream + 16u * k.off, (uint32_t)a.p.seed, (uint32_t)(a.p.seed >> 32), o);
     const float u1 = ((float)(o[0] >> 8) + 1.0f) * (1.0f / 16777216.0f), u2 = (float)(o[1] >> 8) * (1.0f / 16777216.0f);
     return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
 }
 
 // coarse depth of sample i (model/nerf_trainer.py:129-139): torch.linspace + stratified jitter
 __device__ __forceinline__ float lin_t(int k, int S, float step) { return (k < S / 2) ? step * (float)k : 1.0f - step * (float)(S - 1 - k); }
-template <bool RANDOM>
-__device__ __forceinline__ float z_coarse(const MarchArgs& a, long long gr, int i, float near, float far)
+// RANDOM: 0 = deterministic, 1 = device RNG only (production), 2 = injected tensors where given (parity tests), else device RNG
+template <int RANDOM>
+__device__ __forceinline__ float z_coarse(const MarchArgs& a, long long gr, const RKey& rkey, int i, float near, float far)
 {
     const int S = a.p.S_c;
     const float step = 1.0f / (float)(S - 1);
@@ -380,7 +392,7 @@ __device__ __forceinline__ float z_coarse(const MarchArgs& a, long long gr, int 
         const float zl = near * (1.0f - tl) + far * tl, zh = near * (1.0f - th) + far * th;
         const float lo = i > 0 ? 0.5f * (z + zl) : z;
         const float up = i < S - 1 ? 0.5f * (zh + z) : z;
-        const float xi = a.t_rand ? a.t_rand[gr * S + i] : rng_uniform(a, gr, i, STREAM_XI);
+        const float xi = (RANDOM == 2 && a.t_rand) ? a.t_rand[gr * S + i] : rng_uniform(a, rkey, i, STREAM_XI);
         z = lo + (up - lo) * xi;
     }
     return z;
@@ -394,6 +406,7 @@ __device__ __forceinline__ float z_coarse(const MarchArgs& a, long long gr, int 
 struct LaneCtx {
     const float* sW1; const float* sW2; const float4* sW4;
     const uint4* sA1; const uint4* sA2;         // split-bf16 fragments (PREC == 1 kernels)
+    const float4* sB;                           // LDS copy of b1 | b2 (block kernel; the pair kernel reads them through the buffer path)
     __amdgpu_buffer_rsrc_t wrs;
     int lane, h, hoff;
 };
@@ -495,16 +508,36 @@ __device__ __forceinline__ void mfma_split3(f32x16 (&acc)[4], const uint4* frag 
 }
 #undef KEEP
 
+// Phase timing (tools/phase_profile.sh builds an alternative library with -DHAV_PROFILE): wave-uniform s_memtime deltas summed
+// per phase and added to g_prof at kernel exit.  Waits are attributed to the phase in which the s_waitcnt / s_nop sits.
+#ifdef HAV_PROFILE
+#define HAV_NPROF 12
+__device__ unsigned long long g_prof[HAV_NPROF];
+struct ProfCtx { unsigned long long t, acc[HAV_NPROF]; };
+#define PROF_ARG , ProfCtx& P
+#define PROF_PASS , P
+#define TICK(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+                     P.acc[i] += t_ - P.t; P.t = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PROF_ARG
+#define PROF_PASS
+#define TICK(i) do { } while (0)
+#endif
+
 // PREC = 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  PREC = 1: split-operand bf16 MFMA (3 x bf16 per operand, 6 products).
 template <int GQ, int PREC>
 __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L, int b, float ox, float oy, float oz, float dx,
                                             float dy, float dz, float z, f32x16 (&acc2)[4], float& hd0, float& hd1, float& hd2,
-                                            float& hd3)
+                                            float& hd3 PROF_ARG)
 {
     const int h = L.h, lane = L.lane;
     const float* sW1 = L.sW1;
     const float* sW2 = L.sW2;
     const float4* sW4 = L.sW4;
+    // the bias reads are loop-invariant; an opaque base per tile keeps the compiler from hoisting 128 values out of the sample
+    // loop (and spilling them)
+    const float4* sBt = L.sB;
+    asm volatile("" : "+v"(sBt));
     const int PR = a.p.plane_res, VR = a.p.vol_res;
     // ---- pts = o + d z; skinning field (model/Skinning_Field.py:77-95): half-wave h evaluates bone h ---------
     const float px = ox + dx * z, py = oy + dy * z, pz = oz + dz * z;
@@ -544,6 +577,7 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
     const float den = (w0 + w1) + 1e-8f;
     const float n0 = w0 / den, n1 = w1 / den;
     const float qx_ = n0 * px + n1 * p1x, qy_ = n0 * py + n1 * p1y, qz_ = n0 * pz + n1 * p1z;   // p'
+    TICK(1);
 
     // ---- layer 1 (model/nerf_model.py:104-108): bias + 8 projected tri-plane taps + PE columns on the MFMA ----
     f32x16 acc1[4];
@@ -551,6 +585,11 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+            if (GQ == 8) {       // block kernel: biases are LDS-resident (the texture path is this kernel's busiest unit: keep it for the taps)
+                const float4 bl = sBt[8 * m + 2 * q + h];
+                acc1[m][4 * q + 0] = bl.x; acc1[m][4 * q + 1] = bl.y; acc1[m][4 * q + 2] = bl.z; acc1[m][4 * q + 3] = bl.w;
+                continue;
+            }
             const auto bb = LDB4(OFF_B1 + 32 * m + 8 * q);
             acc1[m][4 * q + 0] = __uint_as_float(bb[0]); acc1[m][4 * q + 1] = __uint_as_float(bb[1]);
             acc1[m][4 * q + 2] = __uint_as_float(bb[2]); acc1[m][4 * q + 3] = __uint_as_float(bb[3]);
@@ -614,6 +653,7 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
             }
         }
     }
+    TICK(2);
     // ---- PE octaves 4h..4h+3 of this half-wave (model/network/embedder.py:32-61) ---------------------
     float pe[KPE_STEPS];
 #pragma unroll
@@ -624,6 +664,7 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
         pe_pair(qz_ * f, pe[6 * kk + 2], pe[6 * kk + 5]);
     }
     __builtin_amdgcn_sched_barrier(0);
+    TICK(3);
 
     if (PREC == 1) {
         if (!(a.ablate & 16))
@@ -647,6 +688,7 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
         }
     }
     relu_tiles(acc1);
+    TICK(4);
 
     __builtin_amdgcn_sched_barrier(0);
     // ---- layer 2: 128 -> 128, relu; B operands are layer-1 accumulator registers, A fragments from LDS ------
@@ -654,6 +696,11 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+            if (GQ == 8) {
+                const float4 bl = sBt[32 + 8 * m + 2 * q + h];
+                acc2[m][4 * q + 0] = bl.x; acc2[m][4 * q + 1] = bl.y; acc2[m][4 * q + 2] = bl.z; acc2[m][4 * q + 3] = bl.w;
+                continue;
+            }
             const auto bb = LDB4(OFF_B2 + 32 * m + 8 * q);
             acc2[m][4 * q + 0] = __uint_as_float(bb[0]); acc2[m][4 * q + 1] = __uint_as_float(bb[1]);
             acc2[m][4 * q + 2] = __uint_as_float(bb[2]); acc2[m][4 * q + 3] = __uint_as_float(bb[3]);
@@ -680,6 +727,7 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
         }
     }
     relu_tiles(acc2);
+    TICK(5);
 
     __builtin_amdgcn_sched_barrier(0);
     // ---- head rows rgb(3, folded fc_rgb o fc_rgbFeat) + alpha: 4 dot products over the 128 hidden units.
@@ -706,7 +754,7 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
         const auto b4 = __builtin_amdgcn_raw_buffer_load_b128(L.wrs, 0, OFF_B4 * 4, 0);
         hd0 += __uint_as_float(b4[0]); hd1 += __uint_as_float(b4[1]); hd2 += __uint_as_float(b4[2]); hd3 += __uint_as_float(b4[3]);
     }
-
+    TICK(6);
 }
 #undef LDB4
 
@@ -738,6 +786,8 @@ __device__ __forceinline__ float dpp_xor4(float v)
 template <bool RANDOM>
 __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_f32_kernel(const MarchArgs a)
 {
+    constexpr int RM = RANDOM ? 2 : 0;
+    const uint32_t call_off = RANDOM ? rng_call_off(a) : 0u;      // one memory read per kernel, not per draw
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const float* sW1 = smem + OFF_W1PE;
     const float* sW2 = smem + OFF_W2;
@@ -807,6 +857,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                 const bool valid = (s < S) && rayok;
                 if (s > S - 1) s = S - 1;
                 const long long gr = rayok ? ray0 + slot : ray0;
+                const RKey rkey = RANDOM ? rng_ray_key(a, gr, call_off) : RKey{0u, 0u, 0u};
                 const int b = (int)(gr / a.p.R);
                 const float* ray = a.rays + gr * a.p.ray_stride;
                 const float ox = ray[0], oy = ray[1], oz = ray[2], dx = ray[3], dy = ray[4], dz = ray[5];
@@ -815,8 +866,8 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                 float z, znb;      // depth of this sample and of the neighbour that defines `dists`
                 const int snb = (s + 1 < S) ? s + 1 : S - 2;       // utils/nerf_util.py:36-37 (last dist repeated)
                 if (pass == 0) {
-                    z = z_coarse<RANDOM>(a, gr, s, near, far);
-                    znb = z_coarse<RANDOM>(a, gr, snb, near, far);
+                    z = z_coarse<RM>(a, gr, rkey, s, near, far);
+                    znb = z_coarse<RM>(a, gr, rkey, snb, near, far);
                 } else {
                     z = s_zf[slot * a.s_pad_f + s];
                     znb = s_zf[slot * a.s_pad_f + snb];
@@ -825,14 +876,17 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
 
                 f32x16 acc2[4];
                 float hd0, hd1, hd2, hd3;
-                sample_eval<16, 0>(a, L, b, ox, oy, oz, dx, dy, dz, z, acc2, hd0, hd1, hd2, hd3);
+#ifdef HAV_PROFILE
+                ProfCtx P;
+#endif
+                sample_eval<16, 0>(a, L, b, ox, oy, oz, dx, dy, dz, z, acc2, hd0, hd1, hd2, hd3 PROF_PASS);
 
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- volume_render_radiance_field (utils/nerf_util.py:28-73) -------------------------------
                 float sg = hd3;
                 if (RANDOM && a.p.noise_std > 0.f) {
                     const float* nz = pass == 0 ? a.noise_c : a.noise_f;
-                    const float e = nz ? nz[gr * S + s] : rng_normal(a, gr, s, pass == 0 ? STREAM_EPS_C : STREAM_EPS_F);
+                    const float e = nz ? nz[gr * S + s] : rng_normal(a, rkey, gr, s, pass == 0 ? STREAM_EPS_C : STREAM_EPS_F);
                     sg += e * a.p.noise_std;
                 }
                 sg = fmaxf(sg, 0.f);
@@ -926,6 +980,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                 }
                 for (int slot = 0; slot < (has1 ? 2 : 1); ++slot) {
                     const long long gr = ray0 + slot;
+                    const RKey rkey = RANDOM ? rng_ray_key(a, gr, call_off) : RKey{0u, 0u, 0u};
                     const float* racc = s_racc + slot * RACC_N;
                     const float accv = racc[R_ACC];
                     float* rgb = (pass == 0 ? a.out.rgb_coarse : a.out.rgb_fine) + gr * 67;
@@ -947,6 +1002,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
             if (pass == 0 && S_fp > 0 && !(a.ablate & 128)) {
                 const int slot = h, li = j;                       // half-wave h prepares ray slot h
                 const long long gr = (slot == 0 || has1) ? ray0 + slot : ray0;
+                const RKey rkey = RANDOM ? rng_ray_key(a, gr, call_off) : RKey{0u, 0u, 0u};
                 const float* ray = a.rays + gr * a.p.ray_stride;
                 const float near = ray[6], far = ray[7];
                 const int nb = S_c - 1, nw = S_c - 2, S_half = (S_c + 1) >> 1, S_f = a.p.S_f;
@@ -968,7 +1024,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                         const float st = 1.0f / (float)(S_f - 1);
                         u = (S_f == 1) ? 0.f : ((k < S_f / 2) ? st * (float)k : 1.0f - st * (float)(S_f - 1 - k));
                     } else {
-                        const float zeta = a.u_rand ? a.u_rand[gr * S_f + k] : rng_uniform(a, gr, k, STREAM_ZETA);
+                        const float zeta = a.u_rand ? a.u_rand[gr * S_f + k] : rng_uniform(a, rkey, k, STREAM_ZETA);
                         const float sN = (float)(1.0 / (double)S_f);
                         u = (float)k * sN + zeta * (float)(1.0 / (double)S_f - 1e-6);
                     }
@@ -978,11 +1034,11 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                     float dnm = cdf[above] - cdf[below];
                     if (dnm < 1e-5f) dnm = 1.0f;
                     const float tt = (u - cdf[below]) / dnm;
-                    const float bl = 0.5f * (z_coarse<RANDOM>(a, gr, below + 1, near, far) + z_coarse<RANDOM>(a, gr, below, near, far));
-                    const float ba = 0.5f * (z_coarse<RANDOM>(a, gr, above + 1, near, far) + z_coarse<RANDOM>(a, gr, above, near, far));
+                    const float bl = 0.5f * (z_coarse<RM>(a, gr, rkey, below + 1, near, far) + z_coarse<RM>(a, gr, rkey, below, near, far));
+                    const float ba = 0.5f * (z_coarse<RM>(a, gr, rkey, above + 1, near, far) + z_coarse<RM>(a, gr, rkey, above, near, far));
                     cand[S_half + k] = bl + tt * (ba - bl);
                 }
-                for (int i = li; i < S_half; i += 32) cand[i] = z_coarse<RANDOM>(a, gr, 2 * i, near, far);   // z_vals[:, ::2]
+                for (int i = li; i < S_half; i += 32) cand[i] = z_coarse<RM>(a, gr, rkey, 2 * i, near, far);   // z_vals[:, ::2]
                 wave_lds_sync();
                 for (int e = li; e < S_fp; e += 32) {              // rank sort == torch.sort on 48 values
                     const float v = cand[e];
@@ -1010,16 +1066,18 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
 // row; the 16 importance samples per ray live in LDS and are merged with the even coarse depths on the fly.
 // Requires S_c <= 67 when a fine pass is requested (host falls back to the pair kernel otherwise).
 // ------------------------------------------------------------------------------------------------
-template <bool RANDOM, int PREC>
+template <int RANDOM, int PREC>
 __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_blk_kernel(const MarchArgs a)
 {
+    constexpr int RM = RANDOM;
+    const uint32_t call_off = RANDOM ? rng_call_off(a) : 0u;      // one memory read per kernel, not per draw
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int WLDS = PREC == 1 ? LDS3_FLOATS : LDS_FLOATS;     // LDS image: fp32 fragments | split-bf16 fragments
     const float* sWFF = smem + OFF_WFT;           // PREC 0: fc_rgbFeat fragments live in the WFT slot (PREC 1 streams them from L2)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* s_n = smem + WLDS + wave * a.scr_floats;      // [S_f][32] importance samples of this wave's rays
+    float* s_n = smem + WLDS + 256 + wave * a.scr_floats;      // [S_f][32] importance samples of this wave's rays (after the b1|b2 copy)
     if (PREC == 1) {
         const float4* src = reinterpret_cast<const float4*>(a.blob + OFF_A1S);
         float4* dst = reinterpret_cast<float4*>(smem);
@@ -1032,13 +1090,21 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
         float4* dstf = reinterpret_cast<float4*>(smem + OFF_WFT);
         for (int i = tid; i < K2_STEPS * 2 * 64 / 4; i += MARCH_THREADS) dstf[i] = srcf[i];
     }
+    if (tid < 64) reinterpret_cast<float4*>(smem + WLDS)[tid] = reinterpret_cast<const float4*>(a.blob + OFF_B1)[tid];   // b1 | b2
     __syncthreads();
 
+#ifdef HAV_PROFILE
+    ProfCtx P;
+    for (int i = 0; i < HAV_NPROF; ++i) P.acc[i] = 0;
+    const unsigned long long t_kernel0 = __builtin_amdgcn_s_memtime();
+    P.t = t_kernel0;
+#endif
     const int j = lane & 31, h = lane >> 5;
     LaneCtx L;
     L.sW1 = smem + OFF_W1PE; L.sW2 = smem + OFF_W2;
     L.sW4 = reinterpret_cast<const float4*>(smem + (PREC == 1 ? (OFF_W4S - OFF_A1S) : OFF_W4));
     L.sA1 = reinterpret_cast<const uint4*>(smem); L.sA2 = reinterpret_cast<const uint4*>(smem + (OFF_A2S - OFF_A1S));
+    L.sB = reinterpret_cast<const float4*>(smem + WLDS);
     L.wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.blob), 0, BLOB_FLOATS * 4, 0x00020000);
     L.lane = lane; L.h = h; L.hoff = h * 16;
 
@@ -1047,6 +1113,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
     const int bpf = (R + 31) >> 5;                       // blocks per frame: a block never straddles two frames
     const long long nblk = (long long)bpf * a.p.B;
 
+    for (int q = 0; q < wave * a.stagger; ++q) __builtin_amdgcn_s_sleep(1);      // 64 cycles each
     long long chunk, base, span;
     int lb, nbx;
     if ((gridDim.x & 7) == 0) {
@@ -1068,6 +1135,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
         const float near = ray[6], far = ray[7];
         const float dn = sqrtf(dx * dx + dy * dy + dz * dz);
         float* wpark = a.out.rgb_fine ? a.out.rgb_fine + gr * 67 : nullptr;   // this ray's parking row for w[0..S_c)
+        const RKey rkey = RANDOM ? rng_ray_key(a, gr, call_off) : RKey{0u, 0u, 0u};
 
         for (int pass = 0; pass < (S_fp > 0 ? 2 : 1); ++pass) {
             const int S = pass == 0 ? S_c : S_fp;
@@ -1083,14 +1151,14 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
             auto next_fine = [&]() -> float {
                 const bool take_e = (ie < S_half) && (ik >= S_f || ze <= nk);
                 const float v = take_e ? ze : nk;
-                if (take_e) { ++ie; ze = (ie < S_half) ? z_coarse<RANDOM>(a, gr, 2 * ie, near, far) : 3.0e38f; }
+                if (take_e) { ++ie; ze = (ie < S_half) ? z_coarse<RM>(a, gr, rkey, 2 * ie, near, far) : 3.0e38f; }
                 else { ++ik; nk = (ik < S_f) ? s_n[ik * 32 + j] : 3.0e38f; }
                 return v;
             };
             float z, znext;
-            if (pass == 0) { z = z_coarse<RANDOM>(a, gr, 0, near, far); znext = z_coarse<RANDOM>(a, gr, 1, near, far); }
+            if (pass == 0) { z = z_coarse<RM>(a, gr, rkey, 0, near, far); znext = z_coarse<RM>(a, gr, rkey, 1, near, far); }
             else {
-                ze = z_coarse<RANDOM>(a, gr, 0, near, far);
+                ze = z_coarse<RM>(a, gr, rkey, 0, near, far);
                 nk = s_n[j];
                 z = next_fine(); znext = next_fine();
             }
@@ -1099,13 +1167,14 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
             for (int s = 0; s < S; ++s) {
                 f32x16 acc2[4];
                 float hd0, hd1, hd2, hd3;
-                sample_eval<8, PREC>(a, L, b, ox, oy, oz, dx, dy, dz, z, acc2, hd0, hd1, hd2, hd3);
+                TICK(0);
+                sample_eval<8, PREC>(a, L, b, ox, oy, oz, dx, dy, dz, z, acc2, hd0, hd1, hd2, hd3 PROF_PASS);
                 __builtin_amdgcn_sched_barrier(0);
                 // volume_render_radiance_field (utils/nerf_util.py:28-73), one ray per lane, sequential in s
                 float sg = hd3;
                 if (RANDOM && a.p.noise_std > 0.f) {
                     const float* nz = pass == 0 ? a.noise_c : a.noise_f;
-                    const float e = nz ? nz[gr * S + s] : rng_normal(a, gr, s, pass == 0 ? STREAM_EPS_C : STREAM_EPS_F);
+                    const float e = (RANDOM == 2 && nz) ? nz[gr * S + s] : rng_normal(a, rkey, gr, s, pass == 0 ? STREAM_EPS_C : STREAM_EPS_F);
                     sg += e * a.p.noise_std;
                 }
                 sg = fmaxf(sg, 0.f);
@@ -1128,10 +1197,11 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                 // advance: dists[-1] repeats dists[-2] (:36-37)
                 z = znext;
                 if (s + 2 < S) {
-                    znext = pass == 0 ? z_coarse<RANDOM>(a, gr, s + 2, near, far) : next_fine();
+                    znext = pass == 0 ? z_coarse<RM>(a, gr, rkey, s + 2, near, far) : next_fine();
                     dist = znext - z;
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                TICK(7);
             }
 
             // ---- fc_rgbFeat on the composited hidden units: [64 x 128] . [128 x 32 rays] on the matrix cores -------------
@@ -1189,6 +1259,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                 }
             }
 
+            TICK(8);
             // ---- inverse-CDF resampling (utils/nerf_util.py:76-117): one ray per lane, one sequential sweep over the CDF ----
             if (pass == 0 && S_fp > 0) {
                 const int nw = S_c - 2, nb = S_c - 1;
@@ -1201,15 +1272,15 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                         const float st = 1.0f / (float)(S_f - 1);
                         return (S_f == 1) ? 0.f : ((kk < S_f / 2) ? st * (float)kk : 1.0f - st * (float)(S_f - 1 - kk));
                     }
-                    const float zeta = a.u_rand ? a.u_rand[gr * S_f + kk] : rng_uniform(a, gr, kk, STREAM_ZETA);
+                    const float zeta = (RANDOM == 2 && a.u_rand) ? a.u_rand[gr * S_f + kk] : rng_uniform(a, rkey, kk, STREAM_ZETA);
                     const float sN = (float)(1.0 / (double)S_f);
                     return (float)kk * sN + zeta * (float)(1.0 / (double)S_f - 1e-6);
                 };
                 float u = u_of(0);
                 // bin centres are carried along the sweep (one coarse depth per bin) so the emission loop, which runs
                 // whenever ANY of the 32 rays emits, stays a handful of instructions
-                float zi = z_coarse<RANDOM>(a, gr, 0, near, far), zi1 = z_coarse<RANDOM>(a, gr, 1, near, far);
-                float zi2 = z_coarse<RANDOM>(a, gr, 2, near, far);
+                float zi = z_coarse<RM>(a, gr, rkey, 0, near, far), zi1 = z_coarse<RM>(a, gr, rkey, 1, near, far);
+                float zi2 = z_coarse<RM>(a, gr, rkey, 2, near, far);
                 for (int i = 0; i < nw; ++i) {
                     run += (wpark[1 + i] + 1e-5f) / sum;
                     const float cdf_hi = run;
@@ -1224,22 +1295,39 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                     }
                     cdf_lo = cdf_hi;
                     zi = zi1; zi1 = zi2;
-                    if (i + 3 < S_c) zi2 = z_coarse<RANDOM>(a, gr, i + 3, near, far);
+                    if (i + 3 < S_c) zi2 = z_coarse<RM>(a, gr, rkey, i + 3, near, far);
                 }
                 if (k < S_f) {                               // u >= cdf[nb-1]: below = above = nb-1 -> the last bin centre
-                    const float zl = 0.5f * (z_coarse<RANDOM>(a, gr, nb, near, far) + z_coarse<RANDOM>(a, gr, nb - 1, near, far));
+                    const float zl = 0.5f * (z_coarse<RM>(a, gr, rkey, nb, near, far) + z_coarse<RM>(a, gr, rkey, nb - 1, near, far));
                     for (; k < S_f; ++k) if (h == 0) s_n[k * 32 + j] = zl;
                 }
                 wave_lds_sync();
             }
+            TICK(9);
         }   // pass
         wave_lds_sync();
     }       // blocks
+#ifdef HAV_PROFILE
+    P.acc[10] = __builtin_amdgcn_s_memtime() - t_kernel0;
+    if (lane == 0)
+        for (int i = 0; i < HAV_NPROF; ++i) atomicAdd(&g_prof[i], P.acc[i]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+#ifdef HAV_PROFILE
+// phase-timing build only: copy (and clear) the per-phase cycle sums
+extern "C" int hav_debug_read_prof(unsigned long long* out12)
+{
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(out12, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * HAV_NPROF);
+    unsigned long long z[HAV_NPROF] = {};
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z));
+    return (int)e;
+}
+#endif
 static float* g_dbg_zfine = nullptr;
 // test hook: next hav_render_rays call also dumps the merged fine depths [B*R,S_fp] to this device buffer
 extern "C" void hav_debug_set_zfine(float* dev_ptr) { g_dbg_zfine = dev_ptr; }
@@ -1264,8 +1352,8 @@ extern "C" const char* hav_render_variant(const HavRenderParams* p)
     if (!p) return "";
     const bool rnd = p->perturb != 0 || p->noise_std > 0.f;
     if (use_block_kernel(p)) {
-        if (use_split_mfma(p)) return rnd ? "hav_march_blk_kernel<true, 1>" : "hav_march_blk_kernel<false, 1>";
-        return rnd ? "hav_march_blk_kernel<true, 0>" : "hav_march_blk_kernel<false, 0>";
+        if (use_split_mfma(p)) return rnd ? "hav_march_blk_kernel<1, 1>" : "hav_march_blk_kernel<0, 1>";
+        return rnd ? "hav_march_blk_kernel<2, 0>" : "hav_march_blk_kernel<0, 0>";
     }
     return rnd ? "hav_march_f32_kernel<true>" : "hav_march_f32_kernel<false>";
 }
@@ -1293,6 +1381,7 @@ extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, cons
     a.out = *out;
     a.dbg_zfine = g_dbg_zfine; g_dbg_zfine = nullptr;
     { const char* e = getenv("HAV_ABLATE"); a.ablate = e ? atoi(e) : 0; }
+    { const char* e = getenv("HAV_STAGGER"); a.stagger = e ? atoi(e) : 0; }
     a.NR = (long long)p->B * p->R;
     a.S_fp = p->S_f > 0 ? (p->S_c + 1) / 2 + p->S_f : 0;
     a.s_pad_c = (p->S_c + 15) & ~15;
@@ -1309,10 +1398,11 @@ extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, cons
     const bool random = p->perturb != 0 || p->noise_std > 0.f;
     static bool attr_set = false;
     if (!attr_set) {
-        const void* ks[6] = {(const void*)hav_march_f32_kernel<false>, (const void*)hav_march_f32_kernel<true>,
-                             (const void*)hav_march_blk_kernel<false, 0>, (const void*)hav_march_blk_kernel<true, 0>,
-                             (const void*)hav_march_blk_kernel<false, 1>, (const void*)hav_march_blk_kernel<true, 1>};
-        for (int i = 0; i < 6; ++i) {
+        const void* ks[7] = {(const void*)hav_march_f32_kernel<false>, (const void*)hav_march_f32_kernel<true>,
+                             (const void*)hav_march_blk_kernel<0, 0>, (const void*)hav_march_blk_kernel<2, 0>,
+                             (const void*)hav_march_blk_kernel<0, 1>, (const void*)hav_march_blk_kernel<1, 1>,
+                             (const void*)hav_march_blk_kernel<2, 1>};
+        for (int i = 0; i < 7; ++i) {
             hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return (int)e;
         }
@@ -1321,18 +1411,20 @@ extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, cons
     if (use_block_kernel(p)) {
         a.scr_floats = ((p->S_f > 0 ? p->S_f : 1) * 32 + 3) & ~3;
         const bool split = use_split_mfma(p);
-        const size_t ldsb = ((size_t)(split ? LDS3_FLOATS : LDS_FLOATS) + (size_t)MARCH_WAVES * a.scr_floats) * sizeof(float);
+        const size_t ldsb = ((size_t)(split ? LDS3_FLOATS : LDS_FLOATS) + 256 + (size_t)MARCH_WAVES * a.scr_floats) * sizeof(float);
         if (ldsb > 160 * 1024) return HAV_EUNSUP;
         const long long nblk = (long long)((p->R + 31) / 32) * p->B;
         int gridb = hav_num_cus();
         const long long needb = (nblk + MARCH_WAVES - 1) / MARCH_WAVES;
         if (needb < gridb) gridb = (int)((needb + 7) / 8 * 8);
+        const bool injected = t_rand || u_rand || noise_c || noise_f;     // parity tests; production draws everything on the device
         if (split) {
-            if (random) hipLaunchKernelGGL((hav_march_blk_kernel<true, 1>), dim3(gridb), dim3(MARCH_THREADS), ldsb, (hipStream_t)stream, a);
-            else hipLaunchKernelGGL((hav_march_blk_kernel<false, 1>), dim3(gridb), dim3(MARCH_THREADS), ldsb, (hipStream_t)stream, a);
+            if (random && injected) hipLaunchKernelGGL((hav_march_blk_kernel<2, 1>), dim3(gridb), dim3(MARCH_THREADS), ldsb, (hipStream_t)stream, a);
+            else if (random) hipLaunchKernelGGL((hav_march_blk_kernel<1, 1>), dim3(gridb), dim3(MARCH_THREADS), ldsb, (hipStream_t)stream, a);
+            else hipLaunchKernelGGL((hav_march_blk_kernel<0, 1>), dim3(gridb), dim3(MARCH_THREADS), ldsb, (hipStream_t)stream, a);
         } else {
-            if (random) hipLaunchKernelGGL((hav_march_blk_kernel<true, 0>), dim3(gridb), dim3(MARCH_THREADS), ldsb, (hipStream_t)stream, a);
-            else hipLaunchKernelGGL((hav_march_blk_kernel<false, 0>), dim3(gridb), dim3(MARCH_THREADS), ldsb, (hipStream_t)stream, a);
+            if (random) hipLaunchKernelGGL((hav_march_blk_kernel<2, 0>), dim3(gridb), dim3(MARCH_THREADS), ldsb, (hipStream_t)stream, a);
+            else hipLaunchKernelGGL((hav_march_blk_kernel<0, 0>), dim3(gridb), dim3(MARCH_THREADS), ldsb, (hipStream_t)stream, a);
         }
         HAV_LAUNCH_CHECK();
         if (p->rng_counter && random) { hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)p->rng_counter); HAV_LAUNCH_CHECK(); }

@@ -78,6 +78,15 @@ def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
         pad = (pad[0], pad[1], pad[0], pad[1])
     if input.device.type == "cpu":
         return upfirdn2d_native(input, kernel, *up, *down, *pad)
+    if not (torch.is_grad_enabled() and input.requires_grad):
+        # inference: straight to the native op (the autograd Function would flip the FIR for a backward that never comes:
+        # one more launch per call, ~50 per frame)
+        _, channel, in_h, in_w = input.shape
+        x = input.reshape(-1, in_h, in_w, 1)
+        if not x.is_contiguous():
+            x = x.contiguous()
+        out = upfirdn2d_op.upfirdn2d(x, kernel, up[0], up[1], down[0], down[1], *pad)
+        return out.view(-1, channel, out.shape[1], out.shape[2])
     return UpFirDn2d.apply(input, kernel, tuple(up), tuple(down), tuple(pad))
 
 

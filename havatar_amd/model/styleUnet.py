@@ -146,10 +146,30 @@ class ModulatedConv2d(nn.Module, _InferenceCache):
         self.demodulate = demodulate
         self.fused = fused
 
-    def forward(self, input, style):
+    def _hip_inference(self, input):
+        return input.is_cuda and input.dtype == torch.float32 and not torch.is_grad_enabled()
+
+    def style_vectors(self, style):
+        """(s [B,Cin], d [B,Cout] | None).  HIP inference: one launch (hav_style_demod) instead of EqualLinear + bias + square +
+        matmul + eps + rsqrt; otherwise the ATen sequence."""
+        mod = self.modulation
+        # sum_{i,ky,kx} (w[o,i] s[b,i])^2 = sum_i s[b,i]^2 * sum_k w[o,i,k]^2
+        wsq = self._cached("wsq", self.weight, lambda: (self.scale * self.weight[0]).pow(2).sum((2, 3)).t().contiguous()) \
+            if self.demodulate else None
+        if self._hip_inference(style) and mod.activation is None:
+            from ..native import fused
+            mw = mod._cached("w", mod.weight, lambda: mod.weight * mod.scale)
+            mb = mod._cached("b", mod.bias, lambda: mod.bias * mod.lr_mul) if mod.bias is not None else None
+            return fused.style_demod(style.contiguous(), mw, mb, wsq, self.eps)
+        s = mod(style)
+        d = torch.rsqrt(torch.matmul(s * s, wsq) + self.eps) if self.demodulate else None
+        return s, d
+
+    def forward_raw(self, input, style):
+        """(conv(x * s) BEFORE demodulation, d): callers that fuse the demodulation into their epilogue use this."""
         B, Cin = input.shape[:2]
         w = self._cached("w", self.weight, lambda: self.scale * self.weight[0])          # [Cout,Cin,k,k]
-        s = self.modulation(style)                                        # [B,Cin]
+        s, d = self.style_vectors(style)                                                  # [B,Cin], [B,Cout]
         x = input * s.view(B, Cin, 1, 1)
         if self.upsample:
             wt = self._cached("wt", self.weight, lambda: (self.scale * self.weight[0]).transpose(0, 1).contiguous())
@@ -158,11 +178,12 @@ class ModulatedConv2d(nn.Module, _InferenceCache):
             out = conv2d_gradfix.conv2d(self.blur(x), w, padding=0, stride=2)
         else:
             out = conv2d_gradfix.conv2d(x, w, padding=self.padding)
-        if self.demodulate:
-            # sum_{i,ky,kx} (w[o,i] s[b,i])^2 = sum_i s[b,i]^2 * sum_k w[o,i,k]^2
-            wsq = self._cached("wsq", self.weight, lambda: (self.scale * self.weight[0]).pow(2).sum((2, 3)).t().contiguous())
-            d = torch.rsqrt(torch.matmul(s * s, wsq) + self.eps)                              # [B,Cout]
-            out = out * d.view(B, -1, 1, 1)
+        return out, d
+
+    def forward(self, input, style):
+        out, d = self.forward_raw(input, style)
+        if d is not None:
+            out = out * d.view(out.shape[0], -1, 1, 1)
         return out
 
 
@@ -272,6 +293,15 @@ class StyledConv(nn.Module):
         self.activate = FusedLeakyReLU(out_channel)
 
     def forward(self, input, style, noise=None):
+        if self.conv._hip_inference(input):
+            # HIP inference: demodulation * noise injection + bias + leaky-relu in ONE pass (hav_styled_epilogue) instead of four
+            from ..native import fused
+            out, d = self.conv.forward_raw(input, style)
+            if noise is None:
+                b, _, h, w = out.shape
+                noise = out.new_empty(b, 1, h, w).normal_()
+            return fused.styled_epilogue(out.contiguous(), d, noise.contiguous(), self.noise.weight, self.activate.bias,
+                                         self.activate.negative_slope, self.activate.scale)
         return self.activate(self.noise(self.conv(input, style), noise=noise))
 
 

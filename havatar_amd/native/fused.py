@@ -46,3 +46,53 @@ def fused_bias_act(input, bias, refer, act, grad, alpha, scale):
             C.c_void_p(torch.cuda.current_stream().cuda_stream))
     _lib.check(rc, "hav_fused_bias_act")
     return out
+
+
+def _f32c(t, name):
+    _check_input(t, name)
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32")
+    return t
+
+
+def style_demod(style, mod_w, mod_b, wsq=None, eps=1e-8):
+    """(s [B,Cin], d [B,Cout] | None): style vector and demodulation factors of one ModulatedConv2d in one launch
+    (hav_style_demod; replaces EqualLinear + bias + square + matmul + eps + rsqrt of model/styleUnet.py:196-254)."""
+    style, mod_w = _f32c(style, "style"), _f32c(mod_w, "mod_w")
+    B, D = style.shape
+    Cin = mod_w.shape[0]
+    s = torch.empty(B, Cin, device=style.device, dtype=torch.float32)
+    d = None
+    Cout = 0
+    if wsq is not None:
+        wsq = _f32c(wsq, "wsq")
+        Cout = wsq.shape[1]
+        d = torch.empty(B, Cout, device=style.device, dtype=torch.float32)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    with torch.cuda.device(style.device):
+        rc = _lib.lib().hav_style_demod(p(s), p(d), p(style), p(mod_w), p(_f32c(mod_b, "mod_b") if mod_b is not None else None), p(wsq),
+                                        float(eps), B, D, Cin, Cout, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, "hav_style_demod")
+    return s, d
+
+
+def styled_epilogue(x, demod, noise, noise_weight, bias, negative_slope=0.2, scale=2 ** 0.5):
+    """leaky_relu((x * demod[b,c] + noise_weight * noise) + bias[c]) * scale in one pass (hav_styled_epilogue)."""
+    x = _f32c(x, "x")
+    B, Cc, H, W = x.shape
+    out = torch.empty_like(x)
+    nb = 0
+    if noise is not None:
+        noise = _f32c(noise, "noise")
+        if noise.numel() == B * H * W and B > 1:
+            nb = 1
+        elif noise.numel() != H * W:
+            raise RuntimeError("styled_epilogue: noise must be [1,1,H,W] or [B,1,H,W]")
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().hav_styled_epilogue(p(out), p(x), p(_f32c(demod, "demod") if demod is not None else None), p(noise),
+                                            p(noise_weight), p(_f32c(bias, "bias") if bias is not None else None),
+                                            float(negative_slope), float(scale), B, Cc, H * W, nb,
+                                            C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, "hav_styled_epilogue")
+    return out

@@ -67,6 +67,25 @@ int hav_upfirdn2d_out_size(int in_h, int in_w, int kh, int kw, int up_x, int up_
                            int pad_y1, int* out_h, int* out_w);
 
 /* ------------------------------------------------------------------------------------------
+ * StyleGAN2 block glue -- the tiny-op chains around every modulated convolution of the tri-plane encoders / the upsampler
+ * (model/styleUnet.py: ModulatedConv2d.forward :196-254 non-fused branch, NoiseInjection :306-310, FusedLeakyReLU;
+ * model/op/fused_act.py).  Not separate native ops in the reference (it runs them as ~10 ATen launches per layer); here each
+ * chain is one launch.  float32 only.
+ *
+ * hav_style_demod:   s[b,i] = <style[b,:], mod_w[i,:]> + mod_b[i]                      (EqualLinear, scale folded into mod_w/mod_b)
+ *                    d[b,o] = rsqrt(sum_i s[b,i]^2 * wsq[i,o] + eps)   if d_out != NULL  (wsq[i,o] = sum_k (scale W[o,i,k])^2)
+ * hav_styled_epilogue: y = leaky_relu((x * d[b,c] + (*noise_weight) * noise[b?,p]) + bias[c], slope) * gain, every product and
+ *                    sum rounded separately in that order (== the unfused ATen sequence); d, noise, bias nullable;
+ *                    noise is [B,HW] if noise_batched else [HW].
+ * ------------------------------------------------------------------------------------------ */
+int hav_style_demod(float* s_out /*[B,Cin]*/, float* d_out /*[B,Cout] or NULL*/, const float* style /*[B,D]*/,
+                    const float* mod_w /*[Cin,D]*/, const float* mod_b /*[Cin] or NULL*/, const float* wsq /*[Cin,Cout] or NULL*/,
+                    float eps, int B, int D, int Cin, int Cout, void* stream);
+int hav_styled_epilogue(float* out, const float* x /*[B,C,HW]*/, const float* d /*[B,C] or NULL*/, const float* noise,
+                        const float* noise_weight /*device scalar or NULL*/, const float* bias /*[C] or NULL*/, float slope,
+                        float gain, int B, int C, int64_t HW, int noise_batched, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Ray march -- replaces Trainer.predict_and_render_radiance (model/nerf_trainer.py:120-201) and
  * everything it calls: ray sampling (:129-141), Deformation_Field_new.forward
  * (model/Skinning_Field.py:70-98), sample_pts_triplane_feat (model/nerf_model.py:88-99),

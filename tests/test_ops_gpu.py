@@ -202,3 +202,41 @@ def test_gen_rays_device_matches_reference_and_oracle():
     assert _lib.lib().hav_gen_rays(C.c_void_p(part.data_ptr()), H, W, intr, c2w, 3.4, 6.0, 3, 5,
                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
     assert torch.equal(part, out[3 * W:5 * W])
+
+
+def test_styled_epilogue_equals_the_unfused_sequence_bitwise():
+    """hav_styled_epilogue vs the ATen sequence of the reference block (model/styleUnet.py: ModulatedConv2d demodulation,
+    NoiseInjection :306-310, FusedLeakyReLU): same operations in the same order -> identical bits."""
+    from havatar_amd.native import fused
+    g = torch.Generator(device=DEV).manual_seed(3)
+    for B, C, H, W in ((1, 512, 64, 64), (2, 24, 16, 16), (1, 7, 5, 3)):      # last one: HW % 4 != 0 -> scalar kernel
+        x = torch.randn(B, C, H, W, device=DEV, generator=g)
+        d = torch.rand(B, C, device=DEV, generator=g) + 0.5
+        bias = torch.randn(C, device=DEV, generator=g)
+        nw = torch.randn(1, device=DEV, generator=g)
+        for noise in (torch.randn(1, 1, H, W, device=DEV, generator=g), torch.randn(B, 1, H, W, device=DEV, generator=g), None):
+            for dd in (d, None):
+                ref = x * dd.view(B, C, 1, 1) if dd is not None else x
+                if noise is not None:
+                    ref = ref + nw * noise
+                ref = torch.nn.functional.leaky_relu(ref + bias.view(1, C, 1, 1), 0.2) * S2
+                got = fused.styled_epilogue(x, dd, noise, nw if noise is not None else None, bias, 0.2, S2)
+                assert torch.equal(got, ref), (B, C, H, W, noise is not None, dd is not None)
+
+
+def test_style_demod_matches_equal_linear_and_rsqrt():
+    """hav_style_demod vs EqualLinear + the demodulation factor of ModulatedConv2d (fp32 sums in a different order: 1e-6 relative)."""
+    from havatar_amd.native import fused
+    g = torch.Generator(device=DEV).manual_seed(4)
+    for B, D, Cin, Cout in ((1, 32, 1024, 512), (2, 64, 256, 12), (1, 32, 7, 3)):
+        style = torch.randn(B, D, device=DEV, generator=g)
+        mw = torch.randn(Cin, D, device=DEV, generator=g) / D ** 0.5
+        mb = torch.ones(Cin, device=DEV)
+        wsq = torch.rand(Cin, Cout, device=DEV, generator=g) / Cin
+        s, d = fused.style_demod(style, mw, mb, wsq, 1e-8)
+        s_ref = torch.nn.functional.linear(style.double(), mw.double(), mb.double())
+        d_ref = torch.rsqrt(torch.matmul(s_ref * s_ref, wsq.double()) + 1e-8)
+        assert (s.double() - s_ref).abs().max().item() <= 2e-6 * s_ref.abs().max().item()
+        assert ((d.double() - d_ref).abs() / d_ref).max().item() <= 2e-6
+        s2, d2 = fused.style_demod(style, mw, None, None)
+        assert d2 is None and (s2.double() - (s_ref - 1.0)).abs().max().item() <= 2e-6 * s_ref.abs().max().item()
