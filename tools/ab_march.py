@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Kernel-only A/B of march-kernel builds on ONE box: python tools/ab_march.py libA.so libB.so ...  ('' = the in-tree library).
+Each library is loaded in a fresh subprocess; prints median kernel ms over N launches for perturb on/off."""
+import os
+import subprocess
+import sys
+
+CHILD = r'''
+import os, sys, ctypes as C
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+from havatar_amd import synth
+from havatar_amd.render import RayMarcher
+dev = torch.device("cuda:0")
+H = W = 512
+sc = synth.scene(H, W, "primary")
+rm = RayMarcher(sc["nerf_scale"], sc["nerf_trans"], sc["skin_scale"], sc["skin_trans"])
+t = lambda a: torch.from_numpy(a).to(dev)
+m = sc["mlp"]
+rm.set_mlp(*[t(m[k]) for k in ("W1", "b1", "W2", "b2", "Wa", "ba", "Wf", "bf", "Wc", "bc")])
+rm.set_triplane(t(sc["planes"]))
+args = (t(sc["rays"]), t(sc["bg"]), t(sc["inv_T"]), t(sc["vol"]), 64, 16)
+out = []
+for perturb in (True, False):
+    for _ in range(3): rm.render(*args, perturb=perturb)
+    ts = []
+    for _ in range(12):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); rm.render(*args, perturb=perturb); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
+    out.append("%s %.3f ms (min %.3f)" % ("perturb" if perturb else "det    ", float(np.median(ts)), min(ts)))
+print(" | ".join(out))
+'''
+for rnd in range(2):
+    for lib in sys.argv[1:]:
+        env = dict(os.environ)
+        if lib:
+            env["HAVATAR_LIB"] = os.path.abspath(lib)
+        else:
+            env.pop("HAVATAR_LIB", None)
+        r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True)
+        print("%-50s %s" % (lib or "(in-tree)", r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-300:]))

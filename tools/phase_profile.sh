@@ -4,7 +4,7 @@
 set -eu
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 ALT=havatar_amd/lib/alt/libhavatar_hip_prof.so
-if [ ! -f "$ALT" ] || [ havatar_amd/csrc/hav_render.hip -nt "$ALT" ]; then
+if [ ! -f "$ALT" ] || [ havatar_amd/csrc/hav_render.hip -nt "$ALT" ] || [ havatar_amd/csrc/hav_ops.hip -nt "$ALT" ]; then
   mkdir -p havatar_amd/lib/alt
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DHAV_PROFILE ${EXTRA:-} -c havatar_amd/csrc/hav_render.hip -o havatar_amd/lib/alt/hav_render_prof.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c havatar_amd/csrc/hav_ops.hip -o havatar_amd/lib/alt/hav_ops.o
