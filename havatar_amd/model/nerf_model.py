@@ -2,6 +2,8 @@
 (reference model/nerf_model.py:10-117).  On HIP tensors at inference only `set_conditional_embedding` (the encoders) runs
 here; gather + PE + MLP are inside the fused ray-march kernel.  `sample_pts_triplane_feat` / `forward` keep the PyTorch
 statement for CPU tensors and autograd.  Only enc_mode='split' (the Trainer's choice) is implemented."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -56,8 +58,23 @@ class ConditionalTriplaneNeRFModel_multiRender_split_view(nn.Module):
         left = cond["left_render_cond"].flip(dims=[3])
         if left.shape[1] > 3:
             left = left[:, :-1]
-        xy, _ = self.XY_gen(styles, front)
-        yz, _ = self.YZ_gen(styles, torch.cat([left, right], dim=1))
+        yz_in = torch.cat([left, right], dim=1)
+        if front.is_cuda and not torch.is_grad_enabled() and os.environ.get("HAVATAR_ENC_STREAMS", "1") != "0":
+            # The two generators are independent until the stack, and at 16^2..64^2 most of their ~90 launches each leave the
+            # GPU nearly idle: run them on two HIP streams (fork/join by events; captured as two branches of the frame's hipGraph).
+            cur = torch.cuda.current_stream(front.device)
+            side = self.__dict__.get("_side_stream")
+            if side is None or side.device != front.device:
+                side = self.__dict__["_side_stream"] = torch.cuda.Stream(device=front.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                yz, _ = self.YZ_gen(styles, yz_in)
+            xy, _ = self.XY_gen(styles, front)
+            cur.wait_stream(side)
+            yz.record_stream(cur)
+        else:
+            xy, _ = self.XY_gen(styles, front)
+            yz, _ = self.YZ_gen(styles, yz_in)
         self.triPlane_embeddings = torch.stack([xy, yz], dim=0)
 
     def sample_pts_triplane_feat(self, batch_pts, bidx=None):

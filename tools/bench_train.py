@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""cfg5: one stage-one optimisation step, B=2 frames x 4096 rays (64x64 patch), 64+48 samples per ray, on the GPU.
+Today the step runs the PyTorch statement of the march under autograd; this prints its time so the HIP backward has
+a number to beat."""
+import os
+import sys
+import tempfile
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from havatar_amd import synth
+from havatar_amd.dataloader.dataloader import Loader
+from havatar_amd.harness import train
+from havatar_amd.model.nerf_trainer import Trainer
+from havatar_amd.utils.cfgnode import CfgNode
+
+dev = torch.device("cuda:0")
+tmp = tempfile.mkdtemp()
+split = synth.write_dataset(tmp, n_frames=2, img_res=512)
+cfgd = synth.harness_config(render_size=128, gen_size=512, img_res=512, perturb=True, noise_std=0.1, rays=4096)
+cfgd["experiment"]["patch_rgb"] = True            # 64x64 patch = 4096 rays per frame, as the reference trains
+cfg = CfgNode(cfgd)
+np.random.seed(0); torch.manual_seed(0)
+tl = Loader(split_file=split, mode="train", batch_size=2, num_workers=0, down_sample=cfg.dataset.down_sample, options=cfg, white_bg=True, shuffle=False)
+idx, batch = next(iter(tl))
+trainer = synth.fill_state_dict(Trainer(cfg, len(tl.dataset))).to(dev).train()
+opt = torch.optim.Adam(trainer.parameters(), lr=5e-4)
+inp, target, mask = train.step_inputs(idx, batch, dev)
+torch.backends.cudnn.benchmark = True
+
+
+def step():
+    loss, parts, psnr = train.training_loss(trainer, cfg, inp, target, mask, torch.nn.functional.mse_loss)
+    loss.backward()
+    opt.step(); opt.zero_grad()
+    return loss
+
+
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+n = 10
+t0 = time.perf_counter()
+for _ in range(n):
+    l = step()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / n
+rays = inp["ray_batch"].shape[0] * inp["ray_batch"].shape[1]
+print("train step: %.1f ms  (%d rays x 112 samples = %.2f M queries, %.2f M queries/s), loss %.4f" % (dt * 1e3, rays, rays * 112 / 1e6, rays * 112 / dt / 1e6, l.item()))
