@@ -50,3 +50,25 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
 rays = inp["ray_batch"].shape[0] * inp["ray_batch"].shape[1]
 print("train step: %.1f ms  (%d rays x 112 samples = %.2f M queries, %.2f M queries/s), loss %.4f" % (dt * 1e3, rays, rays * 112 / 1e6, rays * 112 / dt / 1e6, l.item()))
+
+
+def timed(fn, n=5):
+    ts = []
+    for _ in range(n):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); r = fn(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
+    return float(np.median(ts)), r
+
+
+t_vol, _ = timed(lambda: trainer.headpose_skin_net.canonical_Wvolume())
+lat = trainer.latent_codes[idx.to(dev)] if trainer.latent_codes is not None else None
+t_enc, _ = timed(lambda: trainer.model_coarse.set_conditional_embedding(
+    front_render_cond=inp["front_render_cond"], left_render_cond=inp["left_render_cond"], right_render_cond=inp["right_render_cond"],
+    latents=lat, cond_c=inp["inv_head_T"].reshape(2, -1)))
+t_fwd, (loss, _, _) = timed(lambda: train.training_loss(trainer, cfg, inp, target, mask, torch.nn.functional.mse_loss), n=3)
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record(); loss.backward(); b.record(); torch.cuda.synchronize()
+t_bwd = a.elapsed_time(b)
+opt.zero_grad()
+print("  forward %.1f ms (volume decoder %.1f x2, encoders %.1f, rest = march + loss %.1f) | backward %.1f ms" % (
+    t_fwd, t_vol, t_enc, t_fwd - 2 * t_vol - t_enc, t_bwd))
