@@ -174,3 +174,24 @@ def test_swgan_unet_hip_matches_reference(gold):
     with torch.no_grad():
         img = g(styles=[style], condition_img=cond, randomize_noise=False)
     assert linf(img[:, :, ::16, ::16].cpu().numpy(), gold["swgan_slice"]) <= 2e-3 * float(gold["swgan_cks"][2])
+
+
+@pytest.mark.gpu
+def test_stage_two_cfg4_size_fused_path_equals_aten_path():
+    """BASELINE config 4 size (SWGAN_unet 512 -> 1024, the [1,64,512,512] bias-act and [64,513,513] blur shapes): the inference
+    route (hav_style_demod / hav_styled_epilogue / direct upfirdn2d) against the same module on its autograd route (the
+    reference's ATen chain through the autograd wrappers of model/op) -- same weights, same noise buffers."""
+    from havatar_amd.model.styleUnet import SWGAN_unet
+    g = SWGAN_unet(inp_size=512, inp_ch=64, out_ch=3, out_size=1024, style_dim=64, n_mlp=4, channel_multiplier=2)
+    g.requires_grad_(False)
+    synth.fill_state_dict(g, seed=2)
+    g = g.cuda().eval()
+    cond = torch.from_numpy(synth.normal((1, 64, 512, 512), 92, 0.5)).cuda()
+    style = torch.from_numpy(synth.normal((1, 64), 93)).cuda()
+    with torch.no_grad():
+        fused = g(styles=[style], condition_img=cond, randomize_noise=False)
+    with torch.enable_grad():
+        plain = g(styles=[style], condition_img=cond.clone().requires_grad_(True), randomize_noise=False).detach()
+    assert fused.shape == (1, 3, 1024, 1024) and torch.isfinite(fused).all()
+    scale = plain.abs().max().item()
+    assert scale > 0.1 and (fused - plain).abs().max().item() <= 2e-5 * scale
