@@ -91,6 +91,16 @@ class SplitFileDataset(Dataset):
             cam_K = self.mv_intrinsics[view_idx]
         return view_idx, view, cam_K, pose
 
+    def camera_record(self, view, cam_K, pose):
+        """[18] = intr(4) | c2w[3,4](12) | near | far : everything hav_gen_rays needs to rebuild this view's full-frame ray table on
+        the device (test-mode readers with `device_rays=True`; white background only)."""
+        cam_t = torch.from_numpy(np.asarray(view["transform_matrix_ori"], dtype=np.float32))[:3, -1]
+        dist = float(torch.norm(cam_t))
+        near = dist + self.options.dataset.near * self.options.dataset.length
+        far = dist + self.options.dataset.far * self.options.dataset.length
+        return torch.cat([torch.as_tensor(np.asarray(cam_K, np.float32)[:4]), pose[:3, :4].reshape(-1).float(),
+                          torch.tensor([near, far], dtype=torch.float32)])
+
     def rays_for(self, view_idx, view, cam_K, pose, select_inds, ray_m, with_mask):
         """[n, 11 (+1)] = origin3, dir3, near, far, background3 (, mask) -- dataloader.py:168-185."""
         ray_o, ray_d = data_util.get_rays(self.img_h, self.img_w, cam_K, pose[:3, :4], normalize=True)

@@ -10,9 +10,13 @@ from ._base import SplitFileDataset, make_render_cond_, worker_init_fn  # noqa: 
 
 class MultiView_ImgDataset(SplitFileDataset):
     skip_view = None                                 # every view is kept (dataloaderSR.py:44-49)
+    device_rays = False                              # test mode: emit the 18-float camera record instead of the [N,11] ray table
 
     def load_data(self, frame_dict):
         view_idx, view, cam_K, pose = self.view_camera(frame_dict)
+        if self.mode == "test" and self.device_rays and self.white_bg:
+            data_dict = {"fidx": frame_dict["fidx"], "vidx": [int(view["view_name"])], "camera": self.camera_record(view, cam_K, pose)}
+            return self.add_conditions(data_dict, frame_dict)
         select_inds = self.coords_yx
         mask = ray_m = None
         if self.mode == "train":

@@ -24,7 +24,7 @@ def imwrite_rgb(path, img):
     img = np.ascontiguousarray(img)
     if img.dtype != np.uint8 or img.ndim != 3 or img.shape[2] != 3:
         raise ValueError("imwrite_rgb expects uint8 [H,W,3]")
-    _pil().fromarray(img, "RGB").save(path)
+    _pil().fromarray(img, "RGB").save(path, compress_level=3)        # deflate level of cv2.imwrite's default; pixels are lossless either way
 
 
 def resize_area(img, fx):

@@ -157,3 +157,17 @@ class RayMarcher:
         p.S_c, p.S_f, p.perturb, p.noise_std = S_c, S_f, int(bool(perturb)), float(noise_std)
         p.mlp_mode = self.mlp_mode
         return _lib.lib().hav_render_variant(C.byref(p)).decode()
+
+
+def gen_rays(H, W, intr, c2w, near, far, device, out=None):
+    """[1, H*W, 8] rays (origin, unit direction, near, far) generated ON the device by hav_gen_rays: the device-side form of
+    dataloader/data_util.py::get_rays + the near/far columns of dataloader/dataloader.py:174-181.  intr = (fx, fy, cx/W, cy/H),
+    c2w = [3,4] camera-to-world.  Only 18 floats cross PCIe instead of the [H*W, 11] ray table."""
+    if out is None:
+        out = torch.empty(1, H * W, 8, device=device, dtype=torch.float32)
+    i4 = (C.c_float * 4)(*[float(v) for v in intr])
+    m12 = (C.c_float * 12)(*[float(v) for v in torch.as_tensor(c2w, dtype=torch.float32).reshape(-1)[:12]])
+    with torch.cuda.device(out.device):
+        rc = _lib.lib().hav_gen_rays(C.c_void_p(out.data_ptr()), int(H), int(W), i4, m12, float(near), float(far), 0, int(H), _stream())
+    _lib.check(rc, "hav_gen_rays")
+    return out

@@ -261,11 +261,11 @@ def cond_images(B=1, res=256, seed=60):
     return out
 
 
-def write_dataset(root, n_frames=2, img_res=128, focal=1.7, cam_dist=5.0, seed=60, views=("0",)):
+def write_dataset(root, n_frames=2, img_res=128, focal=1.7, cam_dist=5.0, seed=60, views=("0",), photos=True):
     """A tiny synthetic dataset in the reference's on-disk layout (split file `sv_v31_all.json` + PNGs, see
     havatar_amd/dataloader/_base.py) for the harness tests and demos: pinhole camera of SURVEY 8(d), per-frame head pose
-    `frame_pose(k)`, 256^2 3DMM condition renders from `cond_images`, a shaded-disc photograph and its mask per view.
-    Returns the split-file path."""
+    `frame_pose(k)`, 256^2 3DMM condition renders from `cond_images`, a shaded-disc photograph and its mask per view
+    (`photos=False` skips those two: test-mode readers never open them).  Returns the split-file path."""
     import json
     import os
 
@@ -294,8 +294,9 @@ def write_dataset(root, n_frames=2, img_res=128, focal=1.7, cam_dist=5.0, seed=6
             shade = np.sqrt(np.clip(1.0 - d2, 0.0, 1.0))
             photo = np.stack([0.8 * shade, 0.6 * shade + 0.1, 0.5 * shade + 0.2], -1) * mask[..., None]
             fp, mp = os.path.join(inst, "img_%s.png" % v), os.path.join(inst, "mask_%s.png" % v)
-            imgio.imwrite_rgb(fp, np.floor(photo * 255 + 0.5).astype(np.uint8))
-            imgio.imwrite_rgb(mp, np.repeat((mask * 255).astype(np.uint8)[..., None], 3, -1))
+            if photos:
+                imgio.imwrite_rgb(fp, np.floor(photo * 255 + 0.5).astype(np.uint8))
+                imgio.imwrite_rgb(mp, np.repeat((mask * 255).astype(np.uint8)[..., None], 3, -1))
             infos.append({"view_name": v, "transform_matrix": c2w, "transform_matrix_ori": c2w, "file_path": fp, "mask_path": mp})
         frames.append({"fidx": k, "inst_dir": inst, "head_transformation": head.tolist(), "mutiview_info_ls": infos})
     meta = {"img_res": img_res, "mutiview_intr_ls": [[focal * img_res, focal * img_res, 0.5, 0.5] for _ in views], "frames": frames}
