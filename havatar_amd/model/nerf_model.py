@@ -81,6 +81,11 @@ class ConditionalTriplaneNeRFModel_multiRender_split_view(nn.Module):
         """batch_pts [B,N,3] -> [B*N, 2C], feature index = 2*channel + plane (:88-99)."""
         q = self.gridwarper(batch_pts)
         planes = self.triPlane_embeddings if bidx is None else self.triPlane_embeddings[:, bidx]
+        if q.is_cuda and q.dtype == torch.float32 and q.ndim == 3 and planes.ndim == 5 and planes.shape[0] == 2 \
+                and os.environ.get("HAVATAR_HIP_GATHER", "1") != "0":
+            # training on HIP tensors: one coalesced gather / scatter kernel pair instead of ATen's grid_sampler on NCHW planes
+            from ..native.gather import triplane_gather
+            return triplane_gather(q, planes)
         f = sample_from_triplane_new(q, planes, padding_mode="zeros")
         return f.reshape(-1, f.shape[-1] * f.shape[-2])
 

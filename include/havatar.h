@@ -86,6 +86,18 @@ int hav_styled_epilogue(float* out, const float* x /*[B,C,HW]*/, const float* d 
                         float gain, int B, int C, int64_t HW, int noise_batched, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Tri-plane gather with gradients (training path) -- sample_from_triplane_new + its autograd (utils/util.py:359-406:
+ * two F.grid_sample(bilinear, zeros, align_corners=True) + stack): plane 0 at (q.x,q.y), plane 1 at (q.z,q.y),
+ * feat[i, 2c+p].  Planes are CHANNELS-LAST [2,B,H,W,C] here (the caller permutes; autograd carries the permutation).
+ * q [n,3] are the box-warped coordinates, query i belongs to frame i / n_per_b.
+ * bwd: dplanes_cl += scatter (caller zero-fills), dq [n,3] (nullable) = d loss / d q.
+ * ------------------------------------------------------------------------------------------ */
+int hav_triplane_gather_fwd(float* feat /*[n,2C]*/, const float* planes_cl, const float* q, int64_t n, int64_t n_per_b,
+                            int B, int H, int W, int C, void* stream);
+int hav_triplane_gather_bwd(float* dplanes_cl, float* dq, const float* dfeat /*[n,2C]*/, const float* planes_cl, const float* q,
+                            int64_t n, int64_t n_per_b, int B, int H, int W, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Ray march -- replaces Trainer.predict_and_render_radiance (model/nerf_trainer.py:120-201) and
  * everything it calls: ray sampling (:129-141), Deformation_Field_new.forward
  * (model/Skinning_Field.py:70-98), sample_pts_triplane_feat (model/nerf_model.py:88-99),
