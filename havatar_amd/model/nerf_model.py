@@ -13,6 +13,39 @@ from ..utils.sh_util import eval_sh
 from ..utils.util import create_UniformBoxWarp, sample_from_triplane_new
 
 
+class _SplitKLinear(torch.autograd.Function):
+    """y = x W^T + b for x [n, in] with n in the hundreds of thousands (every sample of every ray).  Forward and dL/dx are
+    ordinary GEMMs; the weight gradient dY^T X contracts over n, a shape ([out x n].[n x in], out,in <= 176) for which rocBLAS
+    runs a single skinny tile (0.5-1 ms per layer per pass on MI355X).  It is evaluated as a batch of 64 partial GEMMs + a sum."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dx = dy @ weight if ctx.needs_input_grad[0] else None
+        dw = db = None
+        if ctx.needs_input_grad[1]:
+            n = x.shape[0]
+            parts = 64
+            while parts > 1 and n % parts:
+                parts //= 2
+            dw = torch.bmm(dy.reshape(parts, n // parts, -1).transpose(1, 2), x.reshape(parts, n // parts, -1)).sum(0)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(0)
+        return dx, dw, db
+
+
+def _linear(layer, x):
+    if x.is_cuda and x.ndim == 2 and x.shape[0] >= 16384 and torch.is_grad_enabled() and layer.weight.requires_grad:
+        return _SplitKLinear.apply(x, layer.weight, layer.bias)
+    return layer(x)
+
+
 class ConditionalTriplaneNeRFModel_multiRender_split_view(nn.Module):
     def __init__(self, XYZ_bounding, num_encoding_fn_xyz=8, latent_code_dim=32, triPlane_feat_dim=32, rgb_feat_dim=32,
                  triplane_res=256, use_emb=True, enc_mode="split", sh_deg=2, cond_latent=True, cond_c_dim=0):
@@ -94,10 +127,10 @@ class ConditionalTriplaneNeRFModel_multiRender_split_view(nn.Module):
         xyz, dirs = inp[..., :3], inp[..., 3:]
         x = torch.cat([pts_feat, self.pos_embedder(xyz)], -1)
         for layer in self.layers_xyz:
-            x = self.relu(layer(x))
-        alpha = self.fc_alpha(x)
-        x = self.fc_rgbFeat(x)
-        sh = self.fc_rgb(x)
+            x = self.relu(_linear(layer, x))
+        alpha = _linear(self.fc_alpha, x)
+        x = _linear(self.fc_rgbFeat, x)
+        sh = _linear(self.fc_rgb, x)
         rgb = sh if self.sh_deg == 0 else eval_sh(self.sh_deg, sh.reshape(sh.shape[0], -1, (self.sh_deg + 1) ** 2), dirs)
         return torch.cat((rgb, x, alpha), dim=-1)
 
