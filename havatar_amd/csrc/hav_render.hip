@@ -6,35 +6,39 @@
 // Replaces Trainer.predict_and_render_radiance and its callees (reference file:line in include/havatar.h
 // and next to each step below).  Design (DESIGN.md has the long form and the measurements behind each choice):
 //
-//  * Work unit = a PAIR of rays per wave64.  A wave evaluates 32 samples per MLP pass ("tile"): lanes
-//    j = lane&31 are the samples, the two half-waves h = lane>>5 split each sample's hidden units, its tri-plane
-//    gather (64 of the 128 projected channels each), its PE octaves (4h..4h+3) and its two skinning bones.
-//    Rows of 16 lanes (= one DPP row) always belong to one ray, so the transmittance product is a
-//    DPP row scan + a scalar carry; 64 coarse samples = 4 rows, 48 fine samples = 3 rows, and the odd
-//    fine row of ray A shares a tile with the first row of ray B: no matrix-core slot is wasted.
-//  * MLP in "transposed" form  H^T[unit][sample] = W[unit][k] . X^T[k][sample]  on v_mfma_f32_32x32x2_f32
-//    (exact fp32).  With this orientation the accumulator registers of layer l ARE the B operands of layer l+1
-//    (lane = its sample's column; register r of a 32-row tile holds rows (r&3)+8(r>>2)+4h, exactly the k-pair an MFMA
-//    step consumes from the two half-waves), so activations never leave registers and never cross lanes between
-//    layers.  Only weights move: pre-permuted once into that k order ("fragment order", hav_mlp_pack) so every A
-//    operand is one conflict-free 256-byte ds_read_b32 per wave.  ALL weights are LDS-resident (122 KB).
-//  * Measured on gfx950: v_mfma_f32_32x32x2_f32 does not overlap with VALU work -- neither from the same wave (each
-//    filler v_fma adds its ~2-4 cycles to the 64-cycle MFMA) nor from the other wave of the SIMD (a wave issuing
-//    back-to-back MFMAs starves its partner's VALU completely; tools/ubench).  Kernel time = MFMA cycles + VALU issue
-//    cycles, so the design minimises BOTH, algebraically:
+//  * Two mappings of rays to a wave64 share one per-tile evaluator (sample_eval): a "tile" is 32 radiance-field queries, lanes
+//    j = lane&31 are the queries, the two half-waves h = lane>>5 split each query's hidden units, its tri-plane gather (64 of the
+//    128 projected channels each), its PE octaves (4h..4h+3) and its two skinning bones.
+//      - BLOCK kernel (hav_march_blk_kernel, the default): a wave owns 32 consecutive rays and walks them through the sample
+//        index together -- neighbouring rays hit the same texels, and compositing is a per-lane recurrence (see its header).
+//      - PAIR kernel (hav_march_f32_kernel, num_coarse > 67 or HAV_MARCH=pair): a wave owns two rays; the 16 lanes of a DPP row
+//        are consecutive samples of one ray, the transmittance product is a DPP row scan + a scalar carry.
+//  * MLP in "transposed" form  H^T[unit][query] = W[unit][k] . X^T[k][query].  With this orientation the accumulator registers
+//    of layer l ARE the B operands of layer l+1 (lane = its query's column; register r of a 32-row tile holds rows
+//    (r&3)+8(r>>2)+4h, exactly the k-group an MFMA step consumes from the two half-waves), so activations never leave
+//    registers and never cross lanes between layers.  Only weights move: pre-permuted once into that k order ("fragment
+//    order", hav_mlp_pack) and LDS-resident.  Two arithmetic modes (HavRenderParams.mlp_mode):
+//      - split-operand bf16 (default): every fp32 operand = hi + mid + lo bf16 exactly, six partial products on
+//        v_mfma_f32_32x32x16_bf16 with fp32 accumulation (mfma_split3) -- fp32-sgemm-class results at 2.7x the matrix rate;
+//      - exact fp32: v_mfma_f32_32x32x2_f32 (an fmaf chain).
+//  * Measured on gfx950 (tools/ubench): MFMA does not overlap with VALU work -- neither from the same wave nor from the other
+//    wave of the SIMD.  Kernel time = MFMA cycles + VALU issue cycles + unhidden tap latency, so the matrix work was cut
+//    algebraically:
 //      - Layer 1's 128 tri-plane columns are folded into the planes once per frame: bilinear interpolation is linear,
 //        W1f (sum_tap w_tap texel_tap) = sum_tap w_tap (W1f texel_tap).  hav_triplane_prepare projects every texel
 //        through W1f (a 128x64 GEMM over 32768 texels = 0.5 GFLOP per frame, vs 2.8 TFLOP for the march) into
 //        128-channel planes stored in accumulator order; the kernel then accumulates 8 taps straight into the layer-1
-//        accumulators (packed FMAs) and only the 48 PE columns go through the matrix cores: 96 MFMAs instead of 352.
+//        accumulators (packed FMAs) and only the 48 PE columns go through the matrix cores.
 //      - fc_rgb o fc_rgbFeat has no activation in between (model/nerf_model.py:110-111): the 3 rgb rows fold into 3
-//        rows over the 128 hidden units; with alpha that is 4 dot products per sample on the VALU.
+//        rows over the 128 hidden units; with alpha that is 4 dot products per query on the VALU.
 //      - the 64 feature channels are LINEAR in h2 and only consumed through the compositing sum:
-//        sum_s w_s (Wf h2_s + bf) = Wf (sum_s w_s h2_s) + bf sum_s w_s.  The kernel composites the 128 hidden units
-//        (reduce-scatter over DPP rows) and applies fc_rgbFeat once per RAY.
-//    Per 32-sample tile that leaves 96 + 256 = 352 MFMAs instead of 736 for the literal network.
+//        sum_s w_s (Wf h2_s + bf) = Wf (sum_s w_s h2_s) + bf sum_s w_s.  The kernel composites the 128 hidden units and
+//        applies fc_rgbFeat once per RAY.
+//    Per tile that leaves 352 f32 MFMAs (or 264 bf16 ones) instead of 736 for the literal network.
 //  * One persistent workgroup (8 waves, 2 per SIMD) per CU; XCD-aware ray assignment keeps each XCD's L2 on one
 //    horizontal band of the image / projected planes.
+//  * Experiment knobs (results are WRONG or timing-only when set): HAV_ABLATE bit mask, HAV_STAGGER, -DHAV_PROFILE (phase
+//    timers, tools/phase_profile.sh), HAV_MARCH=pair|blk, HAV_MLP=f32|split.
 #include "hav_common.h"
 #include <stdlib.h>
 
