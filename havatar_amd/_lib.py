@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libhavatar_hip.so")
 
 HAV_F32, HAV_F16, HAV_BF16, HAV_F64 = 0, 1, 2, 3
 HAV_MLP_SPLIT_BF16, HAV_MLP_F32 = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class HavRenderParams(C.Structure):
@@ -20,7 +20,7 @@ class HavRenderParams(C.Structure):
                 ("nerf_scale", C.c_float * 3), ("nerf_trans", C.c_float * 3),
                 ("skin_scale", C.c_float * 3), ("skin_trans", C.c_float * 3),
                 ("seed", C.c_uint64), ("rng_offset", C.c_uint64), ("mlp_mode", C.c_int32), ("reserved", C.c_int32),
-                ("rng_counter", C.c_void_p)]
+                ("rng_counter", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64)]
 
 
 class HavMlpWeights(C.Structure):
@@ -77,6 +77,8 @@ def lib():
     L.hav_triplane_prepared_bytes.restype = i64
     L.hav_render_rays.argtypes = [C.POINTER(HavRenderParams)] + [vp] * 10 + [C.POINTER(HavRenderOut), vp]
     L.hav_render_rays.restype = i32
+    L.hav_render_workspace_bytes.argtypes = [C.POINTER(HavRenderParams)]
+    L.hav_render_workspace_bytes.restype = i64
     L.hav_render_variant.argtypes = [C.POINTER(HavRenderParams)]
     L.hav_render_variant.restype = C.c_char_p
     L.hav_debug_set_zfine.argtypes = [vp]

@@ -41,6 +41,7 @@
 //    timers, tools/phase_profile.sh), HAV_MARCH=pair|blk, HAV_MLP=f32|split.
 #include "hav_common.h"
 #include <stdlib.h>
+#include <string.h>
 
 // ------------------------------------------------------------------------------------------------
 // packed weight blob (float offsets).  [0, LDS_FLOATS) is copied verbatim into LDS by every workgroup.
@@ -328,6 +329,8 @@ struct MarchArgs {
     unsigned long long rng_base;   // p.rng_offset (+ *p.rng_counter, read on the device)
     int ablate;             // HAV_ABLATE bit mask (timing experiments only; results are wrong when set)
     int stagger;            // start-up delay per wave index, in units of 64 cycles (phase de-synchronisation of the CU's 8 waves)
+    float* ws;              // fine-pass cache (CACHE kernels): one slot of ws_slot floats per wave of the grid
+    long long ws_slot;
     float* dbg_zfine;       // optional [B*R, S_fp] dump of the merged fine depths (tests)
     long long NR;           // B*R
     int S_fp;               // ceil(S_c/2) + S_f, 0 if no fine pass
@@ -1070,7 +1073,31 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
 // row; the 16 importance samples per ray live in LDS and are merged with the even coarse depths on the fly.
 // Requires S_c <= 67 when a fine pass is requested (host falls back to the pair kernel otherwise).
 // ------------------------------------------------------------------------------------------------
-template <int RANDOM, int PREC>
+// CACHE: the merged fine list of a ray contains its even coarse samples (z_vals[::2], model/nerf_trainer.py:170), whose radiance
+// field values the coarse pass has already computed.  With a workspace, the coarse pass parks relu(h2) (64 values per lane)
+// and the 4 raw head values of every even sample, the fine pass evaluates only the S_f NEW samples (parking them too), then
+//   A. sweeps the merged list in depth order per ray with the parked head values only (transmittance, colour, depth, opacity:
+//      the reference's sequential order, unchanged) and records each entry's compositing weight,
+//   B. accumulates sum_e w_e h2_e over the parked entries in ENTRY order -- the same entry for all 32 rays, so every load is a
+//      coalesced 1-KB row (the feature sum is order-independent up to fp32 rounding; the depth-ordered scalars are not touched).
+// 80 instead of 112 field evaluations per ray.  Slot layout per wave (floats): H2 [S_fp][16][64 lanes][4] | RAW [S_fp][32][4] |
+// WV [S_fp][32].  The slot is re-used block after block by the same wave; agent-scope fences order its stores and loads and
+// drop stale L1 lines.
+// streaming accesses to the parked hidden units: non-temporal so that 13 GB per frame do not evict the tri-plane texels from L2
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void nt_store4(float4* p, float4 v)
+{
+    nt_f4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<nt_f4*>(p));
+}
+__device__ __forceinline__ float4 nt_load4(const float4* p)
+{
+    const nt_f4 t = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p));
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+#define WS_H2_FLOATS 4096
+#define WS_ENTRY_FLOATS (WS_H2_FLOATS + 128 + 32)
+template <int RANDOM, int PREC, bool CACHE>
 __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_blk_kernel(const MarchArgs a)
 {
     constexpr int RM = RANDOM;
@@ -1140,6 +1167,16 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
         const float dn = sqrtf(dx * dx + dy * dy + dz * dz);
         float* wpark = a.out.rgb_fine ? a.out.rgb_fine + gr * 67 : nullptr;   // this ray's parking row for w[0..S_c)
         const RKey rkey = RANDOM ? rng_ray_key(a, gr, call_off) : RKey{0u, 0u, 0u};
+        float* slot = CACHE ? a.ws + ((a.ablate & 1024) ? 0 : a.ws_slot * ((long long)blockIdx.x * MARCH_WAVES + wave)) : nullptr;   // 1024: timing experiment, all waves share one L2-resident slot
+        auto park = [&](int e, const f32x16 (&v)[4], float r0, float r1, float r2, float r3) {       // entry e of this block's slot
+            float4* H2 = reinterpret_cast<float4*>(slot + (size_t)e * WS_ENTRY_FLOATS);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+                    nt_store4(&H2[(m * 4 + rg) * 64 + lane], make_float4(v[m][4 * rg + 0], v[m][4 * rg + 1], v[m][4 * rg + 2], v[m][4 * rg + 3]));
+            if (h == 0) reinterpret_cast<float4*>(slot + (size_t)e * WS_ENTRY_FLOATS + WS_H2_FLOATS)[j] = make_float4(r0, r1, r2, r3);
+        };
 
         for (int pass = 0; pass < (S_fp > 0 ? 2 : 1); ++pass) {
             const int S = pass == 0 ? S_c : S_fp;
@@ -1160,15 +1197,104 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                 return v;
             };
             float z, znext;
+            if (CACHE && pass == 1) {
+                // ---- stage 1: the S_f new samples (same k for all 32 rays), parked behind the even coarse entries ----
+                for (int k = 0; k < S_f; ++k) {
+                    f32x16 acc2[4];
+                    float hd0, hd1, hd2, hd3;
+                    TICK(0);
+                    sample_eval<8, PREC>(a, L, b, ox, oy, oz, dx, dy, dz, s_n[k * 32 + j], acc2, hd0, hd1, hd2, hd3 PROF_PASS);
+                    __builtin_amdgcn_sched_barrier(0);
+                    park(S_half + k, acc2, hd0, hd1, hd2, hd3);
+                    TICK(7);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                // ---- stage A: depth-ordered sweep over the merged list with the parked head values -------------------
+                // The entry order of a ray depends only on depths, not on loaded data: a FIFO of 8 (depth, entry, head values)
+                // runs ahead of the consumer, so 8 of the lane-divergent 16-byte reads are in flight instead of one.
+                auto next_entry = [&](int& eid) -> float {
+                    const bool take_e = (ie < S_half) && (ik >= S_f || ze <= nk);
+                    const float v = take_e ? ze : nk;
+                    eid = take_e ? ie : S_half + ik;
+                    if (take_e) { ++ie; ze = (ie < S_half) ? z_coarse<RM>(a, gr, rkey, 2 * ie, near, far) : 3.0e38f; }
+                    else { ++ik; nk = (ik < S_f) ? s_n[ik * 32 + j] : 3.0e38f; }
+                    return v;
+                };
+                ze = z_coarse<RM>(a, gr, rkey, 0, near, far);
+                nk = s_n[j];
+                constexpr int FQ = 8;
+                float zq[FQ]; int eq[FQ]; float4 rq[FQ];
+                const float4* RAWp = reinterpret_cast<const float4*>(slot + WS_H2_FLOATS);          // + e * (WS_ENTRY_FLOATS / 4)
+                int produced = 0;
+#pragma unroll
+                for (int u = 0; u < FQ; ++u) {
+                    zq[u] = 0.f; eq[u] = 0;
+                    if (produced < S) { zq[u] = next_entry(eq[u]); ++produced; }
+                    rq[u] = RAWp[(size_t)eq[u] * (WS_ENTRY_FLOATS / 4) + j];
+                }
+                float dist = 0.f;
+                for (int s0 = 0; s0 < S; s0 += FQ) {
+#pragma unroll
+                    for (int u = 0; u < FQ; ++u) {
+                        const int sidx = s0 + u;
+                        if (sidx < S) {
+                            const float zc = zq[u];
+                            const int ec = eq[u];
+                            const float4 raw = rq[u];
+                            // refill this slot with merged sample sidx + FQ (if any) before using its neighbour's depth
+                            if (produced < S) {
+                                zq[u] = next_entry(eq[u]); ++produced;
+                                rq[u] = RAWp[(size_t)eq[u] * (WS_ENTRY_FLOATS / 4) + j];
+                            }
+                            if (sidx + 1 < S) dist = zq[(u + 1) % FQ] - zc;          // dists[-1] repeats dists[-2] (:36-37)
+                            float sg = raw.w;
+                            if (RANDOM && a.p.noise_std > 0.f) {
+                                const float e = (RANDOM == 2 && a.noise_f) ? a.noise_f[gr * S + sidx] : rng_normal(a, rkey, gr, sidx, STREAM_EPS_F);
+                                sg += e * a.p.noise_std;
+                            }
+                            sg = fmaxf(sg, 0.f);
+                            const float alpha = 1.0f - expf(-sg * (dist * dn));
+                            const float wgt = alpha * T;
+                            T = T * ((1.0f - alpha) + 1e-10f);
+                            c0 = fmaf(wgt, 1.0f / (1.0f + expf(-raw.x)), c0);
+                            c1 = fmaf(wgt, 1.0f / (1.0f + expf(-raw.y)), c1);
+                            c2 = fmaf(wgt, 1.0f / (1.0f + expf(-raw.z)), c2);
+                            dep = fmaf(wgt, zc, dep);
+                            accw += wgt;
+                            wmax = fmaxf(wmax, wgt);
+                            slot[(size_t)ec * WS_ENTRY_FLOATS + WS_H2_FLOATS + 128 + j] = wgt;       // both half-waves write the same value
+                            if (a.dbg_zfine && h == 0 && rayok) a.dbg_zfine[gr * S_fp + sidx] = zc;
+                        }
+                    }
+                }
+                TICK(0);            // (profile build: stage A is booked under "loop top", stage B under "positional encoding")
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                // ---- stage B: composited hidden units, entry order (coalesced 1-KB rows) --------------------------------------
+                for (int e = 0; e < S; ++e) {
+                    const float4* H2 = reinterpret_cast<const float4*>(slot + (size_t)e * WS_ENTRY_FLOATS);
+                    const float wgt = slot[(size_t)e * WS_ENTRY_FLOATS + WS_H2_FLOATS + 128 + j];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const float4 v = nt_load4(&H2[q * 64 + lane]);
+                        hsum[q >> 2][4 * (q & 3) + 0] = fmaf(wgt, v.x, hsum[q >> 2][4 * (q & 3) + 0]);
+                        hsum[q >> 2][4 * (q & 3) + 1] = fmaf(wgt, v.y, hsum[q >> 2][4 * (q & 3) + 1]);
+                        hsum[q >> 2][4 * (q & 3) + 2] = fmaf(wgt, v.z, hsum[q >> 2][4 * (q & 3) + 2]);
+                        hsum[q >> 2][4 * (q & 3) + 3] = fmaf(wgt, v.w, hsum[q >> 2][4 * (q & 3) + 3]);
+                    }
+                }
+                TICK(3);
+            }
             if (pass == 0) { z = z_coarse<RM>(a, gr, rkey, 0, near, far); znext = z_coarse<RM>(a, gr, rkey, 1, near, far); }
-            else {
+            else if (!CACHE) {
                 ze = z_coarse<RM>(a, gr, rkey, 0, near, far);
                 nk = s_n[j];
                 z = next_fine(); znext = next_fine();
             }
-            float dist = znext - z;
+            float dist = (CACHE && pass == 1) ? 0.f : znext - z;
 
-            for (int s = 0; s < S; ++s) {
+            for (int s = 0; s < ((CACHE && pass == 1) ? 0 : S); ++s) {
                 f32x16 acc2[4];
                 float hd0, hd1, hd2, hd3;
                 TICK(0);
@@ -1197,6 +1323,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                 accw += wgt;
                 wmax = fmaxf(wmax, wgt);
                 if (pass == 0 && S_fp > 0 && h == 0 && rayok) wpark[s] = wgt;
+                if (CACHE && pass == 0 && S_fp > 0 && !(s & 1)) park(s >> 1, acc2, hd0, hd1, hd2, hd3);
                 if (pass == 1 && a.dbg_zfine && h == 0 && rayok) a.dbg_zfine[gr * S_fp + s] = z;
                 // advance: dists[-1] repeats dists[-2] (:36-37)
                 z = znext;
@@ -1343,6 +1470,42 @@ static bool use_block_kernel(const HavRenderParams* p)
     return p->S_f == 0 || p->S_c <= 67;                   // coarse weights are parked in the 67-float rgb_fine row
 }
 
+static int march_grid_blocks(const HavRenderParams* p)
+{
+    const long long nblk = (long long)((p->R + 31) / 32) * p->B;
+    int gridb = hav_num_cus();
+    const long long needb = (nblk + MARCH_WAVES - 1) / MARCH_WAVES;
+    if (needb < gridb) gridb = (int)((needb + 7) / 8 * 8);
+    return gridb;
+}
+static long long fine_cache_slot_floats(const HavRenderParams* p)
+{
+    const long long S_fp = (p->S_c + 1) / 2 + p->S_f;
+    return S_fp * WS_ENTRY_FLOATS;
+}
+static bool use_split_mfma(const HavRenderParams* p);
+static bool use_block_kernel(const HavRenderParams* p);
+// fine-pass cache: block kernel, split-bf16 arithmetic, a fine pass, and a caller-provided workspace that is large enough
+static bool use_fine_cache(const HavRenderParams* p)
+{
+    // Measured on MI355X: with stratified jitter on (the production setting) skipping the repeated samples is
+    // worth 10-15 % of the kernel; with deterministic depths the coarse tiles are so coherent (all 32 rays at the same depth)
+    // that the 13 GB of parking traffic per frame cancels the gain.  Default: cache iff perturb; HAV_FINE=cache|recompute forces.
+    const char* e = getenv("HAV_FINE");
+    if (e && !strcmp(e, "recompute")) return false;
+    const bool forced = e && !strcmp(e, "cache");
+    if (!forced && !p->perturb) return false;
+    if (!use_block_kernel(p) || !use_split_mfma(p) || p->S_f <= 0 || !p->workspace) return false;
+    return p->workspace_bytes >= (uint64_t)march_grid_blocks(p) * MARCH_WAVES * fine_cache_slot_floats(p) * sizeof(float);
+}
+extern "C" int64_t hav_render_workspace_bytes(const HavRenderParams* p)
+{
+    if (!p || p->S_f <= 0 || p->S_c < 2 || p->R < 0 || p->B < 1) return 0;
+    if (!use_block_kernel(p) || !use_split_mfma(p)) return 0;
+    { const char* e = getenv("HAV_FINE"); if (e ? strcmp(e, "cache") != 0 : !p->perturb) return 0; }
+    return (int64_t)march_grid_blocks(p) * MARCH_WAVES * fine_cache_slot_floats(p) * (int64_t)sizeof(float);
+}
+
 static bool use_split_mfma(const HavRenderParams* p)
 {
     const char* e = getenv("HAV_MLP");                   // A/B override: "f32" / "split"
@@ -1356,8 +1519,11 @@ extern "C" const char* hav_render_variant(const HavRenderParams* p)
     if (!p) return "";
     const bool rnd = p->perturb != 0 || p->noise_std > 0.f;
     if (use_block_kernel(p)) {
-        if (use_split_mfma(p)) return rnd ? "hav_march_blk_kernel<1, 1>" : "hav_march_blk_kernel<0, 1>";
-        return rnd ? "hav_march_blk_kernel<2, 0>" : "hav_march_blk_kernel<0, 0>";
+        if (use_split_mfma(p)) {
+            if (use_fine_cache(p)) return rnd ? "hav_march_blk_kernel<1, 1, true>" : "hav_march_blk_kernel<0, 1, true>";
+            return rnd ? "hav_march_blk_kernel<1, 1, false>" : "hav_march_blk_kernel<0, 1, false>";
+        }
+        return rnd ? "hav_march_blk_kernel<2, 0, false>" : "hav_march_blk_kernel<0, 0, false>";
     }
     return rnd ? "hav_march_f32_kernel<true>" : "hav_march_f32_kernel<false>";
 }
@@ -1402,11 +1568,12 @@ extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, cons
     const bool random = p->perturb != 0 || p->noise_std > 0.f;
     static bool attr_set = false;
     if (!attr_set) {
-        const void* ks[7] = {(const void*)hav_march_f32_kernel<false>, (const void*)hav_march_f32_kernel<true>,
-                             (const void*)hav_march_blk_kernel<0, 0>, (const void*)hav_march_blk_kernel<2, 0>,
-                             (const void*)hav_march_blk_kernel<0, 1>, (const void*)hav_march_blk_kernel<1, 1>,
-                             (const void*)hav_march_blk_kernel<2, 1>};
-        for (int i = 0; i < 7; ++i) {
+        const void* ks[10] = {(const void*)hav_march_f32_kernel<false>, (const void*)hav_march_f32_kernel<true>,
+                              (const void*)hav_march_blk_kernel<0, 0, false>, (const void*)hav_march_blk_kernel<2, 0, false>,
+                              (const void*)hav_march_blk_kernel<0, 1, false>, (const void*)hav_march_blk_kernel<1, 1, false>,
+                              (const void*)hav_march_blk_kernel<2, 1, false>, (const void*)hav_march_blk_kernel<0, 1, true>,
+                              (const void*)hav_march_blk_kernel<1, 1, true>, (const void*)hav_march_blk_kernel<2, 1, true>};
+        for (int i = 0; i < 10; ++i) {
             hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return (int)e;
         }
@@ -1417,19 +1584,17 @@ extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, cons
         const bool split = use_split_mfma(p);
         const size_t ldsb = ((size_t)(split ? LDS3_FLOATS : LDS_FLOATS) + 256 + (size_t)MARCH_WAVES * a.scr_floats) * sizeof(float);
         if (ldsb > 160 * 1024) return HAV_EUNSUP;
-        const long long nblk = (long long)((p->R + 31) / 32) * p->B;
-        int gridb = hav_num_cus();
-        const long long needb = (nblk + MARCH_WAVES - 1) / MARCH_WAVES;
-        if (needb < gridb) gridb = (int)((needb + 7) / 8 * 8);
+        const int gridb = march_grid_blocks(p);
         const bool injected = t_rand || u_rand || noise_c || noise_f;     // parity tests; production draws everything on the device
-        if (split) {
-            if (random && injected) hipLaunchKernelGGL((hav_march_blk_kernel<2, 1>), dim3(gridb), dim3(MARCH_THREADS), ldsb, (hipStream_t)stream, a);
-            else if (random) hipLaunchKernelGGL((hav_march_blk_kernel<1, 1>), dim3(gridb), dim3(MARCH_THREADS), ldsb, (hipStream_t)stream, a);
-            else hipLaunchKernelGGL((hav_march_blk_kernel<0, 1>), dim3(gridb), dim3(MARCH_THREADS), ldsb, (hipStream_t)stream, a);
-        } else {
-            if (random) hipLaunchKernelGGL((hav_march_blk_kernel<2, 0>), dim3(gridb), dim3(MARCH_THREADS), ldsb, (hipStream_t)stream, a);
-            else hipLaunchKernelGGL((hav_march_blk_kernel<0, 0>), dim3(gridb), dim3(MARCH_THREADS), ldsb, (hipStream_t)stream, a);
-        }
+        const int rm = !random ? 0 : (injected ? 2 : 1);
+        const bool cache = use_fine_cache(p);
+        a.ws = cache ? (float*)p->workspace : nullptr;
+        a.ws_slot = fine_cache_slot_floats(p);
+#define LAUNCH_BLK(R_, P_, C_) hipLaunchKernelGGL((hav_march_blk_kernel<R_, P_, C_>), dim3(gridb), dim3(MARCH_THREADS), ldsb, (hipStream_t)stream, a)
+        if (split && cache) { if (rm == 0) LAUNCH_BLK(0, 1, true); else if (rm == 1) LAUNCH_BLK(1, 1, true); else LAUNCH_BLK(2, 1, true); }
+        else if (split) { if (rm == 0) LAUNCH_BLK(0, 1, false); else if (rm == 1) LAUNCH_BLK(1, 1, false); else LAUNCH_BLK(2, 1, false); }
+        else { if (rm == 0) LAUNCH_BLK(0, 0, false); else LAUNCH_BLK(2, 0, false); }
+#undef LAUNCH_BLK
         HAV_LAUNCH_CHECK();
         if (p->rng_counter && random) { hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)p->rng_counter); HAV_LAUNCH_CHECK(); }
         return 0;

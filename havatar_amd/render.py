@@ -50,6 +50,9 @@ class RayMarcher:
         self.rng_offset = 0
         self.seed = 0x9E3779B97F4A7C15
         self.mlp_mode = _lib.HAV_MLP_F32 if os.environ.get("HAVATAR_MLP", "split") == "f32" else _lib.HAV_MLP_SPLIT_BF16
+        # fine-pass cache: re-use the coarse pass's field values for the even coarse samples the merged list repeats
+        self.fine_cache = os.environ.get("HAVATAR_FINE_CACHE", "1") != "0"
+        self._workspace = None
 
     # -- constants -----------------------------------------------------------------------------
     def set_mlp(self, W1, b1, W2, b2, Wa, ba, Wf, bf, Wc, bc, force=False):
@@ -121,6 +124,13 @@ class RayMarcher:
         if self.rng_counter is None or self.rng_counter.device != dev:
             self.rng_counter = torch.zeros(1, dtype=torch.int64, device=dev)      # device-side call counter (graph-replay safe)
         p.rng_counter = self.rng_counter.data_ptr()
+        # scratch for the fine-pass cache (the library never allocates): kept for the life of the marcher, grown on demand
+        L = _lib.lib()
+        need = int(L.hav_render_workspace_bytes(C.byref(p))) if self.fine_cache else 0
+        if need > 0:
+            if self._workspace is None or self._workspace.device != dev or self._workspace.numel() < need:
+                self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+            p.workspace, p.workspace_bytes = self._workspace.data_ptr(), self._workspace.numel()
         t_rand = _chk_f32_cuda("t_rand", t_rand, True)
         u_rand = _chk_f32_cuda("u_rand", u_rand, True)
         noise_c = _chk_f32_cuda("noise_c", noise_c, True)
@@ -137,7 +147,6 @@ class RayMarcher:
             rgb_f = d_f = a_f = None
         out = _lib.HavRenderOut(rgb_c.data_ptr(), d_c.data_ptr(), a_c.data_ptr(), wmax.data_ptr(),
                                 *(t.data_ptr() if t is not None else None for t in (rgb_f, d_f, a_f)))
-        L = _lib.lib()
         zf = None
         with torch.cuda.device(dev):
             if dbg_zfine and S_fp > 0:
@@ -156,6 +165,9 @@ class RayMarcher:
         p = _lib.HavRenderParams()
         p.S_c, p.S_f, p.perturb, p.noise_std = S_c, S_f, int(bool(perturb)), float(noise_std)
         p.mlp_mode = self.mlp_mode
+        p.B, p.R = 1, 1 << 18
+        if self.fine_cache and S_f > 0:                  # same decision as render(): a workspace is always provided when useful
+            p.workspace, p.workspace_bytes = 1, 1 << 62
         return _lib.lib().hav_render_variant(C.byref(p)).decode()
 
 

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define HAV_ABI_VERSION 1
+#define HAV_ABI_VERSION 2
 
 #define HAV_EINVAL   (-1) /* bad size / null pointer / inconsistent arguments            */
 #define HAV_EUNSUP   (-2) /* valid for the reference, not supported by this build        */
@@ -126,6 +126,11 @@ typedef struct HavRenderParams {
     int32_t reserved;     /* must be 0                                                         */
     uint64_t* rng_counter; /* optional DEVICE counter: the call uses rng_offset + *rng_counter and increments the counter
                             * on the stream afterwards, so a hipGraph replay of a captured call draws fresh jitter    */
+    void*    workspace;    /* optional DEVICE scratch, hav_render_workspace_bytes() bytes: the fine pass then re-uses the
+                            * radiance-field values of the even coarse samples that the merged list repeats
+                            * (model/nerf_trainer.py:170) instead of evaluating them again: 80 evaluations per ray, not 112.
+                            * NULL / too small: every merged sample is evaluated, like the reference does.            */
+    uint64_t workspace_bytes;
 } HavRenderParams;
 
 /* How the two dense layers run on the matrix cores.  Both produce fp32-sgemm-class results (parity tests run both):
@@ -134,6 +139,10 @@ typedef struct HavRenderParams {
  *  HAV_MLP_F32:        v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fmaf chain. */
 #define HAV_MLP_SPLIT_BF16 0
 #define HAV_MLP_F32        1
+
+/* Bytes of scratch with which hav_render_rays can skip the repeated even coarse samples for these parameters
+ * (0: not applicable -- no fine pass, exact-f32 mode, or num_coarse > 67). */
+int64_t hav_render_workspace_bytes(const HavRenderParams* p);
 
 /* Radiance MLP parameters in nn.Linear layout (model/nerf_model.py:46-51), device pointers. */
 typedef struct HavMlpWeights {

@@ -20,7 +20,7 @@ class HavRenderParams(C.Structure):
                 ("nerf_scale", C.c_float * 3), ("nerf_trans", C.c_float * 3),
                 ("skin_scale", C.c_float * 3), ("skin_trans", C.c_float * 3),
                 ("seed", C.c_uint64), ("rng_offset", C.c_uint64), ("mlp_mode", C.c_int32), ("reserved", C.c_int32),
-                ("rng_counter", C.c_void_p)]
+                ("rng_counter", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64)]
 
 
 class HavMlpWeights(C.Structure):

@@ -43,7 +43,7 @@ def test_out_size_helper_matches_reference_formula():
 def test_struct_layouts_match_header():
     from havatar_amd import _lib
     from oracle import oracle
-    assert ctypes.sizeof(_lib.HavRenderParams) == 120 == ctypes.sizeof(oracle.HavRenderParams)
+    assert ctypes.sizeof(_lib.HavRenderParams) == 136 == ctypes.sizeof(oracle.HavRenderParams)
     assert ctypes.sizeof(_lib.HavMlpWeights) == 80
     assert ctypes.sizeof(_lib.HavRenderOut) == 56
 

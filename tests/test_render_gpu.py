@@ -231,3 +231,34 @@ def test_bad_arguments_raise():
         rm.render(t(sc["rays"]), t(sc["bg"]), t(sc["inv_T"]), t(sc["vol"]), 1, 16)       # S_c < 2
     with pytest.raises(RuntimeError):
         rm.render(t(sc["rays"]), t(sc["bg"]), t(sc["inv_T"]), t(sc["vol"]), 64, 16, t_rand=t(np.zeros((3,))), perturb=True)
+
+
+@pytest.mark.parametrize("name", [n for n in RENDER if "coarse_only" not in n])
+def test_fine_pass_cache_matches_reference_and_the_recompute_path(name, monkeypatch):
+    """HavRenderParams.workspace: the fine pass re-uses the coarse pass's field values for the even coarse samples the merged list
+    repeats (model/nerf_trainer.py:170) instead of evaluating them again.  Forced on for every fixture (the default enables it only
+    with stratified jitter): same golden tolerances, and against the recompute path only fp32 summation-order noise."""
+    g, sc, cfg, kw = load_render_fixture(name)
+    monkeypatch.setenv("HAV_FINE", "cache")
+    o = hip_render(sc, dbg_zfine=cfg["S_f"] > 0, **cfg, **kw)
+    monkeypatch.setenv("HAV_FINE", "recompute")
+    r = hip_render(sc, dbg_zfine=cfg["S_f"] > 0, **cfg, **kw)
+    for k in OUT_KEYS:
+        if "ref_" + k in g.files:
+            assert linf(o[k], g["ref_" + k]) <= TOL[k], (k, linf(o[k], g["ref_" + k]))
+            # the two kernel instantiations round the coarse weights differently by an ulp, which the inverse CDF amplifies
+            assert linf(o[k], r[k]) <= (2e-6 if "coarse" in k else 0.25 * TOL[k]), (k, linf(o[k], r[k]))
+    if cfg["S_f"] > 0:
+        assert linf(o["z_fine"], r["z_fine"]) <= 2e-3 and np.median(np.abs(o["z_fine"] - r["z_fine"])) <= 1e-6
+
+
+def test_fine_pass_cache_is_the_default_with_jitter_and_needs_a_workspace(monkeypatch):
+    import torch
+    from havatar_amd.render import RayMarcher
+    sc = synth.scene(8, 8, "primary")
+    rm = RayMarcher(sc["nerf_scale"], sc["nerf_trans"], sc["skin_scale"], sc["skin_trans"])
+    monkeypatch.delenv("HAV_FINE", raising=False)
+    assert rm.variant(64, 16, perturb=True).endswith("true>") and rm.variant(64, 16, perturb=False).endswith("false>")
+    rm.fine_cache = False                                          # no workspace offered -> every merged sample is evaluated
+    assert rm.variant(64, 16, perturb=True).endswith("false>")
+    assert rm.variant(64, 0, perturb=True).endswith("false>")      # no fine pass, nothing to cache
