@@ -143,7 +143,7 @@ def main():
     vol = tr.headpose_skin_net.current_volume()
     n_ev = max(3, min(args.steps, 10))
     with torch.no_grad():
-        kern_ms = timed(lambda: m.render(rays, bg, poses[0], vol, S_C, S_F, perturb=perturb), n_ev)
+        kern_ms = timed(lambda: m.render(rays, bg, poses[0], vol, S_C, S_F, perturb=perturb, coarse_outputs=False), n_ev)
         prep_ms = timed(lambda: m.set_triplane(tr.model_coarse.triPlane_embeddings), n_ev)
         enc_ms = timed(lambda: tr.model_coarse.set_conditional_embedding(
             front_render_cond=front, left_render_cond=left, right_render_cond=right, latents=tr.latent_codes[0:1],
@@ -169,7 +169,7 @@ def main():
         return None
 
     if rank == 0:
-        traffic = pmc_traffic(rm.variant(S_C, S_F, perturb=perturb))
+        traffic = pmc_traffic(rm.variant(S_C, S_F, perturb=perturb, coarse_outputs=False))
         res = {
             "metric": "rendered frames/sec @512^2, 64 samples/ray", "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
@@ -180,7 +180,7 @@ def main():
                        "phase_ms": {"encoders_P3": round(enc_ms, 3), "plane_prepare": round(prep_ms, 3), "ray_march_kernel": round(kern_ms, 3)},
                        "rays_per_frame": H * W, "num_coarse": S_C, "num_fine": S_F, "perturb": perturb, "hipgraph": bool(args.graph),
                        "parallelism": "frames sharded, %d rank(s), no data-path collective" % world,
-                       "kernel": rm.variant(S_C, S_F, perturb=perturb)},
+                       "kernel": rm.variant(S_C, S_F, perturb=perturb, coarse_outputs=False)},
             "roofline": {"bound": "mfma", "achieved": round(FLOP_PER_FRAME / (kern_ms * 1e-3) / 1e12, 3), "peak": PEAK_FP32_MFMA / 1e12,
                          "unit": "TFLOP/s", "frac": round(FLOP_PER_FRAME / (kern_ms * 1e-3) / PEAK_FP32_MFMA, 4),
                          "traffic": traffic["bytes"] if traffic else None, "traffic_detail": traffic,

@@ -79,7 +79,7 @@ def lib():
     L.hav_render_rays.restype = i32
     L.hav_render_workspace_bytes.argtypes = [C.POINTER(HavRenderParams)]
     L.hav_render_workspace_bytes.restype = i64
-    L.hav_render_variant.argtypes = [C.POINTER(HavRenderParams)]
+    L.hav_render_variant.argtypes = [C.POINTER(HavRenderParams), i32]
     L.hav_render_variant.restype = C.c_char_p
     L.hav_debug_set_zfine.argtypes = [vp]
     L.hav_debug_set_zfine.restype = None

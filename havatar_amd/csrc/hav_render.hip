@@ -1097,10 +1097,13 @@ __device__ __forceinline__ float4 nt_load4(const float4* p)
 }
 #define WS_H2_FLOATS 4096
 #define WS_ENTRY_FLOATS (WS_H2_FLOATS + 128 + 32)
-template <int RANDOM, int PREC, bool CACHE>
+// CACHE = 2: additionally, the caller does not want the coarse pass's composited outputs (Trainer.forward with a fine pass only
+// uses the fine ones): the coarse pass then carries no composited-hidden-unit accumulators at all (64 VGPRs less in its loop).
+template <int RANDOM, int PREC, int CACHE>
 __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_blk_kernel(const MarchArgs a)
 {
     constexpr int RM = RANDOM;
+    constexpr bool COUT = CACHE != 2;
     const uint32_t call_off = RANDOM ? rng_call_off(a) : 0u;      // one memory read per kernel, not per draw
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int WLDS = PREC == 1 ? LDS3_FLOATS : LDS_FLOATS;     // LDS image: fp32 fragments | split-bf16 fragments
@@ -1176,6 +1179,63 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                 for (int rg = 0; rg < 4; ++rg)
                     nt_store4(&H2[(m * 4 + rg) * 64 + lane], make_float4(v[m][4 * rg + 0], v[m][4 * rg + 1], v[m][4 * rg + 2], v[m][4 * rg + 3]));
             if (h == 0) reinterpret_cast<float4*>(slot + (size_t)e * WS_ENTRY_FLOATS + WS_H2_FLOATS)[j] = make_float4(r0, r1, r2, r3);
+        };
+        // fc_rgbFeat on the composited hidden units ([64 x 128] . [128 x 32 rays] on the matrix cores) + the per-ray output stores
+        auto emit = [&](int pass, const f32x16 (&hs)[4], float c0, float c1, float c2, float dep, float accw, float wmax) {
+            // ---- fc_rgbFeat on the composited hidden units: [64 x 128] . [128 x 32 rays] on the matrix cores -------------
+            f32x16 og[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const auto bb = __builtin_amdgcn_raw_buffer_load_b128(L.wrs, L.hoff, (OFF_BF + 32 * m + 8 * q) * 4, 0);
+                    og[m][4 * q + 0] = __uint_as_float(bb[0]) * accw; og[m][4 * q + 1] = __uint_as_float(bb[1]) * accw;   // bf * sum_s w_s
+                    og[m][4 * q + 2] = __uint_as_float(bb[2]) * accw; og[m][4 * q + 3] = __uint_as_float(bb[3]) * accw;
+                }
+            if (PREC == 1) {          // fragments stream from L2 (once per 32 rays per pass), 8 k-steps in flight
+                float wf[2][16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) wf[0][u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(L.wrs, lane * 4, (OFF_WFF + u * 64) * 4, 0));
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    if (g + 1 < 8) {
+#pragma unroll
+                        for (int u = 0; u < 16; ++u)
+                            wf[(g + 1) & 1][u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(L.wrs, lane * 4, (OFF_WFF + ((g + 1) * 16 + u) * 64) * 4, 0));
+                    }
+#pragma unroll
+                    for (int kq = 0; kq < 8; ++kq) {
+                        const int ks = g * 8 + kq;
+#pragma unroll
+                        for (int m = 0; m < 2; ++m)
+                            og[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[g & 1][kq * 2 + m], hs[ks >> 4][ks & 15], og[m], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < K2_STEPS; ++ks) {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+                        og[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(sWFF[(ks * 2 + m) * 64 + lane], hs[ks >> 4][ks & 15], og[m], 0, 0, 0);
+                }
+            }
+            if (rayok && (pass == 1 || a.out.rgb_coarse)) {          // coarse outputs are optional when there is a fine pass
+                float* rgb = (pass == 0 ? a.out.rgb_coarse : a.out.rgb_fine) + gr * 67;
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rgb[3 + acc_row(m, r, h)] = og[m][r];
+                if (h == 0) {
+                    const float bgx = a.bg ? a.bg[gr * 3 + 0] : 0.f, bgy = a.bg ? a.bg[gr * 3 + 1] : 0.f, bgz = a.bg ? a.bg[gr * 3 + 2] : 0.f;
+                    rgb[0] = a.bg ? c0 + (1.0f - accw) * bgx : c0;              // :70-71
+                    rgb[1] = a.bg ? c1 + (1.0f - accw) * bgy : c1;
+                    rgb[2] = a.bg ? c2 + (1.0f - accw) * bgz : c2;
+                    (pass == 0 ? a.out.depth_coarse : a.out.depth_fine)[gr] = dep;
+                    (pass == 0 ? a.out.acc_coarse : a.out.acc_fine)[gr] = accw;
+                    if (pass == 1 || S_fp == 0) a.out.weights_max[gr] = wmax;  // model/nerf_trainer.py:195,200
+                }
+            }
         };
 
         for (int pass = 0; pass < (S_fp > 0 ? 2 : 1); ++pass) {
@@ -1272,19 +1332,25 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 // ---- stage B: composited hidden units, entry order (coalesced 1-KB rows) --------------------------------------
+                f32x16 hsumB[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) hsumB[m][r] = 0.f;
                 for (int e = 0; e < S; ++e) {
                     const float4* H2 = reinterpret_cast<const float4*>(slot + (size_t)e * WS_ENTRY_FLOATS);
                     const float wgt = slot[(size_t)e * WS_ENTRY_FLOATS + WS_H2_FLOATS + 128 + j];
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
                         const float4 v = nt_load4(&H2[q * 64 + lane]);
-                        hsum[q >> 2][4 * (q & 3) + 0] = fmaf(wgt, v.x, hsum[q >> 2][4 * (q & 3) + 0]);
-                        hsum[q >> 2][4 * (q & 3) + 1] = fmaf(wgt, v.y, hsum[q >> 2][4 * (q & 3) + 1]);
-                        hsum[q >> 2][4 * (q & 3) + 2] = fmaf(wgt, v.z, hsum[q >> 2][4 * (q & 3) + 2]);
-                        hsum[q >> 2][4 * (q & 3) + 3] = fmaf(wgt, v.w, hsum[q >> 2][4 * (q & 3) + 3]);
+                        hsumB[q >> 2][4 * (q & 3) + 0] = fmaf(wgt, v.x, hsumB[q >> 2][4 * (q & 3) + 0]);
+                        hsumB[q >> 2][4 * (q & 3) + 1] = fmaf(wgt, v.y, hsumB[q >> 2][4 * (q & 3) + 1]);
+                        hsumB[q >> 2][4 * (q & 3) + 2] = fmaf(wgt, v.z, hsumB[q >> 2][4 * (q & 3) + 2]);
+                        hsumB[q >> 2][4 * (q & 3) + 3] = fmaf(wgt, v.w, hsumB[q >> 2][4 * (q & 3) + 3]);
                     }
                 }
                 TICK(3);
+                emit(1, hsumB, c0, c1, c2, dep, accw, wmax);
             }
             if (pass == 0) { z = z_coarse<RM>(a, gr, rkey, 0, near, far); znext = z_coarse<RM>(a, gr, rkey, 1, near, far); }
             else if (!CACHE) {
@@ -1311,7 +1377,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                 const float alpha = 1.0f - expf(-sg * (dist * dn));
                 const float wgt = alpha * T;                                   // :60, exclusive product
                 T = T * ((1.0f - alpha) + 1e-10f);
-                {
+                if (COUT) {          // (CACHE == 2: this loop only ever runs the coarse pass, whose composited outputs nobody wants)
                     const f32x16 wv = {wgt, wgt, wgt, wgt, wgt, wgt, wgt, wgt, wgt, wgt, wgt, wgt, wgt, wgt, wgt, wgt};
 #pragma unroll
                     for (int m = 0; m < 4; ++m) hsum[m] = __builtin_elementwise_fma(wv, acc2[m], hsum[m]);   // v_pk_fma_f32
@@ -1335,59 +1401,8 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                 TICK(7);
             }
 
-            // ---- fc_rgbFeat on the composited hidden units: [64 x 128] . [128 x 32 rays] on the matrix cores -------------
-            f32x16 og[2];
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const auto bb = __builtin_amdgcn_raw_buffer_load_b128(L.wrs, L.hoff, (OFF_BF + 32 * m + 8 * q) * 4, 0);
-                    og[m][4 * q + 0] = __uint_as_float(bb[0]) * accw; og[m][4 * q + 1] = __uint_as_float(bb[1]) * accw;   // bf * sum_s w_s
-                    og[m][4 * q + 2] = __uint_as_float(bb[2]) * accw; og[m][4 * q + 3] = __uint_as_float(bb[3]) * accw;
-                }
-            if (PREC == 1) {          // fragments stream from L2 (once per 32 rays per pass), 8 k-steps in flight
-                float wf[2][16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) wf[0][u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(L.wrs, lane * 4, (OFF_WFF + u * 64) * 4, 0));
-#pragma unroll
-                for (int g = 0; g < 8; ++g) {
-                    if (g + 1 < 8) {
-#pragma unroll
-                        for (int u = 0; u < 16; ++u)
-                            wf[(g + 1) & 1][u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(L.wrs, lane * 4, (OFF_WFF + ((g + 1) * 16 + u) * 64) * 4, 0));
-                    }
-#pragma unroll
-                    for (int kq = 0; kq < 8; ++kq) {
-                        const int ks = g * 8 + kq;
-#pragma unroll
-                        for (int m = 0; m < 2; ++m)
-                            og[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[g & 1][kq * 2 + m], hsum[ks >> 4][ks & 15], og[m], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            } else {
-#pragma unroll
-                for (int ks = 0; ks < K2_STEPS; ++ks) {
-#pragma unroll
-                    for (int m = 0; m < 2; ++m)
-                        og[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(sWFF[(ks * 2 + m) * 64 + lane], hsum[ks >> 4][ks & 15], og[m], 0, 0, 0);
-                }
-            }
-            if (rayok) {
-                float* rgb = (pass == 0 ? a.out.rgb_coarse : a.out.rgb_fine) + gr * 67;
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) rgb[3 + acc_row(m, r, h)] = og[m][r];
-                if (h == 0) {
-                    const float bgx = a.bg ? a.bg[gr * 3 + 0] : 0.f, bgy = a.bg ? a.bg[gr * 3 + 1] : 0.f, bgz = a.bg ? a.bg[gr * 3 + 2] : 0.f;
-                    rgb[0] = a.bg ? c0 + (1.0f - accw) * bgx : c0;              // :70-71
-                    rgb[1] = a.bg ? c1 + (1.0f - accw) * bgy : c1;
-                    rgb[2] = a.bg ? c2 + (1.0f - accw) * bgz : c2;
-                    (pass == 0 ? a.out.depth_coarse : a.out.depth_fine)[gr] = dep;
-                    (pass == 0 ? a.out.acc_coarse : a.out.acc_fine)[gr] = accw;
-                    if (pass == 1 || S_fp == 0) a.out.weights_max[gr] = wmax;  // model/nerf_trainer.py:195,200
-                }
+            if constexpr (CACHE != 2) {
+                if (!(CACHE && pass == 1)) emit(pass, hsum, c0, c1, c2, dep, accw, wmax);
             }
 
             TICK(8);
@@ -1514,16 +1529,18 @@ static bool use_split_mfma(const HavRenderParams* p)
     return p->mlp_mode != HAV_MLP_F32;
 }
 
-extern "C" const char* hav_render_variant(const HavRenderParams* p)
+extern "C" const char* hav_render_variant(const HavRenderParams* p, int coarse_outputs)
 {
     if (!p) return "";
+    if (!coarse_outputs && (p->perturb != 0 || p->noise_std > 0.f) && use_block_kernel(p) && use_split_mfma(p) && use_fine_cache(p))
+        return "hav_march_blk_kernel<1, 1, 2>";
     const bool rnd = p->perturb != 0 || p->noise_std > 0.f;
     if (use_block_kernel(p)) {
         if (use_split_mfma(p)) {
-            if (use_fine_cache(p)) return rnd ? "hav_march_blk_kernel<1, 1, true>" : "hav_march_blk_kernel<0, 1, true>";
-            return rnd ? "hav_march_blk_kernel<1, 1, false>" : "hav_march_blk_kernel<0, 1, false>";
+            if (use_fine_cache(p)) return rnd ? "hav_march_blk_kernel<1, 1, 1>" : "hav_march_blk_kernel<0, 1, 1>";
+            return rnd ? "hav_march_blk_kernel<1, 1, 0>" : "hav_march_blk_kernel<0, 1, 0>";
         }
-        return rnd ? "hav_march_blk_kernel<2, 0, false>" : "hav_march_blk_kernel<0, 0, false>";
+        return rnd ? "hav_march_blk_kernel<2, 0, 0>" : "hav_march_blk_kernel<0, 0, 0>";
     }
     return rnd ? "hav_march_f32_kernel<true>" : "hav_march_f32_kernel<false>";
 }
@@ -1539,7 +1556,12 @@ extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, cons
     if (p->plane_res < 2 || p->vol_res < 2) return HAV_EINVAL;
     if (p->S_c > 256 || p->S_f > 128) return HAV_EUNSUP;
     if (p->reserved != 0 || (p->mlp_mode != HAV_MLP_SPLIT_BF16 && p->mlp_mode != HAV_MLP_F32)) return HAV_EINVAL;
-    if (!out->rgb_coarse || !out->depth_coarse || !out->acc_coarse || !out->weights_max) return HAV_EINVAL;
+    // the coarse pass's composited outputs may be declined (all three NULL) when there is a fine pass: Trainer.forward then only
+    // uses the fine ones, and the kernel drops the accumulators that exist for them
+    const bool no_coarse_out = !out->rgb_coarse && !out->depth_coarse && !out->acc_coarse;
+    if (no_coarse_out ? (p->S_f <= 0) : (!out->rgb_coarse || !out->depth_coarse || !out->acc_coarse)) return HAV_EINVAL;
+    if (!out->weights_max) return HAV_EINVAL;
+    if (no_coarse_out && !use_block_kernel(p)) return HAV_EUNSUP;          // the ray-pair kernel always writes them
     if (p->S_f > 0 && (!out->rgb_fine || !out->depth_fine || !out->acc_fine)) return HAV_EINVAL;
     if (p->R == 0) return 0;
 
@@ -1568,12 +1590,13 @@ extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, cons
     const bool random = p->perturb != 0 || p->noise_std > 0.f;
     static bool attr_set = false;
     if (!attr_set) {
-        const void* ks[10] = {(const void*)hav_march_f32_kernel<false>, (const void*)hav_march_f32_kernel<true>,
-                              (const void*)hav_march_blk_kernel<0, 0, false>, (const void*)hav_march_blk_kernel<2, 0, false>,
-                              (const void*)hav_march_blk_kernel<0, 1, false>, (const void*)hav_march_blk_kernel<1, 1, false>,
-                              (const void*)hav_march_blk_kernel<2, 1, false>, (const void*)hav_march_blk_kernel<0, 1, true>,
-                              (const void*)hav_march_blk_kernel<1, 1, true>, (const void*)hav_march_blk_kernel<2, 1, true>};
-        for (int i = 0; i < 10; ++i) {
+        const void* ks[11] = {(const void*)hav_march_f32_kernel<false>, (const void*)hav_march_f32_kernel<true>,
+                              (const void*)hav_march_blk_kernel<0, 0, 0>, (const void*)hav_march_blk_kernel<2, 0, 0>,
+                              (const void*)hav_march_blk_kernel<0, 1, 0>, (const void*)hav_march_blk_kernel<1, 1, 0>,
+                              (const void*)hav_march_blk_kernel<2, 1, 0>, (const void*)hav_march_blk_kernel<0, 1, 1>,
+                              (const void*)hav_march_blk_kernel<1, 1, 1>, (const void*)hav_march_blk_kernel<2, 1, 1>,
+                              (const void*)hav_march_blk_kernel<1, 1, 2>};
+        for (int i = 0; i < 11; ++i) {
             hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return (int)e;
         }
@@ -1591,9 +1614,10 @@ extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, cons
         a.ws = cache ? (float*)p->workspace : nullptr;
         a.ws_slot = fine_cache_slot_floats(p);
 #define LAUNCH_BLK(R_, P_, C_) hipLaunchKernelGGL((hav_march_blk_kernel<R_, P_, C_>), dim3(gridb), dim3(MARCH_THREADS), ldsb, (hipStream_t)stream, a)
-        if (split && cache) { if (rm == 0) LAUNCH_BLK(0, 1, true); else if (rm == 1) LAUNCH_BLK(1, 1, true); else LAUNCH_BLK(2, 1, true); }
-        else if (split) { if (rm == 0) LAUNCH_BLK(0, 1, false); else if (rm == 1) LAUNCH_BLK(1, 1, false); else LAUNCH_BLK(2, 1, false); }
-        else { if (rm == 0) LAUNCH_BLK(0, 0, false); else LAUNCH_BLK(2, 0, false); }
+        if (split && cache && no_coarse_out && rm == 1) LAUNCH_BLK(1, 1, 2);          // the production variant: jitter, cache, fine outputs only
+        else if (split && cache) { if (rm == 0) LAUNCH_BLK(0, 1, 1); else if (rm == 1) LAUNCH_BLK(1, 1, 1); else LAUNCH_BLK(2, 1, 1); }
+        else if (split) { if (rm == 0) LAUNCH_BLK(0, 1, 0); else if (rm == 1) LAUNCH_BLK(1, 1, 0); else LAUNCH_BLK(2, 1, 0); }
+        else { if (rm == 0) LAUNCH_BLK(0, 0, 0); else LAUNCH_BLK(2, 0, 0); }
 #undef LAUNCH_BLK
         HAV_LAUNCH_CHECK();
         if (p->rng_counter && random) { hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)p->rng_counter); HAV_LAUNCH_CHECK(); }

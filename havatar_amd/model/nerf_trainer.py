@@ -62,7 +62,11 @@ class Trainer(torch.nn.Module):
             restore += restore[:-1]
         rays = torch.cat((ray_batch, viewdirs), dim=-1)
         if self._use_hip(rays):
-            out = list(self.predict_and_render_radiance(mode, rays, background_prior, inv_head_T=inv_head_T))   # one launch, no chunk loop
+            # one launch, no chunk loop.  forward(render_full_img=True) only consumes the fine maps: it declines the coarse pass's
+            # composited outputs (they come back as None), which lets the kernel drop their accumulators
+            self._decline_coarse = bool(inputs.get("_fine_maps_only", False)) and opt.num_fine > 0
+            out = list(self.predict_and_render_radiance(mode, rays, background_prior, inv_head_T=inv_head_T))
+            self._decline_coarse = False
         else:
             chunk = opt.chunksize // rays.shape[0]
             rb = get_minibatches(rays, chunksize=chunk, dim=1)
@@ -82,7 +86,7 @@ class Trainer(torch.nn.Module):
         rgb_coarse, _, acc_coarse, weights, rgb_fine, _, acc_fine = self.nerf_forward(
             ray_batch=ray_batch, background_prior=background_prior, latent_code=latent_code, inv_head_T=data["inv_head_T"],
             front_render_cond=data["front_render_cond"], left_render_cond=data["left_render_cond"],
-            right_render_cond=data["right_render_cond"], mode=data["mode"])
+            right_render_cond=data["right_render_cond"], mode=data["mode"], _fine_maps_only=bool(data["render_full_img"]))
         if data["render_full_img"]:
             render = rgb_fine if rgb_fine is not None else rgb_coarse
             mask = acc_fine if acc_fine is not None else acc_coarse
@@ -112,7 +116,8 @@ class Trainer(torch.nn.Module):
             self._planes_key, self._planes_dirty = key, False
         vol = self.headpose_skin_net.current_volume().detach()
         return m.render(ray_batch, background_prior, inv_head_T, vol, int(opt.num_coarse), int(opt.num_fine),
-                        perturb=bool(opt.perturb), noise_std=float(opt.radiance_field_noise_std))
+                        perturb=bool(opt.perturb), noise_std=float(opt.radiance_field_noise_std),
+                        coarse_outputs=not getattr(self, "_decline_coarse", False))
 
     def _render_torch(self, opt, ray_batch, background_prior, inv_head_T):
         """PyTorch statement of predict_and_render_radiance (reference :120-201)."""

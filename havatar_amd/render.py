@@ -91,12 +91,13 @@ class RayMarcher:
 
     # -- launch --------------------------------------------------------------------------------
     def render(self, rays, bg, inv_T, skin_vol, S_c, S_f, perturb=False, noise_std=0.0,
-               t_rand=None, u_rand=None, noise_c=None, noise_f=None, dbg_zfine=False):
+               t_rand=None, u_rand=None, noise_c=None, noise_f=None, dbg_zfine=False, coarse_outputs=True):
         """rays [B,R,>=8], bg [B,R,3]|None, inv_T [B,4,3], skin_vol [2,D,H,W] or [1,2,D,H,W].
 
         Returns the 7-tuple of predict_and_render_radiance (model/nerf_trainer.py:194-201):
         rgb_coarse [B,R,67], depth_coarse [B,R,1], acc_coarse [B,R,1], weights_max [B,R,1],
-        rgb_fine, depth_fine, acc_fine (None x3 if S_f == 0)."""
+        rgb_fine, depth_fine, acc_fine (None x3 if S_f == 0).  coarse_outputs=False (with a fine pass): the caller does not need the
+        coarse pass's composited maps; they come back as None where the kernel can skip them."""
         if self.blob is None or self.planes_cl is None:
             raise RuntimeError("set_mlp() and set_triplane() must be called before render()")
         if self._planes_key != self._blob_key:
@@ -140,13 +141,16 @@ class RayMarcher:
             if t is not None and t.numel() != n:
                 raise RuntimeError(f"{nm} has {t.numel()} elements, expected {n}")
         e = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
-        rgb_c, d_c, a_c, wmax = e(B, R, 67), e(B, R, 1), e(B, R, 1), e(B, R, 1)
+        if not coarse_outputs and S_f > 0 and need > 0:          # declined (only the block kernel can skip them: need > 0 implies it)
+            rgb_c = d_c = a_c = None
+        else:
+            rgb_c, d_c, a_c = e(B, R, 67), e(B, R, 1), e(B, R, 1)
+        wmax = e(B, R, 1)
         if S_f > 0:
             rgb_f, d_f, a_f = e(B, R, 67), e(B, R, 1), e(B, R, 1)
         else:
             rgb_f = d_f = a_f = None
-        out = _lib.HavRenderOut(rgb_c.data_ptr(), d_c.data_ptr(), a_c.data_ptr(), wmax.data_ptr(),
-                                *(t.data_ptr() if t is not None else None for t in (rgb_f, d_f, a_f)))
+        out = _lib.HavRenderOut(*(t.data_ptr() if t is not None else None for t in (rgb_c, d_c, a_c, wmax, rgb_f, d_f, a_f)))
         zf = None
         with torch.cuda.device(dev):
             if dbg_zfine and S_fp > 0:
@@ -161,14 +165,14 @@ class RayMarcher:
         res = (rgb_c, d_c, a_c, wmax, rgb_f, d_f, a_f)
         return res + (zf,) if dbg_zfine else res
 
-    def variant(self, S_c, S_f, perturb=False, noise_std=0.0):
+    def variant(self, S_c, S_f, perturb=False, noise_std=0.0, coarse_outputs=True):
         p = _lib.HavRenderParams()
         p.S_c, p.S_f, p.perturb, p.noise_std = S_c, S_f, int(bool(perturb)), float(noise_std)
         p.mlp_mode = self.mlp_mode
         p.B, p.R = 1, 1 << 18
         if self.fine_cache and S_f > 0:                  # same decision as render(): a workspace is always provided when useful
             p.workspace, p.workspace_bytes = 1, 1 << 62
-        return _lib.lib().hav_render_variant(C.byref(p)).decode()
+        return _lib.lib().hav_render_variant(C.byref(p), int(bool(coarse_outputs))).decode()
 
 
 def gen_rays(H, W, intr, c2w, near, far, device, out=None):

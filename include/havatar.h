@@ -168,7 +168,8 @@ int64_t hav_triplane_prepared_bytes(int B, int H, int W);
 int hav_triplane_prepare(float* dst, const float* src_nchw, const void* mlp_blob, int B, int C, int H, int W,
                          void* stream);
 
-typedef struct HavRenderOut {      /* all device pointers, float32; fine pointers unused if S_f==0 */
+typedef struct HavRenderOut {      /* all device pointers, float32; fine pointers unused if S_f==0.  With a fine pass the three
+                                    * *_coarse pointers may ALL be NULL ("not wanted": Trainer.forward only uses the fine maps then) */
     float* rgb_coarse;   /* [B,R,67]  rgb(3, sigmoid, + background) | feature(64)                 */
     float* depth_coarse; /* [B,R]                                                                 */
     float* acc_coarse;   /* [B,R]                                                                 */
@@ -203,8 +204,9 @@ int hav_render_rays(const HavRenderParams* p, const float* rays, const float* bg
  * [B*R, S_fp] to `dev_ptr` (device memory); one-shot, cleared by that call. */
 void hav_debug_set_zfine(float* dev_ptr);
 
-/* Name of the ray-march kernel variant a call with these parameters would launch (for profiles). */
-const char* hav_render_variant(const HavRenderParams* p);
+/* Name of the ray-march kernel variant a call with these parameters would launch (for profiles); coarse_outputs = 0 if the
+ * call declines the coarse pass's composited outputs (rgb/depth/acc_coarse NULL in HavRenderOut). */
+const char* hav_render_variant(const HavRenderParams* p, int coarse_outputs);
 
 /* ------------------------------------------------------------------------------------------
  * get_rays on device (next-1; reference: dataloader/data_util.py:28-56 +

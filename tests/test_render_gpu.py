@@ -258,7 +258,32 @@ def test_fine_pass_cache_is_the_default_with_jitter_and_needs_a_workspace(monkey
     sc = synth.scene(8, 8, "primary")
     rm = RayMarcher(sc["nerf_scale"], sc["nerf_trans"], sc["skin_scale"], sc["skin_trans"])
     monkeypatch.delenv("HAV_FINE", raising=False)
-    assert rm.variant(64, 16, perturb=True).endswith("true>") and rm.variant(64, 16, perturb=False).endswith("false>")
+    assert rm.variant(64, 16, perturb=True).endswith(", 1>") and rm.variant(64, 16, perturb=False).endswith(", 0>")
+    assert rm.variant(64, 16, perturb=True, coarse_outputs=False).endswith(", 2>")      # production: jitter, cache, fine maps only
     rm.fine_cache = False                                          # no workspace offered -> every merged sample is evaluated
-    assert rm.variant(64, 16, perturb=True).endswith("false>")
-    assert rm.variant(64, 0, perturb=True).endswith("false>")      # no fine pass, nothing to cache
+    assert rm.variant(64, 16, perturb=True).endswith(", 0>")
+    assert rm.variant(64, 0, perturb=True).endswith(", 0>")        # no fine pass, nothing to cache
+
+
+def test_declined_coarse_outputs_leave_the_fine_maps_unchanged():
+    """HavRenderOut with the three coarse pointers NULL (Trainer.forward(render_full_img=True) only uses the fine maps): the fine
+    maps equal those of a call that asks for everything, in every kernel variant that accepts the request."""
+    import torch
+    from havatar_amd.render import RayMarcher
+    sc = synth.scene(16, 16, "primary")
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
+    rm = RayMarcher(sc["nerf_scale"], sc["nerf_trans"], sc["skin_scale"], sc["skin_trans"])
+    rm.set_mlp(*[t(sc["mlp"][k]) for k in ("W1", "b1", "W2", "b2", "Wa", "ba", "Wf", "bf", "Wc", "bc")])
+    rm.set_triplane(t(sc["planes"]))
+    args = (t(sc["rays"]), t(sc["bg"]), t(sc["inv_T"]), t(sc["vol"]), 64, 16)
+    for perturb in (True, False):
+        rm.rng_counter = None
+        full = rm.render(*args, perturb=perturb)
+        rm.rng_counter = None                                      # same device RNG call counter -> same jitter
+        lean = rm.render(*args, perturb=perturb, coarse_outputs=False)
+        torch.cuda.synchronize()
+        if perturb:
+            assert lean[0] is None and lean[1] is None and lean[2] is None
+        for a_, b_ in zip(full[4:7], lean[4:7]):
+            assert (a_ - b_).abs().max().item() <= 2e-5

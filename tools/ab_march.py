@@ -22,11 +22,11 @@ rm.set_triplane(t(sc["planes"]))
 args = (t(sc["rays"]), t(sc["bg"]), t(sc["inv_T"]), t(sc["vol"]), 64, 16)
 out = []
 for perturb in (True, False):
-    for _ in range(3): rm.render(*args, perturb=perturb)
+    for _ in range(3): rm.render(*args, perturb=perturb, coarse_outputs=False)
     ts = []
     for _ in range(12):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); rm.render(*args, perturb=perturb); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
+        a.record(); rm.render(*args, perturb=perturb, coarse_outputs=False); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
     out.append("%s %.3f ms (min %.3f)" % ("perturb" if perturb else "det    ", float(np.median(ts)), min(ts)))
 print(" | ".join(out))
 '''

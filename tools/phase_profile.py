@@ -23,13 +23,13 @@ rays, bg, inv_T, vol = t(sc["rays"]), t(sc["bg"]), t(sc["inv_T"]), t(sc["vol"])
 L = _lib.lib()
 buf = (C.c_ulonglong * 12)()
 for _ in range(2):
-    rm.render(rays, bg, inv_T, vol, 64, 16, perturb=perturb)
+    rm.render(rays, bg, inv_T, vol, 64, 16, perturb=perturb, coarse_outputs=False)
 L.hav_debug_read_prof(buf)
 N = 5
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 ev0.record()
 for _ in range(N):
-    rm.render(rays, bg, inv_T, vol, 64, 16, perturb=perturb)
+    rm.render(rays, bg, inv_T, vol, 64, 16, perturb=perturb, coarse_outputs=False)
 ev1.record()
 torch.cuda.synchronize()
 assert L.hav_debug_read_prof(buf) == 0
@@ -37,7 +37,7 @@ tiles = H * W * 112 // 32
 names = ["loop top (z, jitter)", "geometry + skinning taps", "plane gather (8 taps)", "positional encoding", "layer 1 MFMA + relu",
          "layer 2 MFMA + relu", "head dots", "compositing", "fc_rgbFeat + stores (per block)", "resampling (per block)", "kernel total / wave", "-"]
 tot = sum(buf[i] for i in range(10))
-print("kernel %.2f ms (instrumented), %d tiles, variant %s" % (ev0.elapsed_time(ev1) / N, tiles, rm.variant(64, 16, perturb=perturb)))
+print("kernel %.2f ms (instrumented), %d tiles, variant %s" % (ev0.elapsed_time(ev1) / N, tiles, rm.variant(64, 16, perturb=perturb, coarse_outputs=False)))
 for i in range(10):
     print("  %-34s %9.0f cycles/tile  %5.1f %%" % (names[i], buf[i] / N / tiles, 100.0 * buf[i] / tot))
 print("  %-34s %9.0f cycles/tile" % ("sum of phases", tot / N / tiles))
