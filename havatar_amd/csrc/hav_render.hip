@@ -532,7 +532,7 @@ struct ProfCtx { unsigned long long t, acc[HAV_NPROF]; };
 #endif
 
 // PREC = 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  PREC = 1: split-operand bf16 MFMA (3 x bf16 per operand, 6 products).
-template <int GQ, int PREC>
+template <int GQ, int PREC, bool BLK>
 __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L, int b, float ox, float oy, float oz, float dx,
                                             float dy, float dz, float z, f32x16 (&acc2)[4], float& hd0, float& hd1, float& hd2,
                                             float& hd3 PROF_ARG)
@@ -592,7 +592,7 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            if (GQ == 8) {       // block kernel: biases are LDS-resident (the texture path is this kernel's busiest unit: keep it for the taps)
+            if (BLK) {           // block kernel: biases are LDS-resident (the texture path is this kernel's busiest unit: keep it for the taps)
                 const float4 bl = sBt[8 * m + 2 * q + h];
                 acc1[m][4 * q + 0] = bl.x; acc1[m][4 * q + 1] = bl.y; acc1[m][4 * q + 2] = bl.z; acc1[m][4 * q + 3] = bl.w;
                 continue;
@@ -703,7 +703,7 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            if (GQ == 8) {
+            if (BLK) {
                 const float4 bl = sBt[32 + 8 * m + 2 * q + h];
                 acc2[m][4 * q + 0] = bl.x; acc2[m][4 * q + 1] = bl.y; acc2[m][4 * q + 2] = bl.z; acc2[m][4 * q + 3] = bl.w;
                 continue;
@@ -886,7 +886,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
 #ifdef HAV_PROFILE
                 ProfCtx P;
 #endif
-                sample_eval<16, 0>(a, L, b, ox, oy, oz, dx, dy, dz, z, acc2, hd0, hd1, hd2, hd3 PROF_PASS);
+                sample_eval<16, 0, false>(a, L, b, ox, oy, oz, dx, dy, dz, z, acc2, hd0, hd1, hd2, hd3 PROF_PASS);
 
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- volume_render_radiance_field (utils/nerf_util.py:28-73) -------------------------------
@@ -1095,6 +1095,9 @@ __device__ __forceinline__ float4 nt_load4(const float4* p)
     const nt_f4 t = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p));
     return make_float4(t.x, t.y, t.z, t.w);
 }
+#ifndef HAV_GQ2
+#define HAV_GQ2 16         // float4 loads per gather stage in the fine-maps-only variant (its register budget allows a whole tap: -2 %)
+#endif
 #define WS_H2_FLOATS 4096
 #define WS_ENTRY_FLOATS (WS_H2_FLOATS + 128 + 32)
 // CACHE = 2: additionally, the caller does not want the coarse pass's composited outputs (Trainer.forward with a fine pass only
@@ -1263,7 +1266,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                     f32x16 acc2[4];
                     float hd0, hd1, hd2, hd3;
                     TICK(0);
-                    sample_eval<8, PREC>(a, L, b, ox, oy, oz, dx, dy, dz, s_n[k * 32 + j], acc2, hd0, hd1, hd2, hd3 PROF_PASS);
+                    sample_eval<(CACHE == 2 ? HAV_GQ2 : 8), PREC, true>(a, L, b, ox, oy, oz, dx, dy, dz, s_n[k * 32 + j], acc2, hd0, hd1, hd2, hd3 PROF_PASS);
                     __builtin_amdgcn_sched_barrier(0);
                     park(S_half + k, acc2, hd0, hd1, hd2, hd3);
                     TICK(7);
@@ -1364,7 +1367,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                 f32x16 acc2[4];
                 float hd0, hd1, hd2, hd3;
                 TICK(0);
-                sample_eval<8, PREC>(a, L, b, ox, oy, oz, dx, dy, dz, z, acc2, hd0, hd1, hd2, hd3 PROF_PASS);
+                sample_eval<(CACHE == 2 ? HAV_GQ2 : 8), PREC, true>(a, L, b, ox, oy, oz, dx, dy, dz, z, acc2, hd0, hd1, hd2, hd3 PROF_PASS);
                 __builtin_amdgcn_sched_barrier(0);
                 // volume_render_radiance_field (utils/nerf_util.py:28-73), one ray per lane, sequential in s
                 float sg = hd3;
