@@ -442,10 +442,12 @@ __device__ __forceinline__ void split3(float v0, float v1, uint32_t& ph, uint32_
 }
 
 // relu of the 4 accumulator tiles of a layer, one instruction per value.  fmaxf(x, 0) on an MFMA result costs two (the
-// compiler first canonicalises the operand with v_max x,x; v_med3(x,0,inf) is folded back to the same pair).  The v_max is
-// therefore issued from inline asm -- and because the compiler pads NO wait states between an MFMA and an asm statement that
-// reads its result (measured: ~1 % of rays corrupted, run to run, with a bare asm v_max), the first statement carries the
-// XDL-write -> VALU-read wait states itself (24 >= the 16-pass requirement) and ties all four tiles to it.
+// compiler first canonicalises the operand with v_max x,x; v_med3(x,0,inf) is folded back to the same pair; the integer form
+// bitcast(max(bitcast<int>(x), 0)) is "simplified" into wrong code by this compiler), so the v_max is issued from inline asm, IN
+// PLACE (a separate output operand made the compiler rebuild each accumulator tuple with ~10 v_mov_b64).  The compiler pads
+// NO wait states between an MFMA and an asm statement that reads its result (measured: ~1 % of rays corrupted, run to run,
+// with a bare asm v_max), so the first statement carries the XDL-write -> VALU-read wait states itself (24 >= the 16-pass
+// requirement) and ties all four tiles to it.
 __device__ __forceinline__ void relu_tiles(f32x16 (&acc)[4])
 {
     asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
@@ -453,9 +455,9 @@ __device__ __forceinline__ void relu_tiles(f32x16 (&acc)[4])
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float x = acc[m][r], y;
-            asm volatile("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
-            acc[m][r] = y;
+            float x = acc[m][r];
+            asm volatile("v_max_f32 %0, 0, %0" : "+v"(x));
+            acc[m][r] = x;
         }
 }
 
@@ -746,12 +748,22 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
 #pragma unroll
         for (int mp = 0; mp < 4; ++mp)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float4 w4 = sW4[(mp * 16 + r) * 2 + h];
-                const float v = acc2[mp][r];
-                const f2 vv = {v, v}, wA = {w4.x, w4.y}, wB = {w4.z, w4.w};
-                hA = __builtin_elementwise_fma(vv, wA, hA);
-                hB = __builtin_elementwise_fma(vv, wB, hB);
+            for (int rb = 0; rb < 16; rb += 8) {
+                // 8 broadcast ds_read_b128 in flight, then their 16 packed FMAs: left alone the compiler issues read -> wait -> FMA
+                // 64 times in a row (one full LDS round trip per hidden unit, 6-7 K cycles per tile)
+                typedef float f4v __attribute__((ext_vector_type(4)));
+                f4v w4[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) w4[q] = *reinterpret_cast<const f4v*>(&sW4[(mp * 16 + rb + q) * 2 + h]);
+                // all eight reads must be issued before the first value is consumed
+                asm volatile("" : "+v"(w4[0]), "+v"(w4[1]), "+v"(w4[2]), "+v"(w4[3]), "+v"(w4[4]), "+v"(w4[5]), "+v"(w4[6]), "+v"(w4[7]));
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float v = acc2[mp][rb + q];
+                    const f2 vv = {v, v}, wA = {w4[q].x, w4[q].y}, wB = {w4[q].z, w4[q].w};
+                    hA = __builtin_elementwise_fma(vv, wA, hA);
+                    hB = __builtin_elementwise_fma(vv, wB, hB);
+                }
             }
         hd0 = hA.x; hd1 = hA.y; hd2 = hB.x; hd3 = hB.y;
     }
