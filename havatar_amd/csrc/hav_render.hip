@@ -448,8 +448,23 @@ __device__ __forceinline__ void split3(float v0, float v1, uint32_t& ph, uint32_
 // NO wait states between an MFMA and an asm statement that reads its result (measured: ~1 % of rays corrupted, run to run,
 // with a bare asm v_max), so the first statement carries the XDL-write -> VALU-read wait states itself (24 >= the 16-pass
 // requirement) and ties all four tiles to it.
+// (In the variants that also carry the composited-hidden-unit accumulators the in-place form costs more in spills than it
+// saves in moves: they keep the two-operand form, INPLACE = false.)
+template <bool INPLACE>
 __device__ __forceinline__ void relu_tiles(f32x16 (&acc)[4])
 {
+    if (!INPLACE) {
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float x = acc[m][r], y;
+                asm volatile("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
+                acc[m][r] = y;
+            }
+        return;
+    }
     asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -534,7 +549,7 @@ struct ProfCtx { unsigned long long t, acc[HAV_NPROF]; };
 #endif
 
 // PREC = 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  PREC = 1: split-operand bf16 MFMA (3 x bf16 per operand, 6 products).
-template <int GQ, int PREC, bool BLK>
+template <int GQ, int PREC, bool BLK, bool LEAN = false>
 __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L, int b, float ox, float oy, float oz, float dx,
                                             float dy, float dz, float z, f32x16 (&acc2)[4], float& hd0, float& hd1, float& hd2,
                                             float& hd3 PROF_ARG)
@@ -696,12 +711,12 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    relu_tiles(acc1);
+    relu_tiles<LEAN>(acc1);
     TICK(4);
 
     __builtin_amdgcn_sched_barrier(0);
     // ---- layer 2: 128 -> 128, relu; B operands are layer-1 accumulator registers, A fragments from LDS ------
-    #pragma unroll
+#pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -735,7 +750,7 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    relu_tiles(acc2);
+    relu_tiles<LEAN>(acc2);
     TICK(5);
 
     __builtin_amdgcn_sched_barrier(0);
@@ -744,27 +759,41 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
     {
         typedef float f2 __attribute__((ext_vector_type(2)));
         f2 hA = {0.f, 0.f}, hB = {0.f, 0.f};                 // packed FMAs: (rgb0, rgb1) and (rgb2, alpha)
-        if (!(a.ablate & 64))
+        if (!(a.ablate & 64)) {
+            if (LEAN) {
 #pragma unroll
-        for (int mp = 0; mp < 4; ++mp)
+            for (int mp = 0; mp < 4; ++mp)
 #pragma unroll
-            for (int rb = 0; rb < 16; rb += 8) {
-                // 8 broadcast ds_read_b128 in flight, then their 16 packed FMAs: left alone the compiler issues read -> wait -> FMA
-                // 64 times in a row (one full LDS round trip per hidden unit, 6-7 K cycles per tile)
-                typedef float f4v __attribute__((ext_vector_type(4)));
-                f4v w4[8];
+                for (int rb = 0; rb < 16; rb += 8) {
+                    // 8 broadcast ds_read_b128 in flight, then their 16 packed FMAs: left alone the compiler issues read -> wait -> FMA
+                    // 64 times in a row (one full LDS round trip per hidden unit, 6-7 K cycles per tile)
+                    typedef float f4v __attribute__((ext_vector_type(4)));
+                    f4v w4[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) w4[q] = *reinterpret_cast<const f4v*>(&sW4[(mp * 16 + rb + q) * 2 + h]);
-                // all eight reads must be issued before the first value is consumed
-                asm volatile("" : "+v"(w4[0]), "+v"(w4[1]), "+v"(w4[2]), "+v"(w4[3]), "+v"(w4[4]), "+v"(w4[5]), "+v"(w4[6]), "+v"(w4[7]));
+                    for (int q = 0; q < 8; ++q) w4[q] = *reinterpret_cast<const f4v*>(&sW4[(mp * 16 + rb + q) * 2 + h]);
+                    // all eight reads must be issued before the first value is consumed
+                    asm volatile("" : "+v"(w4[0]), "+v"(w4[1]), "+v"(w4[2]), "+v"(w4[3]), "+v"(w4[4]), "+v"(w4[5]), "+v"(w4[6]), "+v"(w4[7]));
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const float v = acc2[mp][rb + q];
-                    const f2 vv = {v, v}, wA = {w4[q].x, w4[q].y}, wB = {w4[q].z, w4[q].w};
-                    hA = __builtin_elementwise_fma(vv, wA, hA);
-                    hB = __builtin_elementwise_fma(vv, wB, hB);
+                    for (int q = 0; q < 8; ++q) {
+                        const float v = acc2[mp][rb + q];
+                        const f2 vv = {v, v}, wA = {w4[q].x, w4[q].y}, wB = {w4[q].z, w4[q].w};
+                        hA = __builtin_elementwise_fma(vv, wA, hA);
+                        hB = __builtin_elementwise_fma(vv, wB, hB);
+                    }
                 }
+            } else {
+#pragma unroll
+                for (int mp = 0; mp < 4; ++mp)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float4 w4 = sW4[(mp * 16 + r) * 2 + h];
+                        const float v = acc2[mp][r];
+                        const f2 vv = {v, v}, wA = {w4.x, w4.y}, wB = {w4.z, w4.w};
+                        hA = __builtin_elementwise_fma(vv, wA, hA);
+                        hB = __builtin_elementwise_fma(vv, wB, hB);
+                    }
             }
+        }
         hd0 = hA.x; hd1 = hA.y; hd2 = hB.x; hd3 = hB.y;
     }
     hd0 += __shfl_xor(hd0, 32, 64); hd1 += __shfl_xor(hd1, 32, 64);
@@ -1278,7 +1307,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                     f32x16 acc2[4];
                     float hd0, hd1, hd2, hd3;
                     TICK(0);
-                    sample_eval<(CACHE == 2 ? HAV_GQ2 : 8), PREC, true>(a, L, b, ox, oy, oz, dx, dy, dz, s_n[k * 32 + j], acc2, hd0, hd1, hd2, hd3 PROF_PASS);
+                    sample_eval<(CACHE == 2 ? HAV_GQ2 : 8), PREC, true, CACHE == 2>(a, L, b, ox, oy, oz, dx, dy, dz, s_n[k * 32 + j], acc2, hd0, hd1, hd2, hd3 PROF_PASS);
                     __builtin_amdgcn_sched_barrier(0);
                     park(S_half + k, acc2, hd0, hd1, hd2, hd3);
                     TICK(7);
@@ -1379,7 +1408,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                 f32x16 acc2[4];
                 float hd0, hd1, hd2, hd3;
                 TICK(0);
-                sample_eval<(CACHE == 2 ? HAV_GQ2 : 8), PREC, true>(a, L, b, ox, oy, oz, dx, dy, dz, z, acc2, hd0, hd1, hd2, hd3 PROF_PASS);
+                sample_eval<(CACHE == 2 ? HAV_GQ2 : 8), PREC, true, CACHE == 2>(a, L, b, ox, oy, oz, dx, dy, dz, z, acc2, hd0, hd1, hd2, hd3 PROF_PASS);
                 __builtin_amdgcn_sched_barrier(0);
                 // volume_render_radiance_field (utils/nerf_util.py:28-73), one ray per lane, sequential in s
                 float sg = hd3;
