@@ -130,8 +130,12 @@ class RayMarcher:
         need = int(L.hav_render_workspace_bytes(C.byref(p))) if self.fine_cache else 0
         if need > 0:
             if self._workspace is None or self._workspace.device != dev or self._workspace.numel() < need:
-                self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
-            p.workspace, p.workspace_bytes = self._workspace.data_ptr(), self._workspace.numel()
+                try:
+                    self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+                except torch.OutOfMemoryError:            # no room for the cache: evaluate every merged sample, like the reference
+                    self._workspace, self.fine_cache, need = None, False, 0
+            if need > 0:
+                p.workspace, p.workspace_bytes = self._workspace.data_ptr(), self._workspace.numel()
         t_rand = _chk_f32_cuda("t_rand", t_rand, True)
         u_rand = _chk_f32_cuda("u_rand", u_rand, True)
         noise_c = _chk_f32_cuda("noise_c", noise_c, True)
