@@ -216,3 +216,21 @@ def test_reenactment_cli_gpu(tmp_path, dataset, gold):
 def test_training_step_gpu(dataset, gold):
     """H2 on the device (autograd through the PyTorch statement of the march + the HIP custom ops of the encoders)."""
     _check_step(*_train_step(dataset, gold, "det", "cuda"), gold, "det", rtol=2e-3)
+
+
+def test_reenactment_cli_shards_frames_across_ranks(tmp_path, dataset, gold, monkeypatch):
+    """config 3 plumbing (frames sharded over ranks, no data-path collective): with WORLD_SIZE=2 each rank renders its own frames
+    and writes the same files a single process would."""
+    from havatar_amd.harness import reenact
+    cfg_path = _write_cfg(tmp_path / "cfg.yml")
+    ckpt = _checkpoint(tmp_path / "avatar.pth")
+    monkeypatch.setenv("HAVATAR_WORKERS", "0")
+    names = []
+    for rank in (0, 1):
+        monkeypatch.setenv("RANK", str(rank))
+        monkeypatch.setenv("WORLD_SIZE", "2")
+        written = reenact.main(["--config", cfg_path, "--ckpt", ckpt, "--savedir", str(tmp_path / "out"), "--split", dataset[1]], device="cpu")
+        assert [os.path.basename(p) for p in written] == ["%d_00.png" % rank]
+        names += written
+    for k, p in enumerate(names):
+        _png_close(imgio.imread_rgb(p), gold["h1_png_%d" % k], max_lsb=1, max_frac=0.01)
