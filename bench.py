@@ -24,10 +24,11 @@ FLOP_PER_FRAME = FLOP_PER_QUERY * Q_PER_RAY * H * W     # 2.7848e12
 BYTES_PER_FRAME = 600 * H * W + 8388608 + 2097152 + 190992   # compulsory HBM bytes
 PEAK_FP32_MFMA = 157.3e12                               # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA = 2500e12                                # MI355X_MICROARCH.md: bf16 MFMA, dense
-DTYPE = {False: "f32 (3 x bf16 split-operand MFMA, fp32 accumulate; fp32-sgemm-class results)", True: "f32"}
+DTYPE = {"half": "f32 (2 x fp16 split-operand MFMA, fp32 accumulate; fp32-sgemm-class results)",
+         "split": "f32 (3 x bf16 split-operand MFMA, fp32 accumulate; fp32-sgemm-class results)", "f32": "f32"}
 # matrix-core work the kernel actually executes per 32-sample tile: 11 k-chunks x 4 row tiles x 6 products of
 # v_mfma_f32_32x32x16_bf16 (32768 FLOP each), or 352 v_mfma_f32_32x32x2_f32 (4096 FLOP each) in the exact-fp32 mode
-EXEC_FLOP_PER_TILE = {False: 264 * 32768, True: 352 * 4096}
+EXEC_FLOP_PER_TILE = {"half": 132 * 32768, "split": 264 * 32768, "f32": 352 * 4096}       # MFMA instructions per 32-query tile x FLOP each
 
 
 def cpu_baseline(sc, rows, threads):
@@ -150,7 +151,8 @@ def main():
             cond_c=poses[0].view(1, -1)), n_ev)
     rm = m
 
-    F32 = os.environ.get("HAVATAR_MLP", "split") == "f32"
+    MODE = {"f32": "f32", "split": "split", "bf16": "split"}.get(os.environ.get("HAVATAR_MLP", "half"), "half")
+    F32 = MODE == "f32"
 
     def pmc_traffic(kernel):
         """HBM-side bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (profiles/*_pmc.json, written by
@@ -177,7 +179,7 @@ def main():
         res = {
             "metric": "rendered frames/sec @512^2, 64 samples/ray", "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[os.environ.get("HAVATAR_MLP", "split") == "f32"], "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[MODE], "data": "synthetic",
             "config": {"workload": "cfg2: Trainer.forward(render_full_img=True) for one 512x512 frame per GPU per step: tri-plane encoders "
                                    "(P3: 2x StyleGAN_zxc, MIOpen convs + HIP upfirdn2d/fused_bias_act) -> per-frame plane projection -> fused "
                                    "ray march (P5-P12) over 262144 rays x (64 coarse + 48 fine) = 29.36M radiance-MLP queries -> [1,67,512,512]",
@@ -190,11 +192,11 @@ def main():
                          "traffic": traffic["bytes"] if traffic else None, "traffic_detail": traffic,
                          "kernel_ms": round(kern_ms, 3), "flop_per_launch": FLOP_PER_FRAME,
                          "note": "achieved = ALGORITHMIC fp32 FLOP of the reference network (94848/query) / kernel time, against the fp32 "
-                                 "MFMA peak; the kernel removes 52% of that work by linearity (DESIGN.md 3.3) and, in split mode, runs the "
-                                 "rest on bf16 MFMA, and the fine pass re-uses the even coarse samples instead of evaluating them again (3.7), so frac > 1 is expected",
+                                 "MFMA peak; the kernel removes 52% of that work by linearity (DESIGN.md 3.3) and, in the split modes, runs the "
+                                 "rest on the 16-bit MFMA pipe, and the fine pass re-uses the even coarse samples instead of evaluating them again (3.7), so frac > 1 is expected",
                          "field_evaluations_per_ray": {"reference": Q_PER_RAY, "executed": q_exec},
-                         "mfma_executed_TFLOPs": round(EXEC_FLOP_PER_TILE[F32] * (H * W * q_exec // 32) / (kern_ms * 1e-3) / 1e12, 2),
-                         "mfma_executed_frac_of_peak": round(EXEC_FLOP_PER_TILE[F32] * (H * W * q_exec // 32) / (kern_ms * 1e-3) /
+                         "mfma_executed_TFLOPs": round(EXEC_FLOP_PER_TILE[MODE] * (H * W * q_exec // 32) / (kern_ms * 1e-3) / 1e12, 2),
+                         "mfma_executed_frac_of_peak": round(EXEC_FLOP_PER_TILE[MODE] * (H * W * q_exec // 32) / (kern_ms * 1e-3) /
                                                              (PEAK_FP32_MFMA if F32 else PEAK_BF16_MFMA), 4),
                          "hbm_algorithmic_bytes_per_launch": BYTES_PER_FRAME,
                          "hbm_achieved_GBps": round(BYTES_PER_FRAME / (kern_ms * 1e-3) / 1e9, 2), "hbm_frac_of_8TBps": round(BYTES_PER_FRAME / (kern_ms * 1e-3) / 8e12, 5)},

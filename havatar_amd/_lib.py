@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libhavatar_hip.so")
 
 HAV_F32, HAV_F16, HAV_BF16, HAV_F64 = 0, 1, 2, 3
-HAV_MLP_SPLIT_BF16, HAV_MLP_F32 = 0, 1
+HAV_MLP_SPLIT_BF16, HAV_MLP_F32, HAV_MLP_SPLIT_F16 = 0, 1, 2
 ABI_VERSION = 2
 
 

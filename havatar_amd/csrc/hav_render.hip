@@ -40,6 +40,7 @@
 //  * Experiment knobs (results are WRONG or timing-only when set): HAV_ABLATE bit mask, HAV_STAGGER, -DHAV_PROFILE (phase
 //    timers, tools/phase_profile.sh), HAV_MARCH=pair|blk, HAV_MLP=f32|split.
 #include "hav_common.h"
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -67,7 +68,12 @@
 #define OFF_A2S (OFF_A1S + 3 * 4 * 3 * 64 * 4)      // [8 chunks][4][3][64][4 dwords]  layer 2
 #define OFF_W4S (OFF_A2S + 8 * 4 * 3 * 64 * 4)      // copy of W4 so that [A1S | A2S | W4S] is one contiguous LDS image
 #define LDS3_FLOATS (3 * 4 * 3 * 64 * 4 + 8 * 4 * 3 * 64 * 4 + K2_STEPS * 2 * 4)    // 34304 dwords = 134 KB
-#define BLOB_FLOATS (OFF_W4S + K2_STEPS * 2 * 4)
+// split-operand (2 x fp16) fragments for v_mfma_f32_32x32x16_f16: per (16-wide k chunk, row tile, part hi/lo, lane) 8 halves
+#define OFF_A1H (OFF_W4S + K2_STEPS * 2 * 4)        // [3 chunks][4][2][64][4 dwords]
+#define OFF_A2H (OFF_A1H + 3 * 4 * 2 * 64 * 4)      // [8 chunks][4][2][64][4 dwords]
+#define OFF_W4H (OFF_A2H + 8 * 4 * 2 * 64 * 4)      // copy of W4: [A1H | A2H | W4H] is one contiguous LDS image
+#define LDSH_FLOATS (3 * 4 * 2 * 64 * 4 + 8 * 4 * 2 * 64 * 4 + K2_STEPS * 2 * 4)    // 23040 dwords = 90 KB
+#define BLOB_FLOATS (OFF_W4H + K2_STEPS * 2 * 4)
 
 extern "C" int64_t hav_mlp_blob_bytes(void) { return (int64_t)BLOB_FLOATS * 4; }
 
@@ -108,7 +114,32 @@ __global__ void __launch_bounds__(256) mlp_pack_kernel(float* __restrict__ blob,
             v = (float)s;
         } else v = w.ba[0];
     } else if (e < OFF_W1F) v = w.bf[e - OFF_BF];
-    else if (e >= OFF_W4S) {
+    else if (e >= OFF_W4H) {
+        const int q = e - OFF_W4H;
+        const int c = q & 3, hh = (q >> 2) & 1, ks = q >> 3;
+        const int col = acc_row(ks >> 4, ks & 15, hh);
+        if (c < 3) {
+            double s = 0.0;
+            for (int k = 0; k < 64; ++k) s += (double)w.Wc[c * 64 + k] * (double)w.Wf[k * HAV_HID + col];
+            v = (float)s;
+        } else v = w.Wa[col];
+    } else if (e >= OFF_A1H) {
+        // same element order as the bf16 fragments; 2-way fp16 split, round-to-nearest at both levels: wv = hi + lo (+ <= 2^-22 |wv|)
+        const bool l2 = e >= OFF_A2H;
+        const int q = e - (l2 ? OFF_A2H : OFF_A1H);
+        const int d = q & 3, l = (q >> 2) & 63, part = (q >> 8) & 1, m = (q >> 9) & 3, ch = q >> 11;
+        const int row = 32 * m + (l & 31), hh = l >> 5;
+        uint32_t word = 0;
+        for (int t = 0; t < 2; ++t) {
+            const int el = 2 * d + t;
+            const float wv = l2 ? w.W2[row * HAV_HID + acc_row(ch >> 1, 8 * (ch & 1) + el, hh)]
+                                : w.W1[row * HAV_IN + 2 * HAV_PC + 24 * hh + 8 * ch + el];
+            const __half hi = __float2half_rn(wv);
+            const __half lo = __float2half_rn(wv - __half2float(hi));
+            word |= (uint32_t)__half_as_ushort(part ? lo : hi) << (16 * t);
+        }
+        v = __uint_as_float(word);
+    } else if (e >= OFF_W4S) {
         const int q = e - OFF_W4S;
         const int c = q & 3, hh = (q >> 2) & 1, ks = q >> 3;
         const int col = acc_row(ks >> 4, ks & 15, hh);
@@ -530,6 +561,55 @@ __device__ __forceinline__ void mfma_split3(f32x16 (&acc)[4], const uint4* frag 
     }
     asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[3]) : "v"(pa), "v"(pb));      // the last MFMA's operands outlive it by 32 wait states
 }
+// Two-part fp16 variant: x = hi + lo with both parts rounded to nearest (representation error <= 2^-22 |x|, the order of the fp32
+// accumulation error of a 128-term dot product), three products (hi.lo, lo.hi, hi.hi) on v_mfma_f32_32x32x16_f16: half the
+// matrix time and two thirds of the LDS of the bf16 triple split.  Same operand keep-alive discipline as above.
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split2h(float v0, float v1, uint32_t& ph, uint32_t& pl)
+{
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const f2 v = {v0, v1};
+    const h2 hi = __builtin_convertvector(v, h2);
+    const f2 r = v - __builtin_convertvector(hi, f2);           // exact
+    const h2 lo = __builtin_convertvector(r, h2);
+    ph = __builtin_bit_cast(uint32_t, hi);
+    pl = __builtin_bit_cast(uint32_t, lo);
+}
+template <int NCH, typename GetV>
+__device__ __forceinline__ void mfma_split2h(f32x16 (&acc)[4], const uint4* frag /* [NCH][4 m][2 parts][64 lanes] */, int lane, GetV getv)
+{
+    uint4 A[2][2];
+    uint4 bh, bl;
+    f16x8_t pa, pb;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) A[0][q] = frag[q * 64 + lane];
+#pragma unroll
+    for (int g = 0; g < NCH * 4; ++g) {
+        const int m = g & 3, ch = g >> 2;
+        if (m == 0) {
+            float v[8];
+            getv(ch, v);
+            split2h(v[0], v[1], bh.x, bl.x); split2h(v[2], v[3], bh.y, bl.y);
+            split2h(v[4], v[5], bh.z, bl.z); split2h(v[6], v[7], bh.w, bl.w);
+        }
+        const f16x8_t xh = __builtin_bit_cast(f16x8_t, bh), xl = __builtin_bit_cast(f16x8_t, bl);
+        const f16x8_t ah = __builtin_bit_cast(f16x8_t, A[g & 1][0]), al = __builtin_bit_cast(f16x8_t, A[g & 1][1]);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh, acc[m], 0, 0, 0);
+        if (g > 0) { KEEP(acc[m], pa); KEEP(acc[m], pb); }
+        if (g + 1 < NCH * 4) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) A[(g + 1) & 1][q] = frag[((g + 1) * 2 + q) * 64 + lane];
+        }
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl, acc[m], 0, 0, 0);
+        KEEP(acc[m], al);
+        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh, acc[m], 0, 0, 0);
+        KEEP(acc[m], xl);
+        pa = ah; pb = xh;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[3]) : "v"(pa), "v"(pb));
+}
 #undef KEEP
 
 // Phase timing (tools/phase_profile.sh builds an alternative library with -DHAV_PROFILE): wave-uniform s_memtime deltas summed
@@ -690,7 +770,12 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
     __builtin_amdgcn_sched_barrier(0);
     TICK(3);
 
-    if (PREC == 1) {
+    if (PREC == 2) {
+        mfma_split2h<3>(acc1, L.sA1, lane, [&](int c, float (&v)[8]) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = pe[8 * c + e];
+        });
+    } else if (PREC == 1) {
         if (!(a.ablate & 16))
         mfma_split3<3>(acc1, L.sA1, lane, [&](int c, float (&v)[8]) {
 #pragma unroll
@@ -729,7 +814,12 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
             acc2[m][4 * q + 0] = __uint_as_float(bb[0]); acc2[m][4 * q + 1] = __uint_as_float(bb[1]);
             acc2[m][4 * q + 2] = __uint_as_float(bb[2]); acc2[m][4 * q + 3] = __uint_as_float(bb[3]);
         }
-    if (PREC == 1) {
+    if (PREC == 2) {
+        mfma_split2h<8>(acc2, L.sA2, lane, [&](int ch, float (&v)[8]) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = acc1[ch >> 1][8 * (ch & 1) + e];
+        });
+    } else if (PREC == 1) {
         if (!(a.ablate & 32))
         mfma_split3<8>(acc2, L.sA2, lane, [&](int ch, float (&v)[8]) {
 #pragma unroll
@@ -1150,16 +1240,16 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
     constexpr bool COUT = CACHE != 2;
     const uint32_t call_off = RANDOM ? rng_call_off(a) : 0u;      // one memory read per kernel, not per draw
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int WLDS = PREC == 1 ? LDS3_FLOATS : LDS_FLOATS;     // LDS image: fp32 fragments | split-bf16 fragments
+    constexpr int WLDS = PREC == 2 ? LDSH_FLOATS : (PREC == 1 ? LDS3_FLOATS : LDS_FLOATS);     // LDS image: fp32 | split-bf16 | split-fp16 fragments
     const float* sWFF = smem + OFF_WFT;           // PREC 0: fc_rgbFeat fragments live in the WFT slot (PREC 1 streams them from L2)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* s_n = smem + WLDS + 256 + wave * a.scr_floats;      // [S_f][32] importance samples of this wave's rays (after the b1|b2 copy)
-    if (PREC == 1) {
-        const float4* src = reinterpret_cast<const float4*>(a.blob + OFF_A1S);
+    if (PREC >= 1) {
+        const float4* src = reinterpret_cast<const float4*>(a.blob + (PREC == 2 ? OFF_A1H : OFF_A1S));
         float4* dst = reinterpret_cast<float4*>(smem);
-        for (int i = tid; i < LDS3_FLOATS / 4; i += MARCH_THREADS) dst[i] = src[i];
+        for (int i = tid; i < WLDS / 4; i += MARCH_THREADS) dst[i] = src[i];
     } else {
         const float4* src = reinterpret_cast<const float4*>(a.blob);
         float4* dst = reinterpret_cast<float4*>(smem);
@@ -1180,8 +1270,9 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
     const int j = lane & 31, h = lane >> 5;
     LaneCtx L;
     L.sW1 = smem + OFF_W1PE; L.sW2 = smem + OFF_W2;
-    L.sW4 = reinterpret_cast<const float4*>(smem + (PREC == 1 ? (OFF_W4S - OFF_A1S) : OFF_W4));
-    L.sA1 = reinterpret_cast<const uint4*>(smem); L.sA2 = reinterpret_cast<const uint4*>(smem + (OFF_A2S - OFF_A1S));
+    L.sW4 = reinterpret_cast<const float4*>(smem + (PREC == 2 ? (OFF_W4H - OFF_A1H) : (PREC == 1 ? (OFF_W4S - OFF_A1S) : OFF_W4)));
+    L.sA1 = reinterpret_cast<const uint4*>(smem);
+    L.sA2 = reinterpret_cast<const uint4*>(smem + (PREC == 2 ? (OFF_A2H - OFF_A1H) : (OFF_A2S - OFF_A1S)));
     L.sB = reinterpret_cast<const float4*>(smem + WLDS);
     L.wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.blob), 0, BLOB_FLOATS * 4, 0x00020000);
     L.lane = lane; L.h = h; L.hoff = h * 16;
@@ -1236,7 +1327,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                     og[m][4 * q + 0] = __uint_as_float(bb[0]) * accw; og[m][4 * q + 1] = __uint_as_float(bb[1]) * accw;   // bf * sum_s w_s
                     og[m][4 * q + 2] = __uint_as_float(bb[2]) * accw; og[m][4 * q + 3] = __uint_as_float(bb[3]) * accw;
                 }
-            if (PREC == 1) {          // fragments stream from L2 (once per 32 rays per pass), 8 k-steps in flight
+            if (PREC >= 1) {          // fragments stream from L2 (once per 32 rays per pass), 8 k-steps in flight
                 float wf[2][16];
 #pragma unroll
                 for (int u = 0; u < 16; ++u) wf[0][u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(L.wrs, lane * 4, (OFF_WFF + u * 64) * 4, 0));
@@ -1565,28 +1656,29 @@ extern "C" int64_t hav_render_workspace_bytes(const HavRenderParams* p)
     return (int64_t)march_grid_blocks(p) * MARCH_WAVES * fine_cache_slot_floats(p) * (int64_t)sizeof(float);
 }
 
-static bool use_split_mfma(const HavRenderParams* p)
+// 0 = exact f32 MFMA, 1 = bf16 triple split, 2 = fp16 double split
+static int mlp_prec(const HavRenderParams* p)
 {
-    const char* e = getenv("HAV_MLP");                   // A/B override: "f32" / "split"
-    if (e && e[0] == 'f') return false;
-    if (e && e[0] == 's') return true;
-    return p->mlp_mode != HAV_MLP_F32;
+    const char* e = getenv("HAV_MLP");                   // A/B override: "f32" / "split" (bf16 x 3) / "half" (fp16 x 2)
+    if (e && e[0] == 'f') return 0;
+    if (e && e[0] == 's') return 1;
+    if (e && e[0] == 'h') return 2;
+    return p->mlp_mode == HAV_MLP_F32 ? 0 : (p->mlp_mode == HAV_MLP_SPLIT_F16 ? 2 : 1);
 }
+static bool use_split_mfma(const HavRenderParams* p) { return mlp_prec(p) != 0; }
 
 extern "C" const char* hav_render_variant(const HavRenderParams* p, int coarse_outputs)
 {
     if (!p) return "";
-    if (!coarse_outputs && (p->perturb != 0 || p->noise_std > 0.f) && use_block_kernel(p) && use_split_mfma(p) && use_fine_cache(p))
-        return "hav_march_blk_kernel<1, 1, 2>";
     const bool rnd = p->perturb != 0 || p->noise_std > 0.f;
-    if (use_block_kernel(p)) {
-        if (use_split_mfma(p)) {
-            if (use_fine_cache(p)) return rnd ? "hav_march_blk_kernel<1, 1, 1>" : "hav_march_blk_kernel<0, 1, 1>";
-            return rnd ? "hav_march_blk_kernel<1, 1, 0>" : "hav_march_blk_kernel<0, 1, 0>";
-        }
-        return rnd ? "hav_march_blk_kernel<2, 0, 0>" : "hav_march_blk_kernel<0, 0, 0>";
-    }
-    return rnd ? "hav_march_f32_kernel<true>" : "hav_march_f32_kernel<false>";
+    if (!use_block_kernel(p)) return rnd ? "hav_march_f32_kernel<true>" : "hav_march_f32_kernel<false>";
+    static char name[64];
+    const int prec = mlp_prec(p);
+    const bool cache = use_fine_cache(p);
+    const int cm = (cache && !coarse_outputs && rnd) ? 2 : (cache ? 1 : 0);
+    const int rm = !rnd ? 0 : (prec == 0 ? 2 : 1);          // (the f32 mode only instantiates the injected-tensor RNG variant)
+    snprintf(name, sizeof(name), "hav_march_blk_kernel<%d, %d, %d>", rm, prec, cm);
+    return name;
 }
 
 extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, const float* bg, const float* inv_T,
@@ -1599,7 +1691,7 @@ extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, cons
     if (p->plane_ch != HAV_PC) return HAV_EUNSUP;                 // Trainer hard-codes triPlane_feat_dim=64 (nerf_trainer.py:22)
     if (p->plane_res < 2 || p->vol_res < 2) return HAV_EINVAL;
     if (p->S_c > 256 || p->S_f > 128) return HAV_EUNSUP;
-    if (p->reserved != 0 || (p->mlp_mode != HAV_MLP_SPLIT_BF16 && p->mlp_mode != HAV_MLP_F32)) return HAV_EINVAL;
+    if (p->reserved != 0 || (p->mlp_mode != HAV_MLP_SPLIT_BF16 && p->mlp_mode != HAV_MLP_F32 && p->mlp_mode != HAV_MLP_SPLIT_F16)) return HAV_EINVAL;
     // the coarse pass's composited outputs may be declined (all three NULL) when there is a fine pass: Trainer.forward then only
     // uses the fine ones, and the kernel drops the accumulators that exist for them
     const bool no_coarse_out = !out->rgb_coarse && !out->depth_coarse && !out->acc_coarse;
@@ -1634,13 +1726,17 @@ extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, cons
     const bool random = p->perturb != 0 || p->noise_std > 0.f;
     static bool attr_set = false;
     if (!attr_set) {
-        const void* ks[11] = {(const void*)hav_march_f32_kernel<false>, (const void*)hav_march_f32_kernel<true>,
+        const void* ks[18] = {(const void*)hav_march_f32_kernel<false>, (const void*)hav_march_f32_kernel<true>,
                               (const void*)hav_march_blk_kernel<0, 0, 0>, (const void*)hav_march_blk_kernel<2, 0, 0>,
                               (const void*)hav_march_blk_kernel<0, 1, 0>, (const void*)hav_march_blk_kernel<1, 1, 0>,
                               (const void*)hav_march_blk_kernel<2, 1, 0>, (const void*)hav_march_blk_kernel<0, 1, 1>,
                               (const void*)hav_march_blk_kernel<1, 1, 1>, (const void*)hav_march_blk_kernel<2, 1, 1>,
-                              (const void*)hav_march_blk_kernel<1, 1, 2>};
-        for (int i = 0; i < 11; ++i) {
+                              (const void*)hav_march_blk_kernel<1, 1, 2>,
+                              (const void*)hav_march_blk_kernel<0, 2, 0>, (const void*)hav_march_blk_kernel<1, 2, 0>,
+                              (const void*)hav_march_blk_kernel<2, 2, 0>, (const void*)hav_march_blk_kernel<0, 2, 1>,
+                              (const void*)hav_march_blk_kernel<1, 2, 1>, (const void*)hav_march_blk_kernel<2, 2, 1>,
+                              (const void*)hav_march_blk_kernel<1, 2, 2>};
+        for (int i = 0; i < 18; ++i) {
             hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return (int)e;
         }
@@ -1649,7 +1745,8 @@ extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, cons
     if (use_block_kernel(p)) {
         a.scr_floats = ((p->S_f > 0 ? p->S_f : 1) * 32 + 3) & ~3;
         const bool split = use_split_mfma(p);
-        const size_t ldsb = ((size_t)(split ? LDS3_FLOATS : LDS_FLOATS) + 256 + (size_t)MARCH_WAVES * a.scr_floats) * sizeof(float);
+        const int precl = mlp_prec(p);
+        const size_t ldsb = ((size_t)(precl == 2 ? LDSH_FLOATS : (precl == 1 ? LDS3_FLOATS : LDS_FLOATS)) + 256 + (size_t)MARCH_WAVES * a.scr_floats) * sizeof(float);
         if (ldsb > 160 * 1024) return HAV_EUNSUP;
         const int gridb = march_grid_blocks(p);
         const bool injected = t_rand || u_rand || noise_c || noise_f;     // parity tests; production draws everything on the device
@@ -1658,10 +1755,17 @@ extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, cons
         a.ws = cache ? (float*)p->workspace : nullptr;
         a.ws_slot = fine_cache_slot_floats(p);
 #define LAUNCH_BLK(R_, P_, C_) hipLaunchKernelGGL((hav_march_blk_kernel<R_, P_, C_>), dim3(gridb), dim3(MARCH_THREADS), ldsb, (hipStream_t)stream, a)
-        if (split && cache && no_coarse_out && rm == 1) LAUNCH_BLK(1, 1, 2);          // the production variant: jitter, cache, fine outputs only
-        else if (split && cache) { if (rm == 0) LAUNCH_BLK(0, 1, 1); else if (rm == 1) LAUNCH_BLK(1, 1, 1); else LAUNCH_BLK(2, 1, 1); }
-        else if (split) { if (rm == 0) LAUNCH_BLK(0, 1, 0); else if (rm == 1) LAUNCH_BLK(1, 1, 0); else LAUNCH_BLK(2, 1, 0); }
+        const int prec = mlp_prec(p);
+#define LAUNCH_SPLIT(P_)                                                                                                          \
+        do {                                                                                                                      \
+            if (cache && no_coarse_out && rm == 1) LAUNCH_BLK(1, P_, 2);          /* production: jitter, cache, fine maps only */ \
+            else if (cache) { if (rm == 0) LAUNCH_BLK(0, P_, 1); else if (rm == 1) LAUNCH_BLK(1, P_, 1); else LAUNCH_BLK(2, P_, 1); } \
+            else { if (rm == 0) LAUNCH_BLK(0, P_, 0); else if (rm == 1) LAUNCH_BLK(1, P_, 0); else LAUNCH_BLK(2, P_, 0); }        \
+        } while (0)
+        if (prec == 2) LAUNCH_SPLIT(2);
+        else if (prec == 1) LAUNCH_SPLIT(1);
         else { if (rm == 0) LAUNCH_BLK(0, 0, 0); else LAUNCH_BLK(2, 0, 0); }
+#undef LAUNCH_SPLIT
 #undef LAUNCH_BLK
         HAV_LAUNCH_CHECK();
         if (p->rng_counter && random) { hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)p->rng_counter); HAV_LAUNCH_CHECK(); }

@@ -122,7 +122,7 @@ typedef struct HavRenderParams {
     float   skin_scale[3], skin_trans[3];   /* ... of the skinning box (nerf_trainer.py:29-34)  */
     uint64_t seed;        /* key of the on-device xi/zeta/eps streams used when the rand pointers are NULL */
     uint64_t rng_offset;  /* counter base of the on-device streams (advance per call)          */
-    int32_t mlp_mode;     /* HAV_MLP_SPLIT_BF16 (0, default) or HAV_MLP_F32                    */
+    int32_t mlp_mode;     /* HAV_MLP_SPLIT_BF16 (0), HAV_MLP_F32 (1) or HAV_MLP_SPLIT_F16 (2)   */
     int32_t reserved;     /* must be 0                                                         */
     uint64_t* rng_counter; /* optional DEVICE counter: the call uses rng_offset + *rng_counter and increments the counter
                             * on the stream afterwards, so a hipGraph replay of a captured call draws fresh jitter    */
@@ -133,12 +133,16 @@ typedef struct HavRenderParams {
     uint64_t workspace_bytes;
 } HavRenderParams;
 
-/* How the two dense layers run on the matrix cores.  Both produce fp32-sgemm-class results (parity tests run both):
+/* How the two dense layers run on the matrix cores.  All three produce fp32-sgemm-class results (parity tests run all):
  *  HAV_MLP_SPLIT_BF16: each fp32 operand is split exactly into 3 bf16 parts and the 6 leading bf16 x bf16 products are
  *                      accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (error ~2^-23 relative per product);
  *  HAV_MLP_F32:        v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fmaf chain. */
 #define HAV_MLP_SPLIT_BF16 0
 #define HAV_MLP_F32        1
+#define HAV_MLP_SPLIT_F16  2     /* each fp32 operand = hi + lo fp16 (both rounded to nearest: <= 2^-22 relative -- the size of the
+                                  * fp32 accumulation error of a 128-term dot product), 3 products on v_mfma_f32_32x32x16_f16:
+                                  * half the matrix time and two thirds of the LDS of the bf16 triple split.  Needs weights and
+                                  * hidden activations below 65504 in magnitude (fp16 range); the Python layer's default. */
 
 /* Bytes of scratch with which hav_render_rays can skip the repeated even coarse samples for these parameters
  * (0: not applicable -- no fine pass, exact-f32 mode, or num_coarse > 67). */

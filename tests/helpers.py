@@ -32,7 +32,7 @@ def load_render_fixture(name):
 
 
 def hip_render(sc, S_c, S_f, perturb=False, noise_std=0.0, t_rand=None, u_rand=None, noise_c=None, noise_f=None,
-               dbg_zfine=False, mlp="split"):
+               dbg_zfine=False, mlp="half"):
     """Run the HIP ray march (through the C ABI) on a synth-style scene; returns numpy outputs keyed like OUT_KEYS."""
     import torch
     from havatar_amd.render import RayMarcher
@@ -40,7 +40,7 @@ def hip_render(sc, S_c, S_f, perturb=False, noise_std=0.0, t_rand=None, u_rand=N
     t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
     from havatar_amd import _lib
     rm = RayMarcher(sc["nerf_scale"], sc["nerf_trans"], sc["skin_scale"], sc["skin_trans"])
-    rm.mlp_mode = _lib.HAV_MLP_F32 if mlp == "f32" else _lib.HAV_MLP_SPLIT_BF16
+    rm.mlp_mode = {"f32": _lib.HAV_MLP_F32, "half": _lib.HAV_MLP_SPLIT_F16}.get(mlp, _lib.HAV_MLP_SPLIT_BF16)
     m = sc["mlp"]
     rm.set_mlp(*[t(m[k]) for k in ("W1", "b1", "W2", "b2", "Wa", "ba", "Wf", "bf", "Wc", "bc")])
     rm.set_triplane(t(sc["planes"]))

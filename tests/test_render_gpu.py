@@ -16,7 +16,7 @@ RENDER = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN,
 TOL = dict(rgb_coarse=2e-5, depth_coarse=1e-4, acc_coarse=2e-5, weights_max=1e-3, rgb_fine=1e-3, depth_fine=5e-3, acc_fine=1e-3)
 
 
-MLP_MODES = ("split", "f32")      # both matrix-core modes of the MLP (include/havatar.h: HAV_MLP_SPLIT_BF16 / HAV_MLP_F32)
+MLP_MODES = ("half", "split", "f32")      # the three matrix-core modes of the MLP (include/havatar.h: HAV_MLP_SPLIT_F16 / _SPLIT_BF16 / _F32)
 
 
 @pytest.mark.parametrize("mlp", MLP_MODES)
