@@ -72,8 +72,9 @@
 #define OFF_A1H (OFF_W4S + K2_STEPS * 2 * 4)        // [3 chunks][4][2][64][4 dwords]
 #define OFF_A2H (OFF_A1H + 3 * 4 * 2 * 64 * 4)      // [8 chunks][4][2][64][4 dwords]
 #define OFF_W4H (OFF_A2H + 8 * 4 * 2 * 64 * 4)      // copy of W4: [A1H | A2H | W4H] is one contiguous LDS image
-#define LDSH_FLOATS (3 * 4 * 2 * 64 * 4 + 8 * 4 * 2 * 64 * 4 + K2_STEPS * 2 * 4)    // 23040 dwords = 90 KB
-#define BLOB_FLOATS (OFF_W4H + K2_STEPS * 2 * 4)
+#define OFF_AFH (OFF_W4H + K2_STEPS * 2 * 4)        // [8 chunks][2 row tiles][2][64][4 dwords]  fc_rgbFeat, same k order as layer 2
+#define LDSH_FLOATS (3 * 4 * 2 * 64 * 4 + 8 * 4 * 2 * 64 * 4 + K2_STEPS * 2 * 4 + 8 * 2 * 2 * 64 * 4)    // 31232 dwords = 122 KB
+#define BLOB_FLOATS (OFF_AFH + 8 * 2 * 2 * 64 * 4)
 
 extern "C" int64_t hav_mlp_blob_bytes(void) { return (int64_t)BLOB_FLOATS * 4; }
 
@@ -114,7 +115,19 @@ __global__ void __launch_bounds__(256) mlp_pack_kernel(float* __restrict__ blob,
             v = (float)s;
         } else v = w.ba[0];
     } else if (e < OFF_W1F) v = w.bf[e - OFF_BF];
-    else if (e >= OFF_W4H) {
+    else if (e >= OFF_AFH) {
+        const int q = e - OFF_AFH;
+        const int d = q & 3, l = (q >> 2) & 63, part = (q >> 8) & 1, m = (q >> 9) & 1, ch = q >> 10;
+        const int row = 32 * m + (l & 31), hh = l >> 5;
+        uint32_t word = 0;
+        for (int t = 0; t < 2; ++t) {
+            const float wv = w.Wf[row * HAV_HID + acc_row(ch >> 1, 8 * (ch & 1) + 2 * d + t, hh)];
+            const __half hi = __float2half_rn(wv);
+            const __half lo = __float2half_rn(wv - __half2float(hi));
+            word |= (uint32_t)__half_as_ushort(part ? lo : hi) << (16 * t);
+        }
+        v = __uint_as_float(word);
+    } else if (e >= OFF_W4H) {
         const int q = e - OFF_W4H;
         const int c = q & 3, hh = (q >> 2) & 1, ks = q >> 3;
         const int col = acc_row(ks >> 4, ks & 15, hh);
@@ -444,6 +457,7 @@ __device__ __forceinline__ float z_coarse(const MarchArgs& a, long long gr, cons
 struct LaneCtx {
     const float* sW1; const float* sW2; const float4* sW4;
     const uint4* sA1; const uint4* sA2;         // split-bf16 fragments (PREC == 1 kernels)
+    const uint4* sAF;                           // fc_rgbFeat fragments (fp16 split; feature parking, PREC == 2)
     const float4* sB;                           // LDS copy of b1 | b2 (block kernel; the pair kernel reads them through the buffer path)
     __amdgpu_buffer_rsrc_t wrs;
     int lane, h, hoff;
@@ -576,8 +590,8 @@ __device__ __forceinline__ void split2h(float v0, float v1, uint32_t& ph, uint32
     ph = __builtin_bit_cast(uint32_t, hi);
     pl = __builtin_bit_cast(uint32_t, lo);
 }
-template <int NCH, typename GetV>
-__device__ __forceinline__ void mfma_split2h(f32x16 (&acc)[4], const uint4* frag /* [NCH][4 m][2 parts][64 lanes] */, int lane, GetV getv)
+template <int NCH, int NM, typename GetV>
+__device__ __forceinline__ void mfma_split2h(f32x16 (&acc)[NM], const uint4* frag /* [NCH][NM row tiles][2 parts][64 lanes] */, int lane, GetV getv)
 {
     uint4 A[2][2];
     uint4 bh, bl;
@@ -585,8 +599,8 @@ __device__ __forceinline__ void mfma_split2h(f32x16 (&acc)[4], const uint4* frag
 #pragma unroll
     for (int q = 0; q < 2; ++q) A[0][q] = frag[q * 64 + lane];
 #pragma unroll
-    for (int g = 0; g < NCH * 4; ++g) {
-        const int m = g & 3, ch = g >> 2;
+    for (int g = 0; g < NCH * NM; ++g) {
+        const int m = g % NM, ch = g / NM;
         if (m == 0) {
             float v[8];
             getv(ch, v);
@@ -597,7 +611,7 @@ __device__ __forceinline__ void mfma_split2h(f32x16 (&acc)[4], const uint4* frag
         const f16x8_t ah = __builtin_bit_cast(f16x8_t, A[g & 1][0]), al = __builtin_bit_cast(f16x8_t, A[g & 1][1]);
         acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh, acc[m], 0, 0, 0);
         if (g > 0) { KEEP(acc[m], pa); KEEP(acc[m], pb); }
-        if (g + 1 < NCH * 4) {
+        if (g + 1 < NCH * NM) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) A[(g + 1) & 1][q] = frag[((g + 1) * 2 + q) * 64 + lane];
         }
@@ -608,7 +622,7 @@ __device__ __forceinline__ void mfma_split2h(f32x16 (&acc)[4], const uint4* frag
         pa = ah; pb = xh;
         __builtin_amdgcn_sched_barrier(0);
     }
-    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[3]) : "v"(pa), "v"(pb));
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[NM - 1]) : "v"(pa), "v"(pb));
 }
 #undef KEEP
 
@@ -771,7 +785,7 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
     TICK(3);
 
     if (PREC == 2) {
-        mfma_split2h<3>(acc1, L.sA1, lane, [&](int c, float (&v)[8]) {
+        mfma_split2h<3, 4>(acc1, L.sA1, lane, [&](int c, float (&v)[8]) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = pe[8 * c + e];
         });
@@ -815,7 +829,7 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
             acc2[m][4 * q + 2] = __uint_as_float(bb[2]); acc2[m][4 * q + 3] = __uint_as_float(bb[3]);
         }
     if (PREC == 2) {
-        mfma_split2h<8>(acc2, L.sA2, lane, [&](int ch, float (&v)[8]) {
+        mfma_split2h<8, 4>(acc2, L.sA2, lane, [&](int ch, float (&v)[8]) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = acc1[ch >> 1][8 * (ch & 1) + e];
         });
@@ -1238,6 +1252,10 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
 {
     constexpr int RM = RANDOM;
     constexpr bool COUT = CACHE != 2;
+    // fp16 mode: the fc_rgbFeat fragments fit in LDS next to the layer weights, so what is parked per sample is its 64 FEATURES
+    // (8 rows of 1 KB per wave) instead of its 128 hidden units (16 rows): half the parking traffic for 48 more MFMAs per parked tile
+    constexpr bool FEATPARK = (PREC == 2) && (CACHE != 0);
+    constexpr int H2F = FEATPARK ? WS_H2_FLOATS / 2 : WS_H2_FLOATS, ENTF = H2F + 128 + 32;      // floats of one parked entry
     const uint32_t call_off = RANDOM ? rng_call_off(a) : 0u;      // one memory read per kernel, not per draw
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int WLDS = PREC == 2 ? LDSH_FLOATS : (PREC == 1 ? LDS3_FLOATS : LDS_FLOATS);     // LDS image: fp32 | split-bf16 | split-fp16 fragments
@@ -1273,6 +1291,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
     L.sW4 = reinterpret_cast<const float4*>(smem + (PREC == 2 ? (OFF_W4H - OFF_A1H) : (PREC == 1 ? (OFF_W4S - OFF_A1S) : OFF_W4)));
     L.sA1 = reinterpret_cast<const uint4*>(smem);
     L.sA2 = reinterpret_cast<const uint4*>(smem + (PREC == 2 ? (OFF_A2H - OFF_A1H) : (OFF_A2S - OFF_A1S)));
+    L.sAF = reinterpret_cast<const uint4*>(smem + (OFF_AFH - OFF_A1H));
     L.sB = reinterpret_cast<const float4*>(smem + WLDS);
     L.wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.blob), 0, BLOB_FLOATS * 4, 0x00020000);
     L.lane = lane; L.h = h; L.hoff = h * 16;
@@ -1307,16 +1326,33 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
         const RKey rkey = RANDOM ? rng_ray_key(a, gr, call_off) : RKey{0u, 0u, 0u};
         float* slot = CACHE ? a.ws + ((a.ablate & 1024) ? 0 : a.ws_slot * ((long long)blockIdx.x * MARCH_WAVES + wave)) : nullptr;   // 1024: timing experiment, all waves share one L2-resident slot
         auto park = [&](int e, const f32x16 (&v)[4], float r0, float r1, float r2, float r3) {       // entry e of this block's slot
-            float4* H2 = reinterpret_cast<float4*>(slot + (size_t)e * WS_ENTRY_FLOATS);
+            float4* H2 = reinterpret_cast<float4*>(slot + (size_t)e * ENTF);
+            if (FEATPARK) {
+                f32x16 ft[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ft[m][r] = 0.f;
+                mfma_split2h<8, 2>(ft, L.sAF, lane, [&](int ch, float (&x)[8]) {
+#pragma unroll
+                    for (int el = 0; el < 8; ++el) x[el] = v[ch >> 1][8 * (ch & 1) + el];
+                });
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg)
+                        nt_store4(&H2[(m * 4 + rg) * 64 + lane], make_float4(ft[m][4 * rg + 0], ft[m][4 * rg + 1], ft[m][4 * rg + 2], ft[m][4 * rg + 3]));
+            } else
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg)
                     nt_store4(&H2[(m * 4 + rg) * 64 + lane], make_float4(v[m][4 * rg + 0], v[m][4 * rg + 1], v[m][4 * rg + 2], v[m][4 * rg + 3]));
-            if (h == 0) reinterpret_cast<float4*>(slot + (size_t)e * WS_ENTRY_FLOATS + WS_H2_FLOATS)[j] = make_float4(r0, r1, r2, r3);
+            if (h == 0) reinterpret_cast<float4*>(slot + (size_t)e * ENTF + H2F)[j] = make_float4(r0, r1, r2, r3);
         };
         // fc_rgbFeat on the composited hidden units ([64 x 128] . [128 x 32 rays] on the matrix cores) + the per-ray output stores
-        auto emit = [&](int pass, const f32x16 (&hs)[4], float c0, float c1, float c2, float dep, float accw, float wmax) {
+        auto emit = [&](int pass, const f32x16 (&hs)[4], float c0, float c1, float c2, float dep, float accw, float wmax,
+                        const f32x16* fs = nullptr) {          // fs: composited features (feature parking) instead of hidden units
             // ---- fc_rgbFeat on the composited hidden units: [64 x 128] . [128 x 32 rays] on the matrix cores -------------
             f32x16 og[2];
 #pragma unroll
@@ -1327,7 +1363,10 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                     og[m][4 * q + 0] = __uint_as_float(bb[0]) * accw; og[m][4 * q + 1] = __uint_as_float(bb[1]) * accw;   // bf * sum_s w_s
                     og[m][4 * q + 2] = __uint_as_float(bb[2]) * accw; og[m][4 * q + 3] = __uint_as_float(bb[3]) * accw;
                 }
-            if (PREC >= 1) {          // fragments stream from L2 (once per 32 rays per pass), 8 k-steps in flight
+            if (fs) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) og[m] += fs[m];
+            } else if (PREC >= 1) {          // fragments stream from L2 (once per 32 rays per pass), 8 k-steps in flight
                 float wf[2][16];
 #pragma unroll
                 for (int u = 0; u < 16; ++u) wf[0][u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(L.wrs, lane * 4, (OFF_WFF + u * 64) * 4, 0));
@@ -1420,13 +1459,13 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                 nk = s_n[j];
                 constexpr int FQ = 8;
                 float zq[FQ]; int eq[FQ]; float4 rq[FQ];
-                const float4* RAWp = reinterpret_cast<const float4*>(slot + WS_H2_FLOATS);          // + e * (WS_ENTRY_FLOATS / 4)
+                const float4* RAWp = reinterpret_cast<const float4*>(slot + H2F);          // + e * (ENTF / 4)
                 int produced = 0;
 #pragma unroll
                 for (int u = 0; u < FQ; ++u) {
                     zq[u] = 0.f; eq[u] = 0;
                     if (produced < S) { zq[u] = next_entry(eq[u]); ++produced; }
-                    rq[u] = RAWp[(size_t)eq[u] * (WS_ENTRY_FLOATS / 4) + j];
+                    rq[u] = RAWp[(size_t)eq[u] * (ENTF / 4) + j];
                 }
                 float dist = 0.f;
                 for (int s0 = 0; s0 < S; s0 += FQ) {
@@ -1440,7 +1479,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                             // refill this slot with merged sample sidx + FQ (if any) before using its neighbour's depth
                             if (produced < S) {
                                 zq[u] = next_entry(eq[u]); ++produced;
-                                rq[u] = RAWp[(size_t)eq[u] * (WS_ENTRY_FLOATS / 4) + j];
+                                rq[u] = RAWp[(size_t)eq[u] * (ENTF / 4) + j];
                             }
                             if (sidx + 1 < S) dist = zq[(u + 1) % FQ] - zc;          // dists[-1] repeats dists[-2] (:36-37)
                             float sg = raw.w;
@@ -1458,7 +1497,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                             dep = fmaf(wgt, zc, dep);
                             accw += wgt;
                             wmax = fmaxf(wmax, wgt);
-                            slot[(size_t)ec * WS_ENTRY_FLOATS + WS_H2_FLOATS + 128 + j] = wgt;       // both half-waves write the same value
+                            slot[(size_t)ec * ENTF + H2F + 128 + j] = wgt;       // both half-waves write the same value
                             if (a.dbg_zfine && h == 0 && rayok) a.dbg_zfine[gr * S_fp + sidx] = zc;
                         }
                     }
@@ -1466,17 +1505,18 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                 TICK(0);            // (profile build: stage A is booked under "loop top", stage B under "positional encoding")
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                // ---- stage B: composited hidden units, entry order (coalesced 1-KB rows) --------------------------------------
+                // ---- stage B: composited hidden units (or features), entry order (coalesced 1-KB rows) ---------------------------
                 f32x16 hsumB[4];
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) hsumB[m][r] = 0.f;
+                constexpr int NROW = FEATPARK ? 8 : 16;
                 for (int e = 0; e < S; ++e) {
-                    const float4* H2 = reinterpret_cast<const float4*>(slot + (size_t)e * WS_ENTRY_FLOATS);
-                    const float wgt = slot[(size_t)e * WS_ENTRY_FLOATS + WS_H2_FLOATS + 128 + j];
+                    const float4* H2 = reinterpret_cast<const float4*>(slot + (size_t)e * ENTF);
+                    const float wgt = slot[(size_t)e * ENTF + H2F + 128 + j];
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) {
+                    for (int q = 0; q < NROW; ++q) {
                         const float4 v = nt_load4(&H2[q * 64 + lane]);
                         hsumB[q >> 2][4 * (q & 3) + 0] = fmaf(wgt, v.x, hsumB[q >> 2][4 * (q & 3) + 0]);
                         hsumB[q >> 2][4 * (q & 3) + 1] = fmaf(wgt, v.y, hsumB[q >> 2][4 * (q & 3) + 1]);
@@ -1485,7 +1525,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                     }
                 }
                 TICK(3);
-                emit(1, hsumB, c0, c1, c2, dep, accw, wmax);
+                emit(1, hsumB, c0, c1, c2, dep, accw, wmax, FEATPARK ? hsumB : nullptr);       // (feature parking: hsumB[0..1] are the features)
             }
             if (pass == 0) { z = z_coarse<RM>(a, gr, rkey, 0, near, far); znext = z_coarse<RM>(a, gr, rkey, 1, near, far); }
             else if (!CACHE) {
@@ -1628,10 +1668,11 @@ static int march_grid_blocks(const HavRenderParams* p)
     if (needb < gridb) gridb = (int)((needb + 7) / 8 * 8);
     return gridb;
 }
+static int mlp_prec(const HavRenderParams* p);
 static long long fine_cache_slot_floats(const HavRenderParams* p)
 {
     const long long S_fp = (p->S_c + 1) / 2 + p->S_f;
-    return S_fp * WS_ENTRY_FLOATS;
+    return S_fp * ((mlp_prec(p) == 2 ? WS_H2_FLOATS / 2 : WS_H2_FLOATS) + 128 + 32);      // features (fp16 mode) or hidden units
 }
 static bool use_split_mfma(const HavRenderParams* p);
 static bool use_block_kernel(const HavRenderParams* p);
