@@ -1682,10 +1682,11 @@ static bool use_fine_cache(const HavRenderParams* p)
     // Measured on MI355X: with stratified jitter on (the production setting) skipping the repeated samples is
     // worth 10-15 % of the kernel; with deterministic depths the coarse tiles are so coherent (all 32 rays at the same depth)
     // that the 13 GB of parking traffic per frame cancels the gain.  Default: cache iff perturb; HAV_FINE=cache|recompute forces.
+    // With feature parking (fp16 mode) the parking stream is half as large and the cache pays with deterministic depths as well.
     const char* e = getenv("HAV_FINE");
     if (e && !strcmp(e, "recompute")) return false;
     const bool forced = e && !strcmp(e, "cache");
-    if (!forced && !p->perturb) return false;
+    if (!forced && !p->perturb && mlp_prec(p) != 2) return false;
     if (!use_block_kernel(p) || !use_split_mfma(p) || p->S_f <= 0 || !p->workspace) return false;
     return p->workspace_bytes >= (uint64_t)march_grid_blocks(p) * MARCH_WAVES * fine_cache_slot_floats(p) * sizeof(float);
 }
@@ -1693,7 +1694,7 @@ extern "C" int64_t hav_render_workspace_bytes(const HavRenderParams* p)
 {
     if (!p || p->S_f <= 0 || p->S_c < 2 || p->R < 0 || p->B < 1) return 0;
     if (!use_block_kernel(p) || !use_split_mfma(p)) return 0;
-    { const char* e = getenv("HAV_FINE"); if (e ? strcmp(e, "cache") != 0 : !p->perturb) return 0; }
+    { const char* e = getenv("HAV_FINE"); if (e ? strcmp(e, "cache") != 0 : (!p->perturb && mlp_prec(p) != 2)) return 0; }
     return (int64_t)march_grid_blocks(p) * MARCH_WAVES * fine_cache_slot_floats(p) * (int64_t)sizeof(float);
 }
 
@@ -1716,7 +1717,7 @@ extern "C" const char* hav_render_variant(const HavRenderParams* p, int coarse_o
     static char name[64];
     const int prec = mlp_prec(p);
     const bool cache = use_fine_cache(p);
-    const int cm = (cache && !coarse_outputs && rnd) ? 2 : (cache ? 1 : 0);
+    const int cm = (cache && !coarse_outputs && (rnd || prec == 2)) ? 2 : (cache ? 1 : 0);
     const int rm = !rnd ? 0 : (prec == 0 ? 2 : 1);          // (the f32 mode only instantiates the injected-tensor RNG variant)
     snprintf(name, sizeof(name), "hav_march_blk_kernel<%d, %d, %d>", rm, prec, cm);
     return name;
@@ -1767,7 +1768,7 @@ extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, cons
     const bool random = p->perturb != 0 || p->noise_std > 0.f;
     static bool attr_set = false;
     if (!attr_set) {
-        const void* ks[18] = {(const void*)hav_march_f32_kernel<false>, (const void*)hav_march_f32_kernel<true>,
+        const void* ks[19] = {(const void*)hav_march_f32_kernel<false>, (const void*)hav_march_f32_kernel<true>,
                               (const void*)hav_march_blk_kernel<0, 0, 0>, (const void*)hav_march_blk_kernel<2, 0, 0>,
                               (const void*)hav_march_blk_kernel<0, 1, 0>, (const void*)hav_march_blk_kernel<1, 1, 0>,
                               (const void*)hav_march_blk_kernel<2, 1, 0>, (const void*)hav_march_blk_kernel<0, 1, 1>,
@@ -1776,8 +1777,8 @@ extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, cons
                               (const void*)hav_march_blk_kernel<0, 2, 0>, (const void*)hav_march_blk_kernel<1, 2, 0>,
                               (const void*)hav_march_blk_kernel<2, 2, 0>, (const void*)hav_march_blk_kernel<0, 2, 1>,
                               (const void*)hav_march_blk_kernel<1, 2, 1>, (const void*)hav_march_blk_kernel<2, 2, 1>,
-                              (const void*)hav_march_blk_kernel<1, 2, 2>};
-        for (int i = 0; i < 18; ++i) {
+                              (const void*)hav_march_blk_kernel<1, 2, 2>, (const void*)hav_march_blk_kernel<0, 2, 2>};
+        for (int i = 0; i < 19; ++i) {
             hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return (int)e;
         }
@@ -1800,6 +1801,7 @@ extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, cons
 #define LAUNCH_SPLIT(P_)                                                                                                          \
         do {                                                                                                                      \
             if (cache && no_coarse_out && rm == 1) LAUNCH_BLK(1, P_, 2);          /* production: jitter, cache, fine maps only */ \
+            else if (cache && no_coarse_out && rm == 0 && P_ == 2) LAUNCH_BLK(0, 2, 2);                                           \
             else if (cache) { if (rm == 0) LAUNCH_BLK(0, P_, 1); else if (rm == 1) LAUNCH_BLK(1, P_, 1); else LAUNCH_BLK(2, P_, 1); } \
             else { if (rm == 0) LAUNCH_BLK(0, P_, 0); else if (rm == 1) LAUNCH_BLK(1, P_, 0); else LAUNCH_BLK(2, P_, 0); }        \
         } while (0)

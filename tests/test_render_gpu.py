@@ -258,8 +258,13 @@ def test_fine_pass_cache_is_the_default_with_jitter_and_needs_a_workspace(monkey
     sc = synth.scene(8, 8, "primary")
     rm = RayMarcher(sc["nerf_scale"], sc["nerf_trans"], sc["skin_scale"], sc["skin_trans"])
     monkeypatch.delenv("HAV_FINE", raising=False)
-    assert rm.variant(64, 16, perturb=True).endswith(", 1>") and rm.variant(64, 16, perturb=False).endswith(", 0>")
+    from havatar_amd import _lib
+    # fp16 mode (default): the cache is on whenever a workspace is offered; bf16 mode: only with jitter
+    assert rm.variant(64, 16, perturb=True).endswith(", 1>") and rm.variant(64, 16, perturb=False).endswith(", 1>")
     assert rm.variant(64, 16, perturb=True, coarse_outputs=False).endswith(", 2>")      # production: jitter, cache, fine maps only
+    rm.mlp_mode = _lib.HAV_MLP_SPLIT_BF16
+    assert rm.variant(64, 16, perturb=True).endswith("1, 1>") and rm.variant(64, 16, perturb=False).endswith("1, 0>")
+    rm.mlp_mode = _lib.HAV_MLP_SPLIT_F16
     rm.fine_cache = False                                          # no workspace offered -> every merged sample is evaluated
     assert rm.variant(64, 16, perturb=True).endswith(", 0>")
     assert rm.variant(64, 0, perturb=True).endswith(", 0>")        # no fine pass, nothing to cache
