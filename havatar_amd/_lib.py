@@ -23,6 +23,12 @@ class HavRenderParams(C.Structure):
                 ("rng_counter", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64)]
 
 
+class HavFieldParams(C.Structure):
+    _fields_ = [("n", C.c_int64), ("n_per_b", C.c_int64), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
+                ("D", C.c_int32), ("nerf_scale", C.c_float * 3), ("nerf_trans", C.c_float * 3),
+                ("skin_scale", C.c_float * 3), ("skin_trans", C.c_float * 3)]
+
+
 class HavMlpWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("W1", "b1", "W2", "b2", "Wa", "ba", "Wf", "bf", "Wc", "bc")]
 
@@ -68,6 +74,14 @@ def lib():
     L.hav_triplane_gather_fwd.restype = i32
     L.hav_triplane_gather_bwd.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, vp]
     L.hav_triplane_gather_bwd.restype = i32
+    L.hav_field_inputs_fwd.argtypes = [vp, C.POINTER(HavFieldParams), vp, vp, vp, vp, vp]
+    L.hav_field_inputs_fwd.restype = i32
+    L.hav_field_inputs_bwd.argtypes = [vp, vp, vp, C.POINTER(HavFieldParams), vp, vp, vp, vp, vp]
+    L.hav_field_inputs_bwd.restype = i32
+    L.hav_composite_fwd.argtypes = [vp] * 9 + [i64, i32, i32, i32, vp]
+    L.hav_composite_fwd.restype = i32
+    L.hav_composite_bwd.argtypes = [vp] * 10 + [i64, i32, i32, i32, vp]
+    L.hav_composite_bwd.restype = i32
     L.hav_mlp_blob_bytes.restype = i64
     L.hav_mlp_pack.argtypes = [vp, C.POINTER(HavMlpWeights), vp]
     L.hav_mlp_pack.restype = i32

@@ -1,0 +1,332 @@
+// hav_train.hip -- the training-path statement of the march as two kernel pairs with gradients.
+//
+// The inference kernel (hav_render.hip) fuses the whole of predict_and_render_radiance; under autograd the radiance MLP stays on
+// rocBLAS (its weight gradients are K = 0.9 M GEMMs) and what surrounds it is fused here:
+//   field inputs  = Deformation_Field_new.forward (model/Skinning_Field.py:70-98) -> UniformBoxWarp_new (utils/util.py:232-236)
+//                   -> sample_from_triplane_new (:359-406) + Embedder.embed (model/network/embedder.py:32-61) -> cat (nerf_model.py:104)
+//                   : pts [n,3] -> X [n, 2C+48];   gradients to the planes (channels-last) and to the skinning volume
+//   compositing   = volume_render_radiance_field + cumprod_exclusive (utils/nerf_util.py:4-73)
+//                   : rf [rays,S,CH+1] -> rgb/acc/weights/depth;   gradient to rf
+// Both are one wave per unit (query / ray) with lanes along channels or samples, so every plane row and every radiance-field row
+// is read and written coalesced; scatters are float atomics on rows (planes) or on single taps (volume).
+#include "hav_common.h"
+
+#define PE_FREQS 8
+#define PE_DIM (6 * PE_FREQS)
+
+__device__ __forceinline__ float wsum64(float v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+struct FieldArgs {
+    float* X;
+    const float* dX;
+    float* dplanes;
+    float* dvol;
+    const float* pts;
+    const float* invT;
+    const float* vol;
+    const float* planes;
+    float ss[3], st[3], bs[3], bt[3];
+    int64_t n, n_per_b;
+    int B, H, W, C, D;
+};
+
+// bilinear taps of F.grid_sample(align_corners=True, padding_mode='zeros'); weights of out-of-range taps are zeroed
+__device__ __forceinline__ void plane_taps(float u, float v, int H, int W, int (&idx)[4], float (&w)[4], float& wx0, float& wx1,
+                                           float& wy0, float& wy1, bool (&valid)[4])
+{
+    const float ix = ((u + 1.0f) * 0.5f) * (float)(W - 1), iy = ((v + 1.0f) * 0.5f) * (float)(H - 1);
+    float x0f = floorf(ix), y0f = floorf(iy);
+    wx1 = ix - x0f; wx0 = 1.0f - wx1; wy1 = iy - y0f; wy0 = 1.0f - wy1;
+    x0f = fminf(fmaxf(x0f, -2.f), (float)W + 1.f); y0f = fminf(fmaxf(y0f, -2.f), (float)H + 1.f);
+    const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+    const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W, vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+    const int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x1, 0), W - 1), cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y1, 0), H - 1);
+    idx[0] = cy0 * W + cx0; idx[1] = cy0 * W + cx1; idx[2] = cy1 * W + cx0; idx[3] = cy1 * W + cx1;
+    valid[0] = vx0 && vy0; valid[1] = vx1 && vy0; valid[2] = vx0 && vy1; valid[3] = vx1 && vy1;
+    w[0] = valid[0] ? wx0 * wy0 : 0.f; w[1] = valid[1] ? wx1 * wy0 : 0.f; w[2] = valid[2] ? wx0 * wy1 : 0.f; w[3] = valid[3] ? wx1 * wy1 : 0.f;
+}
+
+// MODE 0: X out.  MODE 1: dplanes / dvol scatter from dX.
+template <int MODE>
+__global__ void __launch_bounds__(256) field_inputs_kernel(FieldArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int C = a.C, H = a.H, W = a.W, D = a.D, XW = 2 * C + PE_DIM;
+    const size_t plane_sz = (size_t)a.B * H * W * C, vol_sz = (size_t)D * D * D;
+    for (int64_t i = wave0; i < a.n; i += nwaves) {
+        const int b = (int)(i / a.n_per_b);
+        const float px = a.pts[i * 3 + 0], py = a.pts[i * 3 + 1], pz = a.pts[i * 3 + 2];
+        // ---- Deformation_Field_new: p_0 = p (identity), p_1 = (p + tau) M       (Skinning_Field.py:77-83)
+        const float* T = a.invT + (size_t)b * 12;
+        const float tx = px + T[9], ty = py + T[10], tz = pz + T[11];
+        const float p1x = tx * T[0] + ty * T[3] + tz * T[6], p1y = tx * T[1] + ty * T[4] + tz * T[7], p1z = tx * T[2] + ty * T[5] + tz * T[8];
+        // skinning weights: lanes 0-7 hold the 8 taps of bone 0 at boxwarp(p_0), lanes 8-15 those of bone 1 at boxwarp(p_1)
+        // (grid_sample 3-D, align_corners=True, padding_mode='border', :85)
+        const int bone = (lane >> 3) & 1, tap = lane & 7;
+        const float sx = bone ? p1x : px, sy = bone ? p1y : py, sz = bone ? p1z : pz;
+        float gx = ((sx * a.ss[0] + a.st[0]) + 1.f) * 0.5f * (float)(D - 1), gy = ((sy * a.ss[1] + a.st[1]) + 1.f) * 0.5f * (float)(D - 1),
+              gz = ((sz * a.ss[2] + a.st[2]) + 1.f) * 0.5f * (float)(D - 1);
+        gx = fminf(fmaxf(gx, 0.f), (float)(D - 1)); gy = fminf(fmaxf(gy, 0.f), (float)(D - 1)); gz = fminf(fmaxf(gz, 0.f), (float)(D - 1));
+        const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
+        const int vx = (int)fx + (tap & 1), vy = (int)fy + ((tap >> 1) & 1), vz = (int)fz + (tap >> 2);
+        const float wx = (tap & 1) ? gx - fx : 1.f - (gx - fx), wy = (tap & 2) ? gy - fy : 1.f - (gy - fy), wz = (tap & 4) ? gz - fz : 1.f - (gz - fz);
+        const bool vin = lane < 16 && vx < D && vy < D && vz < D;
+        const size_t vidx = (size_t)bone * vol_sz + ((size_t)vz * D + vy) * D + vx;
+        const float tw = vin ? wx * wy * wz : 0.f;
+        float part = vin ? tw * a.vol[vidx] : 0.f;
+        part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 4, 64);
+        const float w0 = __shfl(part, 0, 64), w1 = __shfl(part, 8, 64);
+        const float s = (w0 + w1) + 1e-8f, h0 = w0 / s, h1 = w1 / s;                       // :87
+        const float rx = h0 * px + h1 * p1x, ry = h0 * py + h1 * p1y, rz = h0 * pz + h1 * p1z;   // :90,95
+        // ---- UniformBoxWarp_new of the NeRF box, then the two plane look-ups (nerf_model.py:88-99)
+        const float qx = rx * a.bs[0] + a.bt[0], qy = ry * a.bs[1] + a.bt[1], qz = rz * a.bs[2] + a.bt[2];
+        float dqx = 0.f, dqy = 0.f, dqz = 0.f;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            int idx[4]; float w[4]; bool valid[4]; float wx0, wx1, wy0, wy1;
+            plane_taps(p ? qz : qx, qy, H, W, idx, w, wx0, wx1, wy0, wy1, valid);
+            const float* pl = a.planes + p * plane_sz + (size_t)b * H * W * C;
+            for (int c = lane; c < C; c += 64) {
+                float t[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) t[k] = valid[k] ? pl[(size_t)idx[k] * C + c] : 0.f;
+                if (MODE == 0) {
+                    a.X[i * XW + 2 * c + p] = ((t[0] * w[0] + t[1] * w[1]) + t[2] * w[2]) + t[3] * w[3];
+                } else {
+                    const float g = a.dX[i * XW + 2 * c + p];
+                    if (a.dplanes) {
+                        float* dpl = a.dplanes + p * plane_sz + (size_t)b * H * W * C;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (valid[k]) atomicAdd(dpl + (size_t)idx[k] * C + c, w[k] * g);
+                    }
+                    const float ggx = g * ((t[1] - t[0]) * wy0 + (t[3] - t[2]) * wy1);
+                    const float ggy = g * ((t[2] - t[0]) * wx0 + (t[3] - t[1]) * wx1);
+                    if (p == 0) dqx += ggx; else dqz += ggx;
+                    dqy += ggy;
+                }
+            }
+        }
+        // ---- Embedder.embed: [f][sin(x f), sin(y f), sin(z f), sin(x f + pi/2), ...], f = 2^0..2^7 (embedder.py:42-56)
+        const int f = lane / 6, r6 = lane - 6 * f, j = r6 >= 3 ? r6 - 3 : r6;
+        const float freq = (float)(1 << (f & 7));
+        const float coord = j == 0 ? rx : (j == 1 ? ry : rz);
+        const float arg = r6 >= 3 ? coord * freq + 1.57079632679489661923f : coord * freq;
+        if (MODE == 0) {
+            if (lane < PE_DIM) a.X[i * XW + 2 * C + lane] = sinf(arg);
+        } else if (a.dvol) {
+            // d loss / d p' : plane coordinates (through the box warp) + the encoding
+            float dx = dqx * (0.5f * (float)(W - 1)) * a.bs[0], dy = dqy * (0.5f * (float)(H - 1)) * a.bs[1], dz = dqz * (0.5f * (float)(W - 1)) * a.bs[2];
+            if (lane < PE_DIM) {
+                const float ge = a.dX[i * XW + 2 * C + lane] * freq * cosf(arg);
+                if (j == 0) dx += ge; else if (j == 1) dy += ge; else dz += ge;
+            }
+            dx = wsum64(dx); dy = wsum64(dy); dz = wsum64(dz);
+            // p' = h0 p0 + h1 p1, h_i = w_i / s: d/dw_i = (d/dh_i - sum_j d/dh_j h_j) / s
+            const float dh0 = dx * px + dy * py + dz * pz, dh1 = dx * p1x + dy * p1y + dz * p1z;
+            const float mix = dh0 * h0 + dh1 * h1;
+            const float dw = ((bone ? dh1 : dh0) - mix) / s;
+            if (vin) atomicAdd(a.dvol + vidx, tw * dw);
+        }
+    }
+}
+
+static int field_check(const HavFieldParams* p, const void* pts, const void* invT, const void* vol, const void* planes)
+{
+    if (!p || !pts || !invT || !vol || !planes) return HAV_EINVAL;
+    if (p->n < 0 || p->n_per_b < 1 || p->B < 1 || p->H < 2 || p->W < 2 || p->C < 1 || p->D < 2) return HAV_EINVAL;
+    if (p->n > p->n_per_b * p->B) return HAV_EINVAL;
+    return 0;
+}
+
+static FieldArgs field_args(const HavFieldParams* p, const float* pts, const float* invT, const float* vol, const float* planes)
+{
+    FieldArgs a{};
+    a.pts = pts; a.invT = invT; a.vol = vol; a.planes = planes;
+    for (int k = 0; k < 3; ++k) { a.ss[k] = p->skin_scale[k]; a.st[k] = p->skin_trans[k]; a.bs[k] = p->nerf_scale[k]; a.bt[k] = p->nerf_trans[k]; }
+    a.n = p->n; a.n_per_b = p->n_per_b; a.B = p->B; a.H = p->H; a.W = p->W; a.C = p->C; a.D = p->D;
+    return a;
+}
+
+static unsigned field_blocks(int64_t n)
+{
+    int64_t blocks = (n + 3) / 4;
+    const int64_t cap = (int64_t)hav_num_cus() * 32;
+    return (unsigned)(blocks > cap ? cap : blocks);
+}
+
+extern "C" int hav_field_inputs_fwd(float* X, const HavFieldParams* p, const float* pts, const float* inv_T, const float* vol,
+                                    const float* planes_cl, void* stream)
+{
+    int rc = field_check(p, pts, inv_T, vol, planes_cl);
+    if (rc || !X) return rc ? rc : HAV_EINVAL;
+    if (p->n == 0) return 0;
+    FieldArgs a = field_args(p, pts, inv_T, vol, planes_cl);
+    a.X = X;
+    hipLaunchKernelGGL(field_inputs_kernel<0>, dim3(field_blocks(p->n)), dim3(256), 0, (hipStream_t)stream, a);
+    HAV_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int hav_field_inputs_bwd(float* dplanes_cl, float* dvol, const float* dX, const HavFieldParams* p, const float* pts,
+                                    const float* inv_T, const float* vol, const float* planes_cl, void* stream)
+{
+    int rc = field_check(p, pts, inv_T, vol, planes_cl);
+    if (rc || !dX || (!dplanes_cl && !dvol)) return rc ? rc : HAV_EINVAL;
+    if (p->n == 0) return 0;
+    FieldArgs a = field_args(p, pts, inv_T, vol, planes_cl);
+    a.dX = dX; a.dplanes = dplanes_cl; a.dvol = dvol;
+    hipLaunchKernelGGL(field_inputs_kernel<1>, dim3(field_blocks(p->n)), dim3(256), 0, (hipStream_t)stream, a);
+    HAV_LAUNCH_CHECK();
+    return 0;
+}
+
+// ================================================================================================
+// Compositing: volume_render_radiance_field(act_feat=False) with gradients (utils/nerf_util.py:28-73)
+// ================================================================================================
+struct CompArgs {
+    float* rgb; float* acc; float* weights; float* depth;                  // fwd out
+    float* d_rf;                                                          // bwd out
+    const float* d_rgb; const float* d_acc; const float* d_w; const float* d_depth;
+    const float* rf; const float* z; const float* rd; const float* noise; const float* bg;
+    int64_t n_rays;
+    int S, CH, nsig;
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <int MODE>
+__global__ void __launch_bounds__(256) composite_kernel(CompArgs a)
+{
+    __shared__ float sw_[4][64], sd_[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* sw = sw_[wv]; float* sd = sd_[wv];
+    const int S = a.S, CH = a.CH, RW = a.CH + 1;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = wave0; r < a.n_rays; r += nwaves) {
+        const float* rf = a.rf + (size_t)r * S * RW;
+        // ---- lane = sample: alpha, transmittance, weight (:36-60)
+        const bool on = lane < S;
+        const int li = on ? lane : S - 1;
+        const float zi = a.z[r * S + li];
+        const int i0 = li < S - 1 ? li : S - 2;
+        const float dz = S > 1 ? a.z[r * S + i0 + 1] - a.z[r * S + i0] : 0.f;       // the last distance is repeated (:37)
+        const float dx = a.rd[r * 3], dy = a.rd[r * 3 + 1], dzz = a.rd[r * 3 + 2];
+        const float dist = dz * sqrtf(dx * dx + dy * dy + dzz * dzz);
+        const float raw = rf[(size_t)li * RW + CH] + (a.noise ? a.noise[r * S + li] : 0.f);
+        const float sigma = fmaxf(raw, 0.f);
+        const float alpha = 1.0f - expf(-sigma * dist);
+        const float tt = on ? (1.0f - alpha) + 1e-10f : 1.0f;
+        float incl = tt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const float u = __shfl_up(incl, o, 64);
+            if (lane >= o) incl *= u;
+        }
+        float excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.0f;
+        const float w = on ? alpha * excl : 0.f;
+        const float acc = wsum64(w);
+        __builtin_amdgcn_wave_barrier();      // sw/sd are private to the wave: LDS executes a wave's accesses in order
+        sw[lane] = w;
+        if (MODE == 0) {
+            const float depth = wsum64(w * zi);
+            if (on) a.weights[r * S + lane] = w;
+            if (lane == 0) { a.acc[r] = acc; a.depth[r] = depth; }
+            __builtin_amdgcn_wave_barrier();
+            // ---- lane = channel: rgb_map = sum_i w_i c_i (:62-63), white-background term on the first three (:70-71)
+            for (int c = lane; c < CH; c += 64) {
+                float s = 0.f;
+                for (int i = 0; i < S; ++i) {
+                    const float v = rf[(size_t)i * RW + c];
+                    s += sw[i] * (c < a.nsig ? sigmoidf_(v) : v);
+                }
+                if (a.bg && c < 3) s += (1.0f - acc) * a.bg[r * 3 + c];
+                a.rgb[r * CH + c] = s;
+            }
+        } else {
+            // ---- G_i = d loss / d w_i
+            const float* drgb = a.d_rgb + (size_t)r * CH;
+            float dacc = a.d_acc ? a.d_acc[r] : 0.f;
+            if (a.bg)
+                for (int c = 0; c < 3 && c < CH; ++c) dacc -= drgb[c] * a.bg[r * 3 + c];
+            float G = dacc + (a.d_depth ? a.d_depth[r] * zi : 0.f) + (a.d_w && on ? a.d_w[r * S + li] : 0.f);
+            {
+                const float* row = rf + (size_t)li * RW;
+                float dot = 0.f;
+                for (int c = 0; c < CH; ++c) {
+                    const float v = row[c];
+                    dot += drgb[c] * (c < a.nsig ? sigmoidf_(v) : v);
+                }
+                G += dot;
+            }
+            if (!on) G = 0.f;
+            // suffix sum of G_j w_j over j > i
+            float suf = G * w;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const float u = __shfl_down(suf, o, 64);
+                if (lane + o < 64) suf += u;
+            }
+            suf -= G * w;
+            const float dalpha = G * excl - suf / tt;
+            const float dsig = dalpha * dist * (1.0f - alpha);
+            sd[lane] = (on && raw > 0.f) ? dsig : 0.f;
+            __builtin_amdgcn_wave_barrier();
+            // ---- lane = channel: d c_i = w_i d_rgb (sigmoid' on the first nsig), d raw_i in the last column
+            for (int c = lane; c < RW; c += 64) {
+                const float g = c < CH ? drgb[c] : 0.f;
+                for (int i = 0; i < S; ++i) {
+                    float o;
+                    if (c == CH) o = sd[i];
+                    else if (c < a.nsig) { const float sg = sigmoidf_(rf[(size_t)i * RW + c]); o = sw[i] * g * sg * (1.0f - sg); }
+                    else o = sw[i] * g;
+                    a.d_rf[((size_t)r * S + i) * RW + c] = o;
+                }
+            }
+        }
+    }
+}
+
+static unsigned comp_blocks(int64_t n_rays)
+{
+    int64_t blocks = (n_rays + 3) / 4;
+    const int64_t cap = (int64_t)hav_num_cus() * 16;
+    return (unsigned)(blocks > cap ? cap : blocks);
+}
+
+extern "C" int hav_composite_fwd(float* rgb, float* acc, float* weights, float* depth, const float* rf, const float* z, const float* rd,
+                                 const float* noise, const float* bg, int64_t n_rays, int S, int CH, int n_sigmoid, void* stream)
+{
+    if (!rgb || !acc || !weights || !depth || !rf || !z || !rd || n_rays < 0 || S < 1 || CH < 1 || n_sigmoid < 0) return HAV_EINVAL;
+    if (S > 64) return HAV_EUNSUP;
+    if (n_rays == 0) return 0;
+    CompArgs a{};
+    a.rgb = rgb; a.acc = acc; a.weights = weights; a.depth = depth; a.rf = rf; a.z = z; a.rd = rd; a.noise = noise; a.bg = bg;
+    a.n_rays = n_rays; a.S = S; a.CH = CH; a.nsig = n_sigmoid;
+    hipLaunchKernelGGL(composite_kernel<0>, dim3(comp_blocks(n_rays)), dim3(256), 0, (hipStream_t)stream, a);
+    HAV_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int hav_composite_bwd(float* d_rf, const float* d_rgb, const float* d_acc, const float* d_weights, const float* d_depth,
+                                 const float* rf, const float* z, const float* rd, const float* noise, const float* bg, int64_t n_rays,
+                                 int S, int CH, int n_sigmoid, void* stream)
+{
+    if (!d_rf || !d_rgb || !rf || !z || !rd || n_rays < 0 || S < 1 || CH < 1 || n_sigmoid < 0) return HAV_EINVAL;
+    if (S > 64) return HAV_EUNSUP;
+    if (n_rays == 0) return 0;
+    CompArgs a{};
+    a.d_rf = d_rf; a.d_rgb = d_rgb; a.d_acc = d_acc; a.d_w = d_weights; a.d_depth = d_depth;
+    a.rf = rf; a.z = z; a.rd = rd; a.noise = noise; a.bg = bg;
+    a.n_rays = n_rays; a.S = S; a.CH = CH; a.nsig = n_sigmoid;
+    hipLaunchKernelGGL(composite_kernel<1>, dim3(comp_blocks(n_rays)), dim3(256), 0, (hipStream_t)stream, a);
+    HAV_LAUNCH_CHECK();
+    return 0;
+}

@@ -7,6 +7,18 @@ on the stream (HavRenderParams.rng_counter), so every replay draws fresh stratif
 """
 import torch
 
+_WEIGHTS_EPOCH = [0]
+
+
+def weights_epoch():
+    """Counter folded into every weight-derived cache key (packed MLP blob, weight-only encoder caches): parameters updated by
+    a replayed graph do not bump `Tensor._version`, so GraphedTrainStep bumps this instead."""
+    return _WEIGHTS_EPOCH[0]
+
+
+def bump_weights_epoch():
+    _WEIGHTS_EPOCH[0] += 1
+
 
 class GraphedForward:
     """Capture `module(**kwargs)` (tensors in `kwargs` are the per-frame inputs) and replay it with new inputs.
@@ -35,3 +47,33 @@ class GraphedForward:
                 raise RuntimeError(f"GraphedForward: non-tensor argument {k!r} changed since capture")
         self.graph.replay()
         return self.out
+
+
+class GraphedTrainStep:
+    """One optimisation step -- forward, backward, optimiser update -- as ONE hipGraph launch.
+
+    cfg5's step is ~3 800 kernel launches for ~55 ms of kernel time: eagerly the host (Python autograd + launch overhead) is the
+    bottleneck at ~80 ms per step.  `step_fn(**tensors) -> (loss, aux)` must be capture-safe (no .item(), no host tensors: the
+    Trainer draws sample_pdf's stratified u on the device while capturing) and the optimiser must be `capturable`.  Run at least
+    one eager step first (solver selection, lazy state); capturing itself executes nothing, so no step is spent on it."""
+
+    def __init__(self, step_fn, optimizer, example):
+        self.static = {k: v.clone() for k, v in example.items()}
+        self.optimizer = optimizer
+        optimizer.zero_grad(set_to_none=True)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            self.loss, self.aux = step_fn(**self.static)
+            self.loss.backward()
+            optimizer.step()
+
+    def matches(self, tensors):
+        return tensors.keys() == self.static.keys() and all(tensors[k].shape == v.shape and tensors[k].dtype == v.dtype
+                                                            for k, v in self.static.items())
+
+    def __call__(self, **tensors):
+        for k, v in tensors.items():
+            self.static[k].copy_(v, non_blocking=True)
+        self.graph.replay()
+        bump_weights_epoch()
+        return self.loss, self.aux

@@ -74,8 +74,93 @@ def training_loss(trainer, cfg, inp, target, ray_mask, rgb_loss_func, percep_los
     loss = loss + latent_code_loss + sw_grad_loss * 1e-4
     parts.update(code_loss=latent_code_loss, sw_grad_loss=sw_grad_loss)
     best = rgb_coarse if rgb_fine is None else rgb_fine
-    psnr = mse2psnr(F.mse_loss(best[..., :3], target[..., :3]).item())
-    return loss, parts, psnr
+    mse = F.mse_loss(best[..., :3], target[..., :3]).detach()
+    if mse.is_cuda and torch.cuda.is_current_stream_capturing():
+        return loss, parts, mse                       # a captured step cannot read it back: the caller converts after the replay
+    return loss, parts, mse2psnr(mse.item())
+
+
+def graph_training_enabled(device, percep_loss_fn=None):
+    """The step runs as one hipGraph launch (graph.GraphedTrainStep) on HIP devices unless HAVATAR_TRAIN_GRAPH=0."""
+    return (torch.device(device).type == "cuda" and percep_loss_fn is None and os.environ.get("HAVATAR_TRAIN_GRAPH", "1") != "0"
+            and os.environ.get("HAVATAR_HIP_TRAIN", "1") != "0")       # the ATen statement of the march reads host tensors
+
+
+def make_optimizer(cfg, trainer, graph):
+    kw = {}
+    if graph and cfg.optimizer.type in ("Adam", "AdamW", "NAdam", "RAdam", "Adamax", "Adagrad", "RMSprop", "SGD", "ASGD", "Adadelta", "Rprop"):
+        # capturable: the step counter and the learning rate live on the device, so the optimiser update can be replayed
+        kw = {"capturable": True} if cfg.optimizer.type != "SGD" else {}
+    return getattr(torch.optim, cfg.optimizer.type)([{"params": list(trainer.parameters())}], lr=cfg.optimizer.lr, **kw)
+
+
+def set_learning_rate(optimizer, lr_new):
+    for g in optimizer.param_groups:
+        if torch.is_tensor(g["lr"]):
+            g["lr"].fill_(lr_new)                     # device-resident rate of a capturable optimiser: the graph reads it
+        else:
+            g["lr"] = lr_new
+
+
+class StepRunner:
+    """forward + backward + optimiser update of one batch; eager for the first `eager_steps` calls (solver selection, lazy
+    optimiser state) and for odd batch shapes, one hipGraph replay otherwise."""
+
+    def __init__(self, trainer, cfg, optimizer, rgb_loss_func, percep_loss_fn=None, graph=False, eager_steps=2):
+        self.trainer, self.cfg, self.optimizer, self.rgb_loss_func, self.percep = trainer, cfg, optimizer, rgb_loss_func, percep_loss_fn
+        self.graph, self.eager_left, self.graphed, self.side = graph, eager_steps, None, None
+        if graph:
+            dev = next(trainer.parameters()).device
+            for g in optimizer.param_groups:          # capturable Adam reads a tensor learning rate inside the graph
+                if not torch.is_tensor(g["lr"]):
+                    g["lr"] = torch.tensor(float(g["lr"]), device=dev)
+                if "capturable" in g:
+                    g["capturable"] = True            # a checkpoint written by an eager run (or by the reference) restores False
+            for st in optimizer.state.values():
+                if torch.is_tensor(st.get("step")) and st["step"].device != dev:
+                    st["step"] = st["step"].to(dev)
+
+    def _loss(self, target, ray_mask, **inp):
+        t = self.trainer
+        full = dict(inp, mode="train", render_full_img=False)
+        loss, parts, mse = training_loss(t, self.cfg, full, target, ray_mask, self.rgb_loss_func, self.percep)
+        return loss, dict(parts, _mse=mse)
+
+    def __call__(self, inp, target, ray_mask):
+        """-> (loss, parts, psnr); gradients are consumed (optimizer.step + zero_grad) inside."""
+        dev = target.device
+        tens = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items() if torch.is_tensor(v)}
+        if self.graph and self.eager_left <= 0 and (self.graphed is None or self.graphed.matches(dict(tens, target=target, ray_mask=ray_mask))):
+            from ..graph import GraphedTrainStep
+            if self.graphed is None:
+                self.graphed = GraphedTrainStep(lambda target, ray_mask, **kw: self._loss(target, ray_mask, **kw), self.optimizer,
+                                                dict(tens, target=target, ray_mask=ray_mask))
+            loss, aux = self.graphed(**tens, target=target, ray_mask=ray_mask)
+            parts = {k: v for k, v in aux.items() if k != "_mse"}
+            return loss, parts, mse2psnr(aux["_mse"].item())
+        self.eager_left -= 1
+        if not self.graph:
+            loss, parts, psnr = training_loss(self.trainer, self.cfg, inp, target, ray_mask, self.rgb_loss_func, self.percep)
+            loss.backward()
+            self.optimizer.step()
+            self.optimizer.zero_grad()
+            return loss, parts, psnr
+        # the eager steps that precede a capture run on a side stream, as the capture itself will: gradient buffers and optimiser
+        # state created on the default stream make the captured backward crash (AccumulateGrad stream mismatch)
+        from ..graph import bump_weights_epoch
+        cur = torch.cuda.current_stream(dev)
+        if self.side is None:
+            self.side = torch.cuda.Stream(device=dev)
+        self.side.wait_stream(cur)
+        with torch.cuda.stream(self.side):
+            self.optimizer.zero_grad(set_to_none=True)
+            loss, parts, psnr = training_loss(self.trainer, self.cfg, inp, target, ray_mask, self.rgb_loss_func, self.percep)
+            loss.backward()
+            self.optimizer.step()
+            self.optimizer.zero_grad(set_to_none=True)
+        cur.wait_stream(self.side)
+        bump_weights_epoch()
+        return loss, parts, psnr
 
 
 def learning_rate(cfg, i):
@@ -153,7 +238,8 @@ def main(argv=None, device=None):
                         options=cfg, white_bg=True)
     val_data = enumerate(val_loader)
     trainer = Trainer(cfg, len(train_loader.dataset)).to(device)
-    optimizer = getattr(torch.optim, cfg.optimizer.type)([{"params": list(trainer.parameters())}], lr=cfg.optimizer.lr)
+    use_graph = graph_training_enabled(device, percep_loss_fn)
+    optimizer = make_optimizer(cfg, trainer, use_graph)
     os.makedirs(args.logdir, exist_ok=True)
     try:
         from torch.utils.tensorboard import SummaryWriter
@@ -173,19 +259,16 @@ def main(argv=None, device=None):
         trainer.headpose_skin_net.pretrain_wc(num_iter=int(os.environ.get("HAVATAR_PRETRAIN_WC", 3000)), vol_thr=cfg.models.coarse.Head_bounding)
     i, steps_done = start_iter, 0
     loss, psnr = None, None
+    run_step = StepRunner(trainer, cfg, optimizer, rgb_loss_func, percep_loss_fn, graph=use_graph)
     while i < cfg.experiment.train_iters:
         trainer.train()
         t0 = time.time()
         for idx, batch in train_loader:
             i += 1
             inp, target, ray_mask = step_inputs(idx, batch, device)
-            loss, parts, psnr = training_loss(trainer, cfg, inp, target, ray_mask, rgb_loss_func, percep_loss_fn)
-            loss.backward()
-            optimizer.step()
-            optimizer.zero_grad()
+            loss, parts, psnr = run_step(inp, target, ray_mask)
             lr_new = learning_rate(cfg, i)
-            for g in optimizer.param_groups:
-                g["lr"] = lr_new
+            set_learning_rate(optimizer, lr_new)
             if i % cfg.experiment.print_every == 0 or i == cfg.experiment.train_iters - 1:
                 print("[TRAIN] Iter: %d Loss: %.06f PSNR: %.06f LatentReg: %.04f e-5 LR: %.02f e-5 TIME: %.02f" % (
                     i, loss.item(), psnr, 1e5 * parts["code_loss"].item(), 1e5 * lr_new, (time.time() - t0) / cfg.experiment.print_every))
@@ -208,7 +291,7 @@ def main(argv=None, device=None):
                 print("Validation loss: %06f Validation PSNR: %06f" % (vloss, vpsnr))
                 trainer.train()
             if i % cfg.experiment.save_every == 0 or i == cfg.experiment.train_iters - 1 or i == start_iter + 1:
-                torch.save({"iter": i, "optimizer_state_dict": optimizer.state_dict(), "loss": loss, "psnr": psnr,
+                torch.save({"iter": i, "optimizer_state_dict": optimizer.state_dict(), "loss": loss.detach().clone(), "psnr": psnr,
                             "trainer_state_dict": trainer.state_dict()}, os.path.join(args.logdir, "checkpoint" + str(i).zfill(5) + ".ckpt"))
                 trainer.headpose_skin_net.visualize_motion_weight_vol(os.path.join(args.logdir, "vis_motionWeightVol" + str(i).zfill(5) + ".obj"))
                 print("================== Saved Checkpoint =================")

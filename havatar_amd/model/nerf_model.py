@@ -125,7 +125,10 @@ class ConditionalTriplaneNeRFModel_multiRender_split_view(nn.Module):
     def forward(self, inp, pts_feat):
         """inp [n,3(+3)], pts_feat [n,2C] -> [n, rgb(3) | feat(64) | alpha(1)] (:101-117)."""
         xyz, dirs = inp[..., :3], inp[..., 3:]
-        x = torch.cat([pts_feat, self.pos_embedder(xyz)], -1)
+        return self.mlp(torch.cat([pts_feat, self.pos_embedder(xyz)], -1), dirs)
+
+    def mlp(self, x, dirs=None):
+        """x [n, 2C+48] = cat(features, encoding) -> [n, rgb(3) | feat(64) | alpha(1)]: the layers of forward() (:106-117)."""
         for layer in self.layers_xyz:
             x = self.relu(_linear(layer, x))
         alpha = _linear(self.fc_alpha, x)

@@ -5,6 +5,8 @@ Difference: `predict_and_render_radiance` on HIP tensors without autograd is ONE
 rays it is given (ray sampling, skinning lookup, tri-plane gather, PE, MLP, compositing, resampling, second pass), and
 `nerf_forward` therefore does not chunk (the reference's chunksize loop only bounds activation memory, :66-71).  CPU
 tensors and autograd-tracked calls take the PyTorch statement of the same algorithm (the reference runs there too)."""
+import os
+
 import numpy as np
 import torch
 from einops import rearrange
@@ -132,7 +134,32 @@ class Trainer(torch.nn.Module):
             z = lower + (upper - lower) * torch.rand(z.shape, dtype=ro.dtype, device=ro.device)
         bg = background_prior.reshape(-1, background_prior.shape[-1]) if background_prior is not None else None
 
+        # HIP tensors under autograd: the field inputs (skinning + box warp + plane gather + encoding) and the compositing are
+        # one kernel each way (hav_field_inputs_*, hav_composite_*); the MLP between them stays on rocBLAS.  No fallback: with
+        # HAVATAR_HIP_TRAIN unset or 1 a missing library raises.
+        fused = (ro.is_cuda and ro.dtype == torch.float32 and max(opt.num_coarse, opt.num_coarse // 2 + opt.num_coarse % 2 + opt.num_fine) <= 64
+                 and self.model_coarse.sh_deg == 0 and os.environ.get("HAVATAR_HIP_TRAIN", "1") != "0")
+        if fused:
+            from ..native.train_ops import composite, field_inputs
+            gw, sw = self.model_coarse.gridwarper, self.headpose_skin_net.gridwarper
+            if getattr(self, "_boxes", None) is None:
+                f = lambda t: t.detach().reshape(3).cpu().tolist()
+                self._boxes = ((f(gw.scale_factor), f(gw.trans_factor)), (f(sw.scale_factor), f(sw.trans_factor)))
+            vol = self.headpose_skin_net.current_volume()             # once per call: the reference re-evaluates the same
+            planes = self.model_coarse.triPlane_embeddings             # VolumeDecoder (no RNG, same weights) for every pass
+
+        def one_pass_hip(zv):
+            pts = (ro[..., None, :] + rd[..., None, :] * zv[..., :, None]).reshape(B, -1, 3)
+            X = field_inputs(pts, inv_head_T, vol, planes, *self._boxes)
+            rf = self.model_coarse.mlp(X).reshape(B * R, zv.shape[-1], -1)
+            std = float(opt.radiance_field_noise_std)
+            noise = torch.randn(rf.shape[:-1], dtype=rf.dtype, device=rf.device) * std if std > 0.0 else None     # same draw as :56
+            rgb, acc, w, depth = composite(rf, zv.reshape(-1, zv.shape[-1]), rd.reshape(-1, 3), noise, bg, n_sigmoid=3)
+            return rgb, None, acc, w, depth
+
         def one_pass(zv):
+            if fused:
+                return one_pass_hip(zv)
             pts = ro[..., None, :] + rd[..., None, :] * zv[..., :, None]
             flat = pts.reshape(B, -1, 3)
             vd = ray_batch[..., -3:].unsqueeze(2).expand(pts.shape).reshape(B, -1, 3)

@@ -21,7 +21,9 @@ class Embedder:
     def embed(self, x, alpha=None):
         if self.N_freqs == 0:
             return x
-        fb = self.freq_bands.to(x.device)
+        if self.freq_bands.device != x.device:                                # once per device (a copy per call would also break
+            self.freq_bands = self.freq_bands.to(x.device)                    # hipGraph capture of the training step)
+        fb = self.freq_bands
         ang = x.unsqueeze(-2) * fb                                            # [..., F, C]
         feat = torch.sin(torch.stack((ang, ang + math.pi / 2), dim=-2))       # [..., F, 2, C]
         if alpha is not None:                                                 # coarse-to-fine window (unused on the path)

@@ -17,6 +17,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from .op import FusedLeakyReLU, conv2d_gradfix, fused_leaky_relu, upfirdn2d
+from ..graph import weights_epoch
 
 _CHANNELS = lambda cm: {4: 512, 8: 512, 16: 512, 32: 512, 64: 256 * cm, 128: 128 * cm, 256: 64 * cm, 512: 32 * cm, 1024: 16 * cm}
 
@@ -29,7 +30,7 @@ class _InferenceCache:
     def _cached(self, name, param, fn):
         if torch.is_grad_enabled() and param.requires_grad:
             return fn()
-        key = (param.data_ptr(), param._version, param.device)
+        key = (param.data_ptr(), param._version, param.device, weights_epoch())
         c = self.__dict__.get("_icache")
         if c is None:
             c = self.__dict__["_icache"] = {}

@@ -1,0 +1,115 @@
+"""Training-path field ops (hav_field_inputs_*, hav_composite_*): the HIP counterparts, under autograd, of what surrounds the
+radiance MLP in predict_and_render_radiance -- skinning field + box warp + tri-plane gather + positional encoding on one side,
+volume_render_radiance_field on the other.  HIP float32 tensors only; there is no fallback in here."""
+import ctypes as C
+
+import torch
+from torch.autograd import Function
+
+from .. import _lib
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_hip(name, *ts):
+    for t in ts:
+        if t is not None and not (t.is_cuda and t.dtype == torch.float32):
+            raise RuntimeError(name + ": HIP float32 tensors only")
+
+
+def _field_params(pts, planes_cl, vol, boxes):
+    P, B, H, W, Cc = planes_cl.shape
+    if P != 2 or pts.ndim != 3 or pts.shape[0] != B or pts.shape[-1] != 3:
+        raise RuntimeError("field_inputs: planes [2,B,H,W,C], pts [B,N,3]")
+    if vol.ndim != 5 or vol.shape[0] != 1 or vol.shape[1] != 2 or not (vol.shape[2] == vol.shape[3] == vol.shape[4]):
+        raise RuntimeError("field_inputs: skinning volume [1,2,D,D,D]")
+    p = _lib.HavFieldParams()
+    p.n, p.n_per_b, p.B, p.H, p.W, p.C, p.D = B * pts.shape[1], pts.shape[1], B, H, W, Cc, vol.shape[2]
+    for name, v in zip(("nerf_scale", "nerf_trans", "skin_scale", "skin_trans"), boxes):
+        setattr(p, name, (C.c_float * 3)(*[float(x) for x in v]))
+    return p
+
+
+class FieldInputs(Function):
+    """X [B*N, 2C+48] = cat(triplane(boxwarp(p')), PE(p')),  p' = skinning_field(pts, inv_T, vol).  Gradients: planes_cl, vol."""
+
+    @staticmethod
+    def forward(ctx, pts, inv_T, vol, planes_cl, boxes):
+        _need_hip("FieldInputs", pts, inv_T, vol, planes_cl)
+        pts, inv_T, vol, planes_cl = pts.contiguous(), inv_T.contiguous(), vol.contiguous(), planes_cl.contiguous()
+        p = _field_params(pts, planes_cl, vol, boxes)
+        X = torch.empty(p.n, 2 * p.C + 48, device=pts.device, dtype=torch.float32)
+        with torch.cuda.device(pts.device):
+            rc = _lib.lib().hav_field_inputs_fwd(_p(X), C.byref(p), _p(pts), _p(inv_T), _p(vol), _p(planes_cl), _stream())
+        _lib.check(rc, "hav_field_inputs_fwd")
+        ctx.save_for_backward(pts, inv_T, vol, planes_cl)
+        ctx.boxes = boxes
+        return X
+
+    @staticmethod
+    def backward(ctx, dX):
+        pts, inv_T, vol, planes_cl = ctx.saved_tensors
+        p = _field_params(pts, planes_cl, vol, ctx.boxes)
+        dvol = torch.zeros_like(vol) if ctx.needs_input_grad[2] else None
+        dpl = torch.zeros_like(planes_cl) if ctx.needs_input_grad[3] else None
+        if dvol is not None or dpl is not None:
+            dX = dX.contiguous()
+            with torch.cuda.device(pts.device):
+                rc = _lib.lib().hav_field_inputs_bwd(_p(dpl), _p(dvol), _p(dX), C.byref(p), _p(pts), _p(inv_T), _p(vol), _p(planes_cl),
+                                                     _stream())
+            _lib.check(rc, "hav_field_inputs_bwd")
+        return None, None, dvol, dpl, None
+
+
+def field_inputs(pts, inv_T, vol, planes_nchw, nerf_box, skin_box):
+    """pts [B,N,3], inv_T [B,4,3], vol [1,2,D,D,D], planes [2,B,C,H,W] (the Trainer's layout), boxes = (scale3, trans3) of the two
+    UniformBoxWarp_new modules -> X [B*N, 2C+48].  The NCHW -> channels-last permutation is a differentiable ATen op."""
+    boxes = (tuple(nerf_box[0]), tuple(nerf_box[1]), tuple(skin_box[0]), tuple(skin_box[1]))
+    return FieldInputs.apply(pts, inv_T, vol, planes_nchw.permute(0, 1, 3, 4, 2).contiguous(), boxes)
+
+
+class Composite(Function):
+    """(rgb [n,CH], acc [n], weights [n,S], depth [n]) = volume_render_radiance_field(rf [n,S,CH+1], z, rd, noise, bg)."""
+
+    @staticmethod
+    def forward(ctx, rf, z, rd, noise, bg, n_sigmoid):
+        _need_hip("Composite", rf, z, rd, noise, bg)
+        rf, z, rd = rf.contiguous(), z.contiguous(), rd.contiguous()
+        noise = noise.contiguous() if noise is not None else None
+        bg = bg.contiguous() if bg is not None else None
+        n, S, RW = rf.shape
+        if z.shape != (n, S) or rd.shape != (n, 3) or (noise is not None and noise.shape != (n, S)) or (bg is not None and bg.shape != (n, 3)):
+            raise RuntimeError("Composite: rf [n,S,CH+1], z [n,S], rd [n,3], noise [n,S], bg [n,3]")
+        rgb = torch.empty(n, RW - 1, device=rf.device, dtype=torch.float32)
+        acc, depth = torch.empty(n, device=rf.device), torch.empty(n, device=rf.device)
+        w = torch.empty(n, S, device=rf.device)
+        with torch.cuda.device(rf.device):
+            rc = _lib.lib().hav_composite_fwd(_p(rgb), _p(acc), _p(w), _p(depth), _p(rf), _p(z), _p(rd), _p(noise), _p(bg), n, S, RW - 1,
+                                              int(n_sigmoid), _stream())
+        _lib.check(rc, "hav_composite_fwd")
+        ctx.save_for_backward(rf, z, rd, noise, bg)
+        ctx.n_sigmoid = int(n_sigmoid)
+        return rgb, acc, w, depth
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_acc, d_w, d_depth):
+        rf, z, rd, noise, bg = ctx.saved_tensors
+        n, S, RW = rf.shape
+        d_rf = torch.empty_like(rf)
+        d_rgb = d_rgb.contiguous() if d_rgb is not None else torch.zeros(n, RW - 1, device=rf.device)
+        d_acc, d_w, d_depth = [t.contiguous() if t is not None else None for t in (d_acc, d_w, d_depth)]
+        with torch.cuda.device(rf.device):
+            rc = _lib.lib().hav_composite_bwd(_p(d_rf), _p(d_rgb), _p(d_acc), _p(d_w), _p(d_depth), _p(rf), _p(z), _p(rd), _p(noise),
+                                              _p(bg), n, S, RW - 1, ctx.n_sigmoid, _stream())
+        _lib.check(rc, "hav_composite_bwd")
+        return d_rf, None, None, None, None, None
+
+
+def composite(rf, z, rd, noise=None, bg=None, n_sigmoid=3):
+    return Composite.apply(rf, z, rd, noise, bg, n_sigmoid)

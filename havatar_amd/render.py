@@ -11,6 +11,7 @@ import os
 import torch
 
 from . import _lib
+from .graph import weights_epoch
 
 _DEBUG_SYNC = os.environ.get("HAVATAR_DEBUG_SYNC", "0") == "1"
 
@@ -61,7 +62,7 @@ class RayMarcher:
         """Pack nn.Linear-layout weights (model/nerf_model.py:46-51) into the fragment-ordered blob."""
         ts = [_chk_f32_cuda(n, t) for n, t in zip(("W1", "b1", "W2", "b2", "Wa", "ba", "Wf", "bf", "Wc", "bc"),
                                                    (W1, b1, W2, b2, Wa, ba, Wf, bf, Wc, bc))]
-        key = tuple((t.data_ptr(), t._version) for t in ts)
+        key = tuple((t.data_ptr(), t._version) for t in ts) + (weights_epoch(),)
         if not force and key == self._blob_key and self.blob is not None:
             return
         L = _lib.lib()

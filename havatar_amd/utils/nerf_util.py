@@ -48,8 +48,13 @@ def sample_pdf(bins, weights, num_samples, det=False):
     else:
         s = 1 / num_samples
         u = (torch.arange(num_samples) * s).unsqueeze(0)
-        u = u + torch.rand(list(cdf.shape[:-1]) + [num_samples], dtype=weights.dtype) * (s - 1e-6)
-        u = u.to(weights.device)
+        if weights.is_cuda and torch.cuda.is_current_stream_capturing():
+            # a captured training step (graph.GraphedTrainStep): a host draw would be frozen into the graph, so this one draw
+            # comes from the device generator (graph-safe Philox offsets) instead of the CPU generator the reference uses
+            u = (torch.arange(num_samples, device=weights.device) * s).unsqueeze(0) + torch.rand(list(cdf.shape[:-1]) + [num_samples], dtype=weights.dtype, device=weights.device) * (s - 1e-6)
+        else:
+            u = u + torch.rand(list(cdf.shape[:-1]) + [num_samples], dtype=weights.dtype) * (s - 1e-6)
+            u = u.to(weights.device)
     u, cdf = u.contiguous(), cdf.contiguous()
     inds = torch.searchsorted(cdf.detach(), u, right=True)
     below = torch.clamp(inds - 1, min=0)

@@ -98,6 +98,43 @@ int hav_triplane_gather_bwd(float* dplanes_cl, float* dq, const float* dfeat /*[
                             int64_t n, int64_t n_per_b, int B, int H, int W, int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Training-path field ops (autograd statement of the march).  The radiance MLP between them stays on
+ * rocBLAS; these replace what surrounds it, forward and backward, with one launch each.
+ *
+ * hav_field_inputs_*: pts [n,3] -> X [n, 2C+48] = cat(tri-plane features, positional encoding) of the DEFORMED point:
+ *   Deformation_Field_new.forward (model/Skinning_Field.py:70-98: two bones {identity, inv_T}, trilinear border sampling of the
+ *   skinning volume vol [2,D,D,D] at the skin-box-warped p_i, normalised blend) -> UniformBoxWarp_new of the NeRF box
+ *   (utils/util.py:232-236) -> sample_from_triplane_new (:359-406; planes channels-last [2,B,H,W,C], feature 2c+plane) and
+ *   Embedder.embed (model/network/embedder.py:32-61; 8 octaves, cos as sin(x + pi/2)) -> cat (model/nerf_model.py:104).
+ *   Query i belongs to frame i / n_per_b (inv_T [B,4,3]).
+ *   bwd: dplanes_cl += scatter of dX (nullable; caller zero-fills), dvol [2,D,D,D] += d loss / d volume through the blend
+ *   weights (nullable; caller zero-fills).  pts and inv_T are data (no gradient), as in the reference's training step.
+ * hav_composite_*: volume_render_radiance_field(act_feat=False) + cumprod_exclusive (utils/nerf_util.py:4-73):
+ *   rf [n_rays,S,CH+1] (density last; the first n_sigmoid channels pass through a sigmoid, :45-46), z [n_rays,S], rd [n_rays,3],
+ *   noise [n_rays,S] (already scaled by radiance_field_noise_std; nullable), bg [n_rays,3] (nullable) ->
+ *   rgb [n_rays,CH], acc [n_rays], weights [n_rays,S], depth [n_rays].  S <= 64 (HAV_EUNSUP above).
+ *   bwd: d_rf [n_rays,S,CH+1] from d_rgb (required), d_acc / d_weights / d_depth (nullable = zero).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct HavFieldParams {
+    int64_t n;            /* queries                                                            */
+    int64_t n_per_b;      /* queries per frame                                                  */
+    int32_t B, H, W, C;   /* planes [2,B,H,W,C]                                                 */
+    int32_t D;            /* skinning volume resolution                                         */
+    float   nerf_scale[3], nerf_trans[3];
+    float   skin_scale[3], skin_trans[3];
+} HavFieldParams;
+
+int hav_field_inputs_fwd(float* X, const HavFieldParams* p, const float* pts, const float* inv_T, const float* vol,
+                         const float* planes_cl, void* stream);
+int hav_field_inputs_bwd(float* dplanes_cl, float* dvol, const float* dX, const HavFieldParams* p, const float* pts,
+                         const float* inv_T, const float* vol, const float* planes_cl, void* stream);
+int hav_composite_fwd(float* rgb, float* acc, float* weights, float* depth, const float* rf, const float* z, const float* rd,
+                      const float* noise, const float* bg, int64_t n_rays, int S, int CH, int n_sigmoid, void* stream);
+int hav_composite_bwd(float* d_rf, const float* d_rgb, const float* d_acc, const float* d_weights, const float* d_depth,
+                      const float* rf, const float* z, const float* rd, const float* noise, const float* bg, int64_t n_rays,
+                      int S, int CH, int n_sigmoid, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Ray march -- replaces Trainer.predict_and_render_radiance (model/nerf_trainer.py:120-201) and
  * everything it calls: ray sampling (:129-141), Deformation_Field_new.forward
  * (model/Skinning_Field.py:70-98), sample_pts_triplane_feat (model/nerf_model.py:88-99),

@@ -268,3 +268,89 @@ def test_triplane_gather_forward_and_gradients_match_grid_sample():
             e_mine = (mine.double() - r64).abs().max().item() / scale
             e_aten = (r32.double() - r64).abs().max().item() / scale
             assert e_mine <= max(2.0 * e_aten, 2e-6), (name, e_mine, e_aten)
+
+
+def _field_inputs_reference(pts, inv_T, vol, planes, nerf_box, skin_box):
+    """PyTorch statement: Deformation_Field_new.forward -> box warp -> sample_from_triplane_new + Embedder -> cat (any dtype)."""
+    from havatar_amd.utils.util import sample_from_triplane_new, voxel_feature
+    B = pts.shape[0]
+    ident = torch.cat([torch.eye(3), torch.zeros(1, 3)], 0).to(pts).unsqueeze(0).expand(B, -1, -1)
+    t = lambda v: torch.tensor(v).to(pts)
+    p_i = [torch.matmul(pts + T[:, -1:], T[:, :3, :3]) for T in (ident, inv_T)]
+    w_c = vol.expand(B, -1, -1, -1, -1)
+    w = torch.cat([voxel_feature(xyz=p * t(skin_box[0]) + t(skin_box[1]), volume_feat=w_c[:, i:i + 1]) for i, p in enumerate(p_i)], -1)
+    w = w / (w.sum(dim=-1, keepdim=True) + 1e-8)
+    rot = w[:, :, 0:1] * p_i[0] + w[:, :, 1:2] * p_i[1]
+    f = sample_from_triplane_new(rot * t(nerf_box[0]) + t(nerf_box[1]), planes, padding_mode="zeros")
+    f = f.reshape(-1, f.shape[-1] * f.shape[-2])
+    x = rot.reshape(-1, 3)
+    from havatar_amd.model.network.embedder import get_embedder
+    return torch.cat([f, get_embedder(multires=8, input_dims=3, include_input=False)[0](x)], -1)
+
+
+def test_field_inputs_forward_and_gradients_match_the_pytorch_statement():
+    """hav_field_inputs_{fwd,bwd} vs skinning field + box warp + tri-plane gather + encoding under ATen autograd (fp64 = truth,
+    ATen fp32 = yardstick): X, d/dplanes, d/dvolume; points inside and outside both boxes, B = 2 with different head poses."""
+    from havatar_amd.native.train_ops import field_inputs
+    g = torch.Generator(device=DEV).manual_seed(21)
+    nerf_box, skin_box = ([0.66, 0.65, 0.7], [0.0, 0.07, 0.14]), ([0.66, 1.9, 0.7], [0.0, -1.7, 0.14])
+    for B, N, Cc, H, D in ((2, 3000, 64, 128, 64), (1, 53, 8, 6, 5)):
+        planes = torch.randn(2, B, Cc, H, H, device=DEV, generator=g, requires_grad=True)
+        vol0 = torch.sigmoid(2 * torch.randn(1, 1, D, D, D, device=DEV, generator=g))
+        vol = torch.cat([vol0, 1 - vol0], 1).requires_grad_(True)
+        pts = torch.rand(B, N, 3, device=DEV, generator=g) * 3.6 - 1.8
+        ang = torch.tensor([0.3, -0.2][:B], device=DEV)
+        Rm = torch.stack([torch.stack([torch.cos(ang), torch.zeros_like(ang), torch.sin(ang)], -1),
+                          torch.tensor([0.0, 1.0, 0.0], device=DEV).expand(B, 3),
+                          torch.stack([-torch.sin(ang), torch.zeros_like(ang), torch.cos(ang)], -1)], 1)
+        inv_T = torch.cat([Rm, torch.tensor([[[0.02, -0.03, 0.01]]], device=DEV).expand(B, 1, 3)], 1).contiguous()
+        up = torch.randn(B * N, 2 * Cc + 48, device=DEV, generator=g)
+
+        def aten(pp, vv, dt):
+            r = _field_inputs_reference(pts.to(dt), inv_T.to(dt), vv, pp, nerf_box, skin_box)
+            return (r,) + torch.autograd.grad(r, (pp, vv), up.to(dt))
+
+        ref32 = aten(planes, vol, torch.float32)
+        ref64 = aten(planes.detach().double().requires_grad_(True), vol.detach().double().requires_grad_(True), torch.float64)
+        got = field_inputs(pts, inv_T, vol, planes, nerf_box, skin_box)
+        gp, gv = torch.autograd.grad(got, (planes, vol), up)
+        for name, mine, r32, r64 in (("X", got, ref32[0], ref64[0]), ("dplanes", gp, ref32[1], ref64[1]), ("dvol", gv, ref32[2], ref64[2])):
+            scale = r64.abs().max().item()
+            e_mine, e_aten = (mine.double() - r64).abs().max().item() / scale, (r32.double() - r64).abs().max().item() / scale
+            assert e_mine <= max(2.0 * e_aten, 4e-6), (name, e_mine, e_aten)
+        assert gv.abs().max().item() > 0 and gp.abs().max().item() > 0
+
+
+def test_composite_forward_and_gradients_match_volume_render_radiance_field():
+    """hav_composite_{fwd,bwd} vs utils/nerf_util.py::volume_render_radiance_field under ATen autograd (fp64 = truth): all four maps
+    and d/d rf with every output carrying a gradient; S = 64 and a ragged S = 48 / 7; with and without noise and background."""
+    from havatar_amd.native.train_ops import composite
+    from havatar_amd.utils.nerf_util import volume_render_radiance_field
+    g = torch.Generator(device=DEV).manual_seed(22)
+    for n, S, CH, use_noise, use_bg in ((1500, 64, 67, True, True), (333, 48, 67, False, True), (5, 7, 3, True, False)):
+        rf = (torch.randn(n, S, CH + 1, device=DEV, generator=g) * 2).requires_grad_(True)
+        z = torch.sort(torch.rand(n, S, device=DEV, generator=g) * 2.6 + 3.4, -1)[0]
+        rd = torch.randn(n, 3, device=DEV, generator=g)
+        noise = torch.randn(n, S, device=DEV, generator=g) * 0.5 if use_noise else None
+        bg = torch.rand(n, 3, device=DEV, generator=g) if use_bg else None
+        ups = [torch.randn(s, device=DEV, generator=g) for s in ((n, CH), (n,), (n, S), (n,))]
+
+        def aten(r, dt):
+            r2 = r + 0                                           # the reference sigmoids rf[..., :3] in place
+            if noise is not None:                                # inject the draw: sigma = relu(raw + noise)
+                r2 = torch.cat([r2[..., :-1], r2[..., -1:] + noise.to(dt)[..., None]], -1)
+            rgb, _, acc, w, depth = volume_render_radiance_field(r2, z.to(dt), rd.to(dt), 0.0, act_feat=False,
+                                                                 background_prior=bg.to(dt) if bg is not None else None)
+            outs = (rgb, acc, w, depth)
+            return outs + torch.autograd.grad(outs, r, [u.to(dt) for u in ups])
+
+        ref32 = aten(rf, torch.float32)
+        ref64 = aten(rf.detach().double().requires_grad_(True), torch.float64)
+        got = composite(rf, z, rd, noise, bg, n_sigmoid=3)
+        got = tuple(got) + torch.autograd.grad(got, rf, ups)
+        for name, mine, r32, r64 in zip(("rgb", "acc", "weights", "depth", "d_rf"), got, ref32, ref64):
+            scale = r64.abs().max().item()
+            e_mine, e_aten = (mine.double() - r64).abs().max().item() / scale, (r32.double() - r64).abs().max().item() / scale
+            assert e_mine <= max(2.0 * e_aten, 4e-6), (name, e_mine, e_aten)
+    with pytest.raises(RuntimeError):
+        composite(torch.zeros(2, 65, 4, device=DEV), torch.zeros(2, 65, device=DEV), torch.ones(2, 3, device=DEV))

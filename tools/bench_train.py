@@ -27,19 +27,18 @@ np.random.seed(0); torch.manual_seed(0)
 tl = Loader(split_file=split, mode="train", batch_size=2, num_workers=0, down_sample=cfg.dataset.down_sample, options=cfg, white_bg=True, shuffle=False)
 idx, batch = next(iter(tl))
 trainer = synth.fill_state_dict(Trainer(cfg, len(tl.dataset))).to(dev).train()
-opt = torch.optim.Adam(trainer.parameters(), lr=5e-4)
+use_graph = train.graph_training_enabled(dev)
+opt = train.make_optimizer(cfg, trainer, use_graph)
 inp, target, mask = train.step_inputs(idx, batch, dev)
 torch.backends.cudnn.benchmark = True
+runner = train.StepRunner(trainer, cfg, opt, torch.nn.functional.mse_loss, graph=use_graph)
 
 
 def step():
-    loss, parts, psnr = train.training_loss(trainer, cfg, inp, target, mask, torch.nn.functional.mse_loss)
-    loss.backward()
-    opt.step(); opt.zero_grad()
-    return loss
+    return runner(inp, target, mask)[0]
 
 
-for _ in range(3):
+for _ in range(4):
     step()
 torch.cuda.synchronize()
 n = 10
@@ -49,7 +48,7 @@ for _ in range(n):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
 rays = inp["ray_batch"].shape[0] * inp["ray_batch"].shape[1]
-print("train step: %.1f ms  (%d rays x 112 samples = %.2f M queries, %.2f M queries/s), loss %.4f" % (dt * 1e3, rays, rays * 112 / 1e6, rays * 112 / dt / 1e6, l.item()))
+print("train step (%s): %.1f ms  (%d rays x 112 samples = %.2f M queries, %.2f M queries/s), loss %.4f" % ("one hipGraph launch" if use_graph else "eager", dt * 1e3, rays, rays * 112 / 1e6, rays * 112 / dt / 1e6, l.item()))
 
 
 def timed(fn, n=5):
