@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(256) field_inputs_kernel(FieldArgs a)
             const float dh0 = dx * px + dy * py + dz * pz, dh1 = dx * p1x + dy * p1y + dz * p1z;
             const float mix = dh0 * h0 + dh1 * h1;
             const float dw = ((bone ? dh1 : dh0) - mix) / s;
-            if (vin) atomicAdd(a.dvol + vidx, tw * dw);
+            if (vin && tw * dw != 0.f) atomicAdd(a.dvol + vidx, tw * dw);   // clamped (border) coordinates: half the taps weigh 0
         }
     }
 }

@@ -189,6 +189,26 @@ def test_training_cli_runs_and_resumes(tmp_path, dataset, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_training_cli_gpu_graph_mode_runs_validates_and_resumes(tmp_path, dataset, monkeypatch, capsys):
+    """train_avatar counterpart on the device with the step as one hipGraph launch: 5 steps (2 eager, capture, replays) with a
+    validation render through the fused inference kernel and a checkpoint, then a resume that captures again."""
+    from havatar_amd.harness import train
+    monkeypatch.setenv("HAVATAR_PRETRAIN_WC", "2")
+    monkeypatch.setenv("HAVATAR_WORKERS", "0")
+    cfg_path = _write_cfg(tmp_path / "cfg.yml", perturb=True, noise_std=0.1)
+    log = tmp_path / "log"
+    last = train.main(["--logdir", str(log), "--datadir", dataset[0], "--config", cfg_path, "--max-steps", "5"], device="cuda")
+    assert last == 4
+    ck = torch.load(log / "checkpoint00000.ckpt", map_location="cpu", weights_only=False)
+    assert set(ck) == {"iter", "optimizer_state_dict", "loss", "psnr", "trainer_state_dict"} and np.isfinite(float(ck["loss"]))
+    last = train.main(["--logdir", str(log), "--datadir", dataset[0], "--config", cfg_path, "--ckpt", str(log / "checkpoint00000.ckpt"),
+                       "--max-steps", "4"], device="cuda")
+    assert last == 4
+    out = capsys.readouterr().out
+    assert "Validation loss" in out and "nan" not in out.lower()
+
+
+@pytest.mark.gpu
 def test_reenactment_cli_gpu(tmp_path, dataset, gold):
     """H1 through the fused HIP renderer + hipGraph + MIOpen encoders: float outputs within the path's tolerance of the
     reference's, PNGs within 2 LSB."""

@@ -50,6 +50,9 @@ dt = (time.perf_counter() - t0) / n
 rays = inp["ray_batch"].shape[0] * inp["ray_batch"].shape[1]
 print("train step (%s): %.1f ms  (%d rays x 112 samples = %.2f M queries, %.2f M queries/s), loss %.4f" % ("one hipGraph launch" if use_graph else "eager", dt * 1e3, rays, rays * 112 / 1e6, rays * 112 / dt / 1e6, l.item()))
 
+if os.environ.get("BENCH_TRAIN_NO_BREAKDOWN"):
+    sys.exit(0)
+
 
 def timed(fn, n=5):
     ts = []
