@@ -151,7 +151,7 @@ class Trainer(torch.nn.Module):
         def one_pass_hip(zv):
             pts = (ro[..., None, :] + rd[..., None, :] * zv[..., :, None]).reshape(B, -1, 3)
             X = field_inputs(pts, inv_head_T, vol, planes, *self._boxes)
-            rf = self.model_coarse.mlp(X).reshape(B * R, zv.shape[-1], -1)
+            rf = self.model_coarse.mlp(X).reshape(B * R, zv.shape[-1], -1).float()      # (bf16 under autocast: the compositing is fp32)
             std = float(opt.radiance_field_noise_std)
             noise = torch.randn(rf.shape[:-1], dtype=rf.dtype, device=rf.device) * std if std > 0.0 else None     # same draw as :56
             rgb, acc, w, depth = composite(rf, zv.reshape(-1, zv.shape[-1]), rd.reshape(-1, 3), noise, bg, n_sigmoid=3)
