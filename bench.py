@@ -57,6 +57,14 @@ def main():
     ap.add_argument("--perturb", type=int, default=1, help="stratified jitter on (reference default for inference)")
     ap.add_argument("--graph", type=int, default=1, help="replay the frame as one hipGraph (0 = eager launches)")
     args = ap.parse_args()
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # one MIOpen user database / kernel cache per rank: N processes selecting solvers for the same ~40 convolution shapes at
+        # the same time otherwise queue on the locks of one shared sqlite file
+        for var, sub in (("MIOPEN_USER_DB_PATH", "db"), ("MIOPEN_CUSTOM_CACHE_DIR", "cache")):
+            if var not in os.environ:
+                d = os.path.join("/tmp", "havatar_miopen_rank%s" % os.environ.get("LOCAL_RANK", "0"), sub)
+                os.makedirs(d, exist_ok=True)
+                os.environ[var] = d
 
     import numpy as np
     import torch
