@@ -17,6 +17,7 @@ import numpy as np
 import torch
 import yaml
 
+from . import per_rank_miopen_cache
 from ..dataloader import imgio
 from ..dataloader.dataloaderSR import Loader
 from ..frames import shard_frames
@@ -100,6 +101,7 @@ def main(argv=None, device=None, style=None):
     np.random.seed(seed)
     torch.manual_seed(seed)
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    per_rank_miopen_cache()
     if device is None:
         device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))       # the reference is GPU-only as well (:133)
     device = torch.device(device)
