@@ -241,10 +241,15 @@ __global__ void __launch_bounds__(256) plane_project_kernel(float* __restrict__ 
 #pragma unroll
     for (int o = 0; o < 32; ++o) sO[tx * 129 + ty * 32 + o] = acc[o];
     __syncthreads();
-    float* out = dst + ((size_t)pb * HW + t0) * 128;
+    // Layout: groups of 4 x-adjacent texels; inside a group the 16-byte piece (h, c) of the four texels is contiguous
+    // ([group][h*16 + c][x & 3][4 floats], 512 floats per group).  The four lanes of a quad are x-adjacent rays at the same sample
+    // index and mostly need the same piece of neighbouring texels: they now hit one 64-byte segment instead of four lines 512 bytes
+    // apart (the texture path serves a quad per cycle only when it stays inside one line).  W % 4 == 0.
+    float* out = dst + (size_t)pb * HW * 128;
     for (int i = tid; i < 64 * 128; i += 256) {
         const int t = i >> 7, hu = i & 127;
-        if (t0 + t < HW) out[(size_t)t * 128 + hu] = sO[t * 129 + hu];
+        const int tt = t0 + t;                       // y * W + x with W % 4 == 0: tt >> 2 = group, tt & 3 = x & 3
+        if (tt < HW) out[(size_t)(tt >> 2) * 512 + (hu >> 2) * 16 + (tt & 3) * 4 + (hu & 3)] = sO[t * 129 + hu];
     }
 }
 
@@ -254,7 +259,7 @@ extern "C" int hav_triplane_prepare(float* dst, const float* src_nchw, const voi
                                     void* stream)
 {
     if (!dst || !src_nchw || !mlp_blob || B < 1 || H < 1 || W < 1) return HAV_EINVAL;
-    if (C != HAV_PC) return HAV_EUNSUP;
+    if (C != HAV_PC || (W & 3)) return HAV_EUNSUP;
     const int HW = H * W;
     const size_t lds = (64 * 64 + 128 * 65 + 64 * 129) * sizeof(float);
     static bool attr_set = false;
@@ -738,18 +743,20 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
             const int cx0 = min(max(x0, 0), PR - 1), cx1 = min(max(x1, 0), PR - 1);
             tw[4 * pl + 0] = (vx0 && vy0) ? wx0 * wy0 : 0.f; tw[4 * pl + 1] = (vx1 && vy0) ? wx1 * wy0 : 0.f;
             tw[4 * pl + 2] = (vx0 && vy1) ? wx0 * wy1 : 0.f; tw[4 * pl + 3] = (vx1 && vy1) ? wx1 * wy1 : 0.f;
-            const float* plb = a.pplanes + ((size_t)pl * a.p.B + b) * PR * PR * 128 + h * 64;
-            tp[4 * pl + 0] = reinterpret_cast<const float4*>(plb + ((size_t)cy0 * PR + cx0) * 128);
-            tp[4 * pl + 1] = reinterpret_cast<const float4*>(plb + ((size_t)cy0 * PR + cx1) * 128);
-            tp[4 * pl + 2] = reinterpret_cast<const float4*>(plb + ((size_t)cy1 * PR + cx0) * 128);
-            tp[4 * pl + 3] = reinterpret_cast<const float4*>(plb + ((size_t)cy1 * PR + cx1) * 128);
+            // prepared layout: [group of 4 x-adjacent texels][piece h*16 + c][x & 3][4 floats]; piece c of this half is float4 4*c
+            const float* plb = a.pplanes + ((size_t)pl * a.p.B + b) * PR * PR * 128 + h * 256;
+            auto texel = [&](int cy, int cx) { return reinterpret_cast<const float4*>(plb + ((size_t)((cy * PR + cx) >> 2)) * 512 + (cx & 3) * 4); };
+            tp[4 * pl + 0] = texel(cy0, cx0);
+            tp[4 * pl + 1] = texel(cy0, cx1);
+            tp[4 * pl + 2] = texel(cy1, cx0);
+            tp[4 * pl + 3] = texel(cy1, cx1);
         }
         // 8 taps x 256 B per lane, two taps (32 x 16 B) in flight.  The empty asm pins each tap's FMAs before the
         // loads that recycle its registers: left alone, the compiler hoists all 128 loads and spills them.
         constexpr int NST = 8 * 16 / GQ;          // pipeline stages: stage g covers float4s [(g*GQ)%16, +GQ) of tap (g*GQ)/16
         float4 tv[2][GQ];
 #pragma unroll
-        for (int c = 0; c < GQ; ++c) { tv[0][c] = tp[0][c]; tv[1][c] = tp[GQ / 16][GQ % 16 + c]; }
+        for (int c = 0; c < GQ; ++c) { tv[0][c] = tp[0][4 * c]; tv[1][c] = tp[GQ / 16][4 * (GQ % 16 + c)]; }
 #pragma unroll
         for (int g = 0; g < NST; ++g) {
             const int tap = (g * GQ) / 16, c0 = (g * GQ) % 16;
@@ -767,7 +774,7 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
             if (g + 2 < NST) {
                 const int ntap = ((g + 2) * GQ) / 16, nc0 = ((g + 2) * GQ) % 16;
 #pragma unroll
-                for (int c = 0; c < GQ; ++c) tv[g & 1][c] = tp[ntap][nc0 + c];
+                for (int c = 0; c < GQ; ++c) tv[g & 1][c] = tp[ntap][4 * (nc0 + c)];
             }
         }
     }
