@@ -73,6 +73,9 @@
 #define OFF_A2H (OFF_A1H + 3 * 4 * 2 * 64 * 4)      // [8 chunks][4][2][64][4 dwords]
 #define OFF_W4H (OFF_A2H + 8 * 4 * 2 * 64 * 4)      // copy of W4: [A1H | A2H | W4H] is one contiguous LDS image
 #define OFF_AFH (OFF_W4H + K2_STEPS * 2 * 4)        // [8 chunks][2 row tiles][2][64][4 dwords]  fc_rgbFeat, same k order as layer 2
+#ifndef HAV_TG
+#define HAV_TG 2          // log2 of the texel group of the prepared-plane layout (4 x-adjacent texels)
+#endif
 #define LDSH_FLOATS (3 * 4 * 2 * 64 * 4 + 8 * 4 * 2 * 64 * 4 + K2_STEPS * 2 * 4 + 8 * 2 * 2 * 64 * 4)    // 31232 dwords = 122 KB
 #define BLOB_FLOATS (OFF_AFH + 8 * 2 * 2 * 64 * 4)
 
@@ -249,7 +252,7 @@ __global__ void __launch_bounds__(256) plane_project_kernel(float* __restrict__ 
     for (int i = tid; i < 64 * 128; i += 256) {
         const int t = i >> 7, hu = i & 127;
         const int tt = t0 + t;                       // y * W + x with W % 4 == 0: tt >> 2 = group, tt & 3 = x & 3
-        if (tt < HW) out[(size_t)(tt >> 2) * 512 + (hu >> 2) * 16 + (tt & 3) * 4 + (hu & 3)] = sO[t * 129 + hu];
+        if (tt < HW) out[(size_t)(tt >> HAV_TG) * (128 << HAV_TG) + (hu >> 2) * (4 << HAV_TG) + (tt & ((1 << HAV_TG) - 1)) * 4 + (hu & 3)] = sO[t * 129 + hu];
     }
 }
 
@@ -259,7 +262,7 @@ extern "C" int hav_triplane_prepare(float* dst, const float* src_nchw, const voi
                                     void* stream)
 {
     if (!dst || !src_nchw || !mlp_blob || B < 1 || H < 1 || W < 1) return HAV_EINVAL;
-    if (C != HAV_PC || (W & 3)) return HAV_EUNSUP;
+    if (C != HAV_PC || (W & ((1 << HAV_TG) - 1))) return HAV_EUNSUP;
     const int HW = H * W;
     const size_t lds = (64 * 64 + 128 * 65 + 64 * 129) * sizeof(float);
     static bool attr_set = false;
@@ -744,8 +747,8 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
             tw[4 * pl + 0] = (vx0 && vy0) ? wx0 * wy0 : 0.f; tw[4 * pl + 1] = (vx1 && vy0) ? wx1 * wy0 : 0.f;
             tw[4 * pl + 2] = (vx0 && vy1) ? wx0 * wy1 : 0.f; tw[4 * pl + 3] = (vx1 && vy1) ? wx1 * wy1 : 0.f;
             // prepared layout: [group of 4 x-adjacent texels][piece h*16 + c][x & 3][4 floats]; piece c of this half is float4 4*c
-            const float* plb = a.pplanes + ((size_t)pl * a.p.B + b) * PR * PR * 128 + h * 256;
-            auto texel = [&](int cy, int cx) { return reinterpret_cast<const float4*>(plb + ((size_t)((cy * PR + cx) >> 2)) * 512 + (cx & 3) * 4); };
+            const float* plb = a.pplanes + ((size_t)pl * a.p.B + b) * PR * PR * 128 + h * (64 << HAV_TG);
+            auto texel = [&](int cy, int cx) { return reinterpret_cast<const float4*>(plb + ((size_t)((cy * PR + cx) >> HAV_TG)) * (128 << HAV_TG) + (cx & ((1 << HAV_TG) - 1)) * 4); };
             tp[4 * pl + 0] = texel(cy0, cx0);
             tp[4 * pl + 1] = texel(cy0, cx1);
             tp[4 * pl + 2] = texel(cy1, cx0);
@@ -756,7 +759,7 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
         constexpr int NST = 8 * 16 / GQ;          // pipeline stages: stage g covers float4s [(g*GQ)%16, +GQ) of tap (g*GQ)/16
         float4 tv[2][GQ];
 #pragma unroll
-        for (int c = 0; c < GQ; ++c) { tv[0][c] = tp[0][4 * c]; tv[1][c] = tp[GQ / 16][4 * (GQ % 16 + c)]; }
+        for (int c = 0; c < GQ; ++c) { tv[0][c] = tp[0][(1 << HAV_TG) * c]; tv[1][c] = tp[GQ / 16][(1 << HAV_TG) * (GQ % 16 + c)]; }
 #pragma unroll
         for (int g = 0; g < NST; ++g) {
             const int tap = (g * GQ) / 16, c0 = (g * GQ) % 16;
@@ -774,7 +777,7 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
             if (g + 2 < NST) {
                 const int ntap = ((g + 2) * GQ) / 16, nc0 = ((g + 2) * GQ) % 16;
 #pragma unroll
-                for (int c = 0; c < GQ; ++c) tv[g & 1][c] = tp[ntap][4 * (nc0 + c)];
+                for (int c = 0; c < GQ; ++c) tv[g & 1][c] = tp[ntap][(1 << HAV_TG) * (nc0 + c)];
             }
         }
     }
