@@ -204,7 +204,9 @@ int hav_mlp_pack(void* blob, const HavMlpWeights* w, void* stream);
  * model/nerf_model.py:85-86).  Output (device, hav_triplane_prepared_bytes(B,H,W) bytes): channels-last planes
  * [2,B,H,W,128] in which every texel has already been multiplied by the 128x64 block of layers_xyz.0 that reads this
  * plane's channels (bilinear interpolation and the first linear layer commute), stored in the ray-march kernel's
- * accumulator order.  Needs the packed blob (hav_mlp_pack) of the CURRENT weights: re-run when planes OR weights change. */
+ * accumulator order.  Needs the packed blob (hav_mlp_pack) of the CURRENT weights: re-run when planes OR weights change.
+ * The buffer's internal arrangement (groups of 4 x-adjacent texels, 16-byte pieces interleaved across the group so that
+ * neighbouring rays read one 64-byte segment) is private to the library: only hav_render_rays reads it.  W % 4 == 0. */
 int64_t hav_triplane_prepared_bytes(int B, int H, int W);
 int hav_triplane_prepare(float* dst, const float* src_nchw, const void* mlp_blob, int B, int C, int H, int W,
                          void* stream);
