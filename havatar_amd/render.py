@@ -75,7 +75,8 @@ class RayMarcher:
         self._keep = ts
 
     def set_triplane(self, planes_nchw):
-        """[2,B,C,H,W] (Trainer.model_coarse.triPlane_embeddings) -> prepared planes [2,B,H,W,128] on the device.
+        """[2,B,C,H,W] (Trainer.model_coarse.triPlane_embeddings) -> prepared planes on the device (128 floats per texel of [2,B,H,W];
+        the arrangement inside the buffer belongs to the library).
 
         Must be called after set_mlp() and again whenever the weights change (the projection uses them)."""
         if self.blob is None:

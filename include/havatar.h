@@ -201,8 +201,8 @@ int64_t hav_mlp_blob_bytes(void);
 int hav_mlp_pack(void* blob, const HavMlpWeights* w, void* stream);
 
 /* Per-frame tri-plane preparation.  Input: NCHW [2,B,64,H,W] (Trainer.model_coarse.triPlane_embeddings,
- * model/nerf_model.py:85-86).  Output (device, hav_triplane_prepared_bytes(B,H,W) bytes): channels-last planes
- * [2,B,H,W,128] in which every texel has already been multiplied by the 128x64 block of layers_xyz.0 that reads this
+ * model/nerf_model.py:85-86).  Output (device, hav_triplane_prepared_bytes(B,H,W) bytes): 128 floats per texel of
+ * [2,B,H,W] in which every texel has already been multiplied by the 128x64 block of layers_xyz.0 that reads this
  * plane's channels (bilinear interpolation and the first linear layer commute), stored in the ray-march kernel's
  * accumulator order.  Needs the packed blob (hav_mlp_pack) of the CURRENT weights: re-run when planes OR weights change.
  * The buffer's internal arrangement (groups of 4 x-adjacent texels, 16-byte pieces interleaved across the group so that
@@ -227,7 +227,7 @@ typedef struct HavRenderOut {      /* all device pointers, float32; fine pointer
  *                                                the only consumer is dead code, nerf_trainer.py:146-150)
  * bg        [B,R,3] or NULL                     (background_prior)
  * inv_T     [B,4,3]                             (inv_head_T: rows 0-2 = M, row 3 = tau)
- * planes    [2,B,H,W,128] prepared planes       (hav_triplane_prepare)
+ * planes    prepared planes, 2*B*H*W*128 floats (hav_triplane_prepare; layout private to the library)
  * skin_vol  [2,D,H,W]                           (canonical_W[0], shared by the batch)
  * mlp_blob  hav_mlp_pack output
  * t_rand    [B,R,S_c] or NULL                   (xi  = torch.rand at nerf_trainer.py:138)
