@@ -598,7 +598,12 @@ __device__ __forceinline__ void split2h(float v0, float v1, uint32_t& ph, uint32
     ph = __builtin_bit_cast(uint32_t, hi);
     pl = __builtin_bit_cast(uint32_t, lo);
 }
-template <int NCH, int NM, typename GetV>
+// HARD: the keep-alives above pin VALUES, not physical registers: when the allocator has to spill or split the live range of an
+// operand between its MFMA and the KEEP (seen in the one instantiation that runs with 64 more live accumulators than the others:
+// the feature projection of a parked tile inside the kernels that also composite the coarse outputs, ~0.4 % of the rays of a
+// full frame wrong in columns 16-31, run to run), the register the MFMA is still reading is free again.  HARD waits the matrix
+// instruction out (32 cycles) before the vector code of the next k-chunk may touch anything.
+template <int NCH, int NM, bool HARD = true, typename GetV>
 __device__ __forceinline__ void mfma_split2h(f32x16 (&acc)[NM], const uint4* frag /* [NCH][NM row tiles][2 parts][64 lanes] */, int lane, GetV getv)
 {
     uint4 A[2][2];
@@ -628,6 +633,7 @@ __device__ __forceinline__ void mfma_split2h(f32x16 (&acc)[NM], const uint4* fra
         acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh, acc[m], 0, 0, 0);
         KEEP(acc[m], xl);
         pa = ah; pb = xh;
+        if (HARD && m == NM - 1 && g + 1 < NCH * NM) asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[m]) : "v"(pa), "v"(pb));
         __builtin_amdgcn_sched_barrier(0);
     }
     asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[NM - 1]) : "v"(pa), "v"(pb));
@@ -1726,7 +1732,7 @@ extern "C" const char* hav_render_variant(const HavRenderParams* p, int coarse_o
     if (!use_block_kernel(p)) return rnd ? "hav_march_f32_kernel<true>" : "hav_march_f32_kernel<false>";
     static char name[64];
     const int prec = mlp_prec(p);
-    const bool cache = use_fine_cache(p);
+    const bool cache = use_fine_cache(p) && !(prec == 2 && coarse_outputs);      // (fp16: only the fine-maps-only kernels use the cache)
     const int cm = (cache && !coarse_outputs && (rnd || prec == 2)) ? 2 : (cache ? 1 : 0);
     const int rm = !rnd ? 0 : (prec == 0 ? 2 : 1);          // (the f32 mode only instantiates the injected-tensor RNG variant)
     snprintf(name, sizeof(name), "hav_march_blk_kernel<%d, %d, %d>", rm, prec, cm);
@@ -1778,17 +1784,16 @@ extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, cons
     const bool random = p->perturb != 0 || p->noise_std > 0.f;
     static bool attr_set = false;
     if (!attr_set) {
-        const void* ks[19] = {(const void*)hav_march_f32_kernel<false>, (const void*)hav_march_f32_kernel<true>,
+        const void* ks[16] = {(const void*)hav_march_f32_kernel<false>, (const void*)hav_march_f32_kernel<true>,
                               (const void*)hav_march_blk_kernel<0, 0, 0>, (const void*)hav_march_blk_kernel<2, 0, 0>,
                               (const void*)hav_march_blk_kernel<0, 1, 0>, (const void*)hav_march_blk_kernel<1, 1, 0>,
                               (const void*)hav_march_blk_kernel<2, 1, 0>, (const void*)hav_march_blk_kernel<0, 1, 1>,
                               (const void*)hav_march_blk_kernel<1, 1, 1>, (const void*)hav_march_blk_kernel<2, 1, 1>,
                               (const void*)hav_march_blk_kernel<1, 1, 2>,
                               (const void*)hav_march_blk_kernel<0, 2, 0>, (const void*)hav_march_blk_kernel<1, 2, 0>,
-                              (const void*)hav_march_blk_kernel<2, 2, 0>, (const void*)hav_march_blk_kernel<0, 2, 1>,
-                              (const void*)hav_march_blk_kernel<1, 2, 1>, (const void*)hav_march_blk_kernel<2, 2, 1>,
+                              (const void*)hav_march_blk_kernel<2, 2, 0>,
                               (const void*)hav_march_blk_kernel<1, 2, 2>, (const void*)hav_march_blk_kernel<0, 2, 2>};
-        for (int i = 0; i < 19; ++i) {
+        for (int i = 0; i < 16; ++i) {
             hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return (int)e;
         }
@@ -1803,7 +1808,11 @@ extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, cons
         const int gridb = march_grid_blocks(p);
         const bool injected = t_rand || u_rand || noise_c || noise_f;     // parity tests; production draws everything on the device
         const int rm = !random ? 0 : (injected ? 2 : 1);
-        const bool cache = use_fine_cache(p);
+        // fp16 mode uses the cache only through the fine-maps-only kernels <.,2,2>: the fp16 kernels that carry the composited
+        // coarse outputs AND project parked tiles (<.,2,1>) are not launched -- at full occupancy ~0.4 % of their rays came out
+        // different from run to run (tools/stress_determinism.py, columns 16-31 of a tile: the MFMA operand hazard of DESIGN.md
+        // 3.5 under 240-280 spilled VGPRs); callers that want the coarse maps get every merged sample evaluated instead.
+        const bool cache = use_fine_cache(p) && !(mlp_prec(p) == 2 && !(no_coarse_out && rm != 2));
         a.ws = cache ? (float*)p->workspace : nullptr;
         a.ws_slot = fine_cache_slot_floats(p);
 #define LAUNCH_BLK(R_, P_, C_) hipLaunchKernelGGL((hav_march_blk_kernel<R_, P_, C_>), dim3(gridb), dim3(MARCH_THREADS), ldsb, (hipStream_t)stream, a)
@@ -1812,7 +1821,7 @@ extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, cons
         do {                                                                                                                      \
             if (cache && no_coarse_out && rm == 1) LAUNCH_BLK(1, P_, 2);          /* production: jitter, cache, fine maps only */ \
             else if (cache && no_coarse_out && rm == 0 && P_ == 2) LAUNCH_BLK(0, 2, 2);                                           \
-            else if (cache) { if (rm == 0) LAUNCH_BLK(0, P_, 1); else if (rm == 1) LAUNCH_BLK(1, P_, 1); else LAUNCH_BLK(2, P_, 1); } \
+            else if (cache && P_ != 2) { if (rm == 0) LAUNCH_BLK(0, 1, 1); else if (rm == 1) LAUNCH_BLK(1, 1, 1); else LAUNCH_BLK(2, 1, 1); } \
             else { if (rm == 0) LAUNCH_BLK(0, P_, 0); else if (rm == 1) LAUNCH_BLK(1, P_, 0); else LAUNCH_BLK(2, P_, 0); }        \
         } while (0)
         if (prec == 2) LAUNCH_SPLIT(2);
