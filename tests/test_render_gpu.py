@@ -271,9 +271,12 @@ def test_fine_pass_cache_is_the_default_with_jitter_and_needs_a_workspace(monkey
     rm = RayMarcher(sc["nerf_scale"], sc["nerf_trans"], sc["skin_scale"], sc["skin_trans"])
     monkeypatch.delenv("HAV_FINE", raising=False)
     from havatar_amd import _lib
-    # fp16 mode (default): the cache is on whenever a workspace is offered; bf16 mode: only with jitter
-    assert rm.variant(64, 16, perturb=True).endswith(", 1>") and rm.variant(64, 16, perturb=False).endswith(", 1>")
-    assert rm.variant(64, 16, perturb=True, coarse_outputs=False).endswith(", 2>")      # production: jitter, cache, fine maps only
+    # fp16 mode (default): the cache serves the fine-maps-only calls (with or without jitter); a call that also wants the coarse
+    # maps evaluates every merged sample (the fp16 kernels that would do both are not dispatched).
+    # bf16 mode: cache iff jitter
+    assert rm.variant(64, 16, perturb=True).endswith("2, 0>") and rm.variant(64, 16, perturb=False).endswith("2, 0>")
+    assert rm.variant(64, 16, perturb=True, coarse_outputs=False).endswith("<1, 2, 2>")      # production: jitter, cache, fine maps only
+    assert rm.variant(64, 16, perturb=False, coarse_outputs=False).endswith("<0, 2, 2>")
     rm.mlp_mode = _lib.HAV_MLP_SPLIT_BF16
     assert rm.variant(64, 16, perturb=True).endswith("1, 1>") and rm.variant(64, 16, perturb=False).endswith("1, 0>")
     rm.mlp_mode = _lib.HAV_MLP_SPLIT_F16
