@@ -166,7 +166,8 @@ typedef struct HavRenderParams {
     void*    workspace;    /* optional DEVICE scratch, hav_render_workspace_bytes() bytes: the fine pass then re-uses the
                             * radiance-field values of the even coarse samples that the merged list repeats
                             * (model/nerf_trainer.py:170) instead of evaluating them again: 80 evaluations per ray, not 112.
-                            * NULL / too small: every merged sample is evaluated, like the reference does.            */
+                            * NULL / too small: every merged sample is evaluated, like the reference does.  In the fp16
+                            * mode the workspace is used by calls that decline the coarse outputs (HavRenderOut) only.    */
     uint64_t workspace_bytes;
 } HavRenderParams;
 
