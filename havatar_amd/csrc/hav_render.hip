@@ -73,6 +73,9 @@
 #define OFF_A2H (OFF_A1H + 3 * 4 * 2 * 64 * 4)      // [8 chunks][4][2][64][4 dwords]
 #define OFF_W4H (OFF_A2H + 8 * 4 * 2 * 64 * 4)      // copy of W4: [A1H | A2H | W4H] is one contiguous LDS image
 #define OFF_AFH (OFF_W4H + K2_STEPS * 2 * 4)        // [8 chunks][2 row tiles][2][64][4 dwords]  fc_rgbFeat, same k order as layer 2
+#ifndef HAV_TAPPAIR
+#define HAV_TAPPAIR 1
+#endif
 #ifndef HAV_TG
 #define HAV_TG 2          // log2 of the texel group of the prepared-plane layout (4 x-adjacent texels)
 #endif
@@ -762,17 +765,22 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
         }
         // 8 taps x 256 B per lane, two taps (32 x 16 B) in flight.  The empty asm pins each tap's FMAs before the
         // loads that recycle its registers: left alone, the compiler hoists all 128 loads and spills them.
-        constexpr int NST = 8 * 16 / GQ;          // pipeline stages: stage g covers float4s [(g*GQ)%16, +GQ) of tap (g*GQ)/16
+        constexpr int NST = 8 * 16 / GQ;          // pipeline stages: stage g covers float4s [(g*GQ)%16, +GQ) of tap (g*GQ)/16 ...
+        // ... or, PAIRED (16-load stages): half the pieces of the two x-adjacent taps of a row, alternating between them -- in the
+        // grouped layout those two pieces are 16 bytes apart three times out of four, so the second load hits the line the first
+        // one just brought in instead of re-walking the group a stage later.  Per accumulator the taps still arrive in order 0..7.
+        constexpr bool PAIRED = (GQ == 16) && HAV_TAPPAIR;
+        auto tap_of = [](int g, int c) constexpr { return PAIRED ? 2 * (g >> 1) + (c & 1) : (g * GQ) / 16; };
+        auto piece_of = [](int g, int c) constexpr { return PAIRED ? 8 * (g & 1) + (c >> 1) : (g * GQ) % 16 + c; };
         float4 tv[2][GQ];
 #pragma unroll
-        for (int c = 0; c < GQ; ++c) { tv[0][c] = tp[0][(1 << HAV_TG) * c]; tv[1][c] = tp[GQ / 16][(1 << HAV_TG) * (GQ % 16 + c)]; }
+        for (int c = 0; c < GQ; ++c) { tv[0][c] = tp[tap_of(0, c)][(1 << HAV_TG) * piece_of(0, c)]; tv[1][c] = tp[tap_of(1, c)][(1 << HAV_TG) * piece_of(1, c)]; }
 #pragma unroll
         for (int g = 0; g < NST; ++g) {
-            const int tap = (g * GQ) / 16, c0 = (g * GQ) % 16;
-            const float wt = tw[tap];
 #pragma unroll
             for (int c = 0; c < GQ; ++c) {     // slot u = 4*c4+e  <->  accumulator (m = u>>4, r = u&15)
-                const int c4 = c0 + c;
+                const int c4 = piece_of(g, c);
+                const float wt = tw[tap_of(g, c)];
                 const float4 t4 = tv[g & 1][c];
                 acc1[c4 >> 2][4 * (c4 & 3) + 0] = fmaf(t4.x, wt, acc1[c4 >> 2][4 * (c4 & 3) + 0]);
                 acc1[c4 >> 2][4 * (c4 & 3) + 1] = fmaf(t4.y, wt, acc1[c4 >> 2][4 * (c4 & 3) + 1]);
@@ -781,9 +789,8 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
             }
             asm volatile("" : "+v"(acc1[0]), "+v"(acc1[1]), "+v"(acc1[2]), "+v"(acc1[3]) : : "memory");
             if (g + 2 < NST) {
-                const int ntap = ((g + 2) * GQ) / 16, nc0 = ((g + 2) * GQ) % 16;
 #pragma unroll
-                for (int c = 0; c < GQ; ++c) tv[g & 1][c] = tp[ntap][(1 << HAV_TG) * (nc0 + c)];
+                for (int c = 0; c < GQ; ++c) tv[g & 1][c] = tp[tap_of(g + 2, c)][(1 << HAV_TG) * piece_of(g + 2, c)];
             }
         }
     }
