@@ -76,6 +76,9 @@
 #ifndef HAV_TAPPAIR
 #define HAV_TAPPAIR 1
 #endif
+#ifndef HAV_TG1
+#define HAV_TG1 2         // ... of plane 1 (z,y)
+#endif
 #ifndef HAV_TG
 #define HAV_TG 2          // log2 of the texel group of the prepared-plane layout (4 x-adjacent texels)
 #endif
@@ -255,7 +258,8 @@ __global__ void __launch_bounds__(256) plane_project_kernel(float* __restrict__ 
     for (int i = tid; i < 64 * 128; i += 256) {
         const int t = i >> 7, hu = i & 127;
         const int tt = t0 + t;                       // y * W + x with W % 4 == 0: tt >> 2 = group, tt & 3 = x & 3
-        if (tt < HW) out[(size_t)(tt >> HAV_TG) * (128 << HAV_TG) + (hu >> 2) * (4 << HAV_TG) + (tt & ((1 << HAV_TG) - 1)) * 4 + (hu & 3)] = sO[t * 129 + hu];
+        const int tg = p ? HAV_TG1 : HAV_TG;
+        if (tt < HW) out[(size_t)(tt >> tg) * (128 << tg) + (hu >> 2) * (4 << tg) + (tt & ((1 << tg) - 1)) * 4 + (hu & 3)] = sO[t * 129 + hu];
     }
 }
 
@@ -265,7 +269,7 @@ extern "C" int hav_triplane_prepare(float* dst, const float* src_nchw, const voi
                                     void* stream)
 {
     if (!dst || !src_nchw || !mlp_blob || B < 1 || H < 1 || W < 1) return HAV_EINVAL;
-    if (C != HAV_PC || (W & ((1 << HAV_TG) - 1))) return HAV_EUNSUP;
+    if (C != HAV_PC || (W & ((1 << HAV_TG) - 1)) || (W & ((1 << HAV_TG1) - 1))) return HAV_EUNSUP;
     const int HW = H * W;
     const size_t lds = (64 * 64 + 128 * 65 + 64 * 129) * sizeof(float);
     static bool attr_set = false;
@@ -756,8 +760,9 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
             tw[4 * pl + 0] = (vx0 && vy0) ? wx0 * wy0 : 0.f; tw[4 * pl + 1] = (vx1 && vy0) ? wx1 * wy0 : 0.f;
             tw[4 * pl + 2] = (vx0 && vy1) ? wx0 * wy1 : 0.f; tw[4 * pl + 3] = (vx1 && vy1) ? wx1 * wy1 : 0.f;
             // prepared layout: [group of 4 x-adjacent texels][piece h*16 + c][x & 3][4 floats]; piece c of this half is float4 4*c
-            const float* plb = a.pplanes + ((size_t)pl * a.p.B + b) * PR * PR * 128 + h * (64 << HAV_TG);
-            auto texel = [&](int cy, int cx) { return reinterpret_cast<const float4*>(plb + ((size_t)((cy * PR + cx) >> HAV_TG)) * (128 << HAV_TG) + (cx & ((1 << HAV_TG) - 1)) * 4); };
+            const int tg = pl ? HAV_TG1 : HAV_TG;
+            const float* plb = a.pplanes + ((size_t)pl * a.p.B + b) * PR * PR * 128 + h * (64 << tg);
+            auto texel = [&](int cy, int cx) { return reinterpret_cast<const float4*>(plb + ((size_t)((cy * PR + cx) >> tg)) * (128 << tg) + (cx & ((1 << tg) - 1)) * 4); };
             tp[4 * pl + 0] = texel(cy0, cx0);
             tp[4 * pl + 1] = texel(cy0, cx1);
             tp[4 * pl + 2] = texel(cy1, cx0);
@@ -772,9 +777,10 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
         constexpr bool PAIRED = (GQ == 16) && HAV_TAPPAIR;
         auto tap_of = [](int g, int c) constexpr { return PAIRED ? 2 * (g >> 1) + (c & 1) : (g * GQ) / 16; };
         auto piece_of = [](int g, int c) constexpr { return PAIRED ? 8 * (g & 1) + (c >> 1) : (g * GQ) % 16 + c; };
+        auto pstep = [](int tap) constexpr { return 1 << (tap >= 4 ? HAV_TG1 : HAV_TG); };      // float4s between consecutive pieces of a texel
         float4 tv[2][GQ];
 #pragma unroll
-        for (int c = 0; c < GQ; ++c) { tv[0][c] = tp[tap_of(0, c)][(1 << HAV_TG) * piece_of(0, c)]; tv[1][c] = tp[tap_of(1, c)][(1 << HAV_TG) * piece_of(1, c)]; }
+        for (int c = 0; c < GQ; ++c) { tv[0][c] = tp[tap_of(0, c)][pstep(tap_of(0, c)) * piece_of(0, c)]; tv[1][c] = tp[tap_of(1, c)][pstep(tap_of(1, c)) * piece_of(1, c)]; }
 #pragma unroll
         for (int g = 0; g < NST; ++g) {
 #pragma unroll
@@ -790,7 +796,7 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
             asm volatile("" : "+v"(acc1[0]), "+v"(acc1[1]), "+v"(acc1[2]), "+v"(acc1[3]) : : "memory");
             if (g + 2 < NST) {
 #pragma unroll
-                for (int c = 0; c < GQ; ++c) tv[g & 1][c] = tp[tap_of(g + 2, c)][(1 << HAV_TG) * piece_of(g + 2, c)];
+                for (int c = 0; c < GQ; ++c) tv[g & 1][c] = tp[tap_of(g + 2, c)][pstep(tap_of(g + 2, c)) * piece_of(g + 2, c)];
             }
         }
     }
