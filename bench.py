@@ -167,7 +167,9 @@ def main():
         tools/profile.sh: FETCH_SIZE and WRITE_SIZE in separate passes, scaled by the factors calibrated in the same run on a
         streaming launch of known size -- MI355X_MICROARCH.md, HBM section).  None when no profile of this kernel is committed."""
         import glob
-        for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc.json")), reverse=True):
+        import re
+        natural = lambda f: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(f))]      # r01_v11 after r01_v9
+        for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc.json")), key=natural, reverse=True):
             try:
                 d = json.load(open(f))
                 k, cal = d[kernel.split("(")[0].strip()], d["calibration"]
