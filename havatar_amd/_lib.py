@@ -10,7 +10,9 @@ LIB_PATH = os.path.join(_HERE, "lib", "libhavatar_hip.so")
 
 HAV_F32, HAV_F16, HAV_BF16, HAV_F64 = 0, 1, 2, 3
 HAV_MLP_SPLIT_BF16, HAV_MLP_F32, HAV_MLP_SPLIT_F16 = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
+HAV_FLAG_PAIR_KERNEL, HAV_FLAG_FINE_CACHE, HAV_FLAG_FINE_RECOMPUTE, HAV_FLAG_NO_FP16_GUARD = 1, 2, 4, 8
+HAV_STATUS_FP16_FALLBACK = 1
 
 
 class HavRenderParams(C.Structure):
@@ -19,8 +21,9 @@ class HavRenderParams(C.Structure):
                 ("plane_res", C.c_int32), ("plane_ch", C.c_int32), ("vol_res", C.c_int32),
                 ("nerf_scale", C.c_float * 3), ("nerf_trans", C.c_float * 3),
                 ("skin_scale", C.c_float * 3), ("skin_trans", C.c_float * 3),
-                ("seed", C.c_uint64), ("rng_offset", C.c_uint64), ("mlp_mode", C.c_int32), ("reserved", C.c_int32),
-                ("rng_counter", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64)]
+                ("seed", C.c_uint64), ("rng_offset", C.c_uint64), ("mlp_mode", C.c_int32), ("flags", C.c_int32),
+                ("rng_counter", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64),
+                ("dbg_zfine", C.c_void_p), ("status", C.c_void_p)]
 
 
 class HavFieldParams(C.Structure):
@@ -93,10 +96,8 @@ def lib():
     L.hav_render_rays.restype = i32
     L.hav_render_workspace_bytes.argtypes = [C.POINTER(HavRenderParams)]
     L.hav_render_workspace_bytes.restype = i64
-    L.hav_render_variant.argtypes = [C.POINTER(HavRenderParams), i32]
-    L.hav_render_variant.restype = C.c_char_p
-    L.hav_debug_set_zfine.argtypes = [vp]
-    L.hav_debug_set_zfine.restype = None
+    L.hav_render_variant_name.argtypes = [C.POINTER(HavRenderParams), i32, i32, C.c_char_p, i32]
+    L.hav_render_variant_name.restype = i32
     L.hav_gen_rays.argtypes = [vp, i32, i32, C.POINTER(f32), C.POINTER(f32), f32, f32, i32, i32, vp]
     L.hav_gen_rays.restype = i32
     _lib = L

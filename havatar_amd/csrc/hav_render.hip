@@ -43,6 +43,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 
 // ------------------------------------------------------------------------------------------------
 // packed weight blob (float offsets).  [0, LDS_FLOATS) is copied verbatim into LDS by every workgroup.
@@ -83,7 +84,11 @@
 #define HAV_TG 2          // log2 of the texel group of the prepared-plane layout (4 x-adjacent texels)
 #endif
 #define LDSH_FLOATS (3 * 4 * 2 * 64 * 4 + 8 * 4 * 2 * 64 * 4 + K2_STEPS * 2 * 4 + 8 * 2 * 2 * 64 * 4)    // 31232 dwords = 122 KB
-#define BLOB_FLOATS (OFF_AFH + 8 * 2 * 2 * 64 * 4)
+// fp16 range guard (include/havatar.h, HAV_MLP_SPLIT_F16): [128] |b1_u| + sum_k |W1pe_uk| per hidden unit, in the accumulator
+// order hu of the prepared planes | [1] max |w| over every weight the fp16 mode converts (inf if one is not finite) | pad
+#define OFF_RNG (OFF_AFH + 8 * 2 * 2 * 64 * 4)
+#define BLOB_FLOATS (OFF_RNG + 132)
+#define HAV_FP16_LIMIT 60000.0f
 
 extern "C" int64_t hav_mlp_blob_bytes(void) { return (int64_t)BLOB_FLOATS * 4; }
 
@@ -124,7 +129,15 @@ __global__ void __launch_bounds__(256) mlp_pack_kernel(float* __restrict__ blob,
             v = (float)s;
         } else v = w.ba[0];
     } else if (e < OFF_W1F) v = w.bf[e - OFF_BF];
-    else if (e >= OFF_AFH) {
+    else if (e >= OFF_RNG) {
+        const int hu = e - OFF_RNG;
+        if (hu < 128) {                 // |PE value| <= 1 + 1e-7 (the second value of a pair is cos x - eps sin x)
+            const int u = acc_row((hu & 63) >> 4, hu & 15, hu >> 6);
+            float sacc = fabsf(w.b1[u]);
+            for (int k = 0; k < 48; ++k) sacc += 1.0001f * fabsf(w.W1[u * HAV_IN + 2 * HAV_PC + k]);
+            v = sacc;
+        } else v = 0.f;                 // OFF_RNG + 128 (max |w|) is written by mlp_wmax_kernel
+    } else if (e >= OFF_AFH) {
         const int q = e - OFF_AFH;
         const int d = q & 3, l = (q >> 2) & 63, part = (q >> 8) & 1, m = (q >> 9) & 1, ch = q >> 10;
         const int row = 32 * m + (l & 31), hh = l >> 5;
@@ -207,11 +220,32 @@ __global__ void __launch_bounds__(256) mlp_pack_kernel(float* __restrict__ blob,
     blob[e] = v;
 }
 
+// max |w| over the weights the fp16 split converts: layer-1 PE columns, layer 2, fc_rgbFeat (the head rows stay fp32 on the VALU).
+// A weight that is not finite, or not below the limit, makes the result +inf (fmaxf would drop a NaN).
+__global__ void __launch_bounds__(256) mlp_wmax_kernel(float* __restrict__ blob, HavMlpWeights w)
+{
+    __shared__ float red[256];
+    float m = 0.f;
+    auto see = [&](float x) { const float ax = fabsf(x); m = (ax < HAV_FP16_LIMIT) ? fmaxf(m, ax) : __builtin_inff(); };
+    for (int i = threadIdx.x; i < HAV_HID * 48; i += 256) see(w.W1[(i / 48) * HAV_IN + 2 * HAV_PC + i % 48]);
+    for (int i = threadIdx.x; i < HAV_HID * HAV_HID; i += 256) see(w.W2[i]);
+    for (int i = threadIdx.x; i < 64 * HAV_HID; i += 256) see(w.Wf[i]);
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + st]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) blob[OFF_RNG + 128] = red[0];
+}
+
 extern "C" int hav_mlp_pack(void* blob, const HavMlpWeights* w, void* stream)
 {
     if (!blob || !w || !w->W1 || !w->b1 || !w->W2 || !w->b2 || !w->Wa || !w->ba || !w->Wf || !w->bf || !w->Wc || !w->bc)
         return HAV_EINVAL;
     hipLaunchKernelGGL(mlp_pack_kernel, dim3((BLOB_FLOATS + 255) / 256), dim3(256), 0, (hipStream_t)stream, (float*)blob, *w);
+    HAV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mlp_wmax_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (float*)blob, *w);
     HAV_LAUNCH_CHECK();
     return 0;
 }
@@ -222,8 +256,12 @@ extern "C" int hav_mlp_pack(void* blob, const HavMlpWeights* w, void* stream)
 // One workgroup = 64 texels x 128 outputs; plane tile, weights and the output tile go through LDS so that both the
 // NCHW reads and the channels-last writes are coalesced.
 // ------------------------------------------------------------------------------------------------
+// trailer of the prepared-plane buffer (uint32 words): [2][128] bit patterns of max_texel |P_p[hu]| (atomicMax on the bits of a
+// non-negative float is a float max; a NaN sorts above +inf) | [256] verdict: 0 = the fp16 split is safe, 1 = not | [257..258] the
+// two bounds (diagnostics)
+#define PREP_TRAILER_WORDS 512
 __global__ void __launch_bounds__(256) plane_project_kernel(float* __restrict__ dst, const float* __restrict__ src,
-                                                            const float* __restrict__ blob, int HW)
+                                                            const float* __restrict__ blob, int HW, unsigned int* __restrict__ trailer)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* sX = sm;                 // [64 c][64 texels]
@@ -261,9 +299,60 @@ __global__ void __launch_bounds__(256) plane_project_kernel(float* __restrict__ 
         const int tg = p ? HAV_TG1 : HAV_TG;
         if (tt < HW) out[(size_t)(tt >> tg) * (128 << tg) + (hu >> 2) * (4 << tg) + (tt & ((1 << tg) - 1)) * 4 + (hu & 3)] = sO[t * 129 + hu];
     }
+    if (tid < 128) {                // fp16 range guard: this tile's max |P[hu]| (texels past the end hold exact zeros)
+        float m = 0.f;
+        unsigned int bad = 0;
+        for (int t = 0; t < 64; ++t) {
+            const float x = fabsf(sO[t * 129 + tid]);
+            bad |= (x != x);
+            m = fmaxf(m, x);
+        }
+        atomicMax(&trailer[p * 128 + tid], bad ? 0x7FC00000u : __float_as_uint(m));
+    }
 }
 
-extern "C" int64_t hav_triplane_prepared_bytes(int B, int H, int W) { return (int64_t)2 * B * H * W * 128 * 4; }
+// |h1_u| <= |b1_u| + sum_k |W1pe_uk| + max |P0_u| + max |P1_u|;  |h2_v| <= |b2_v| + sum_u |W2_vu| bound(h1_u)  (relu only shrinks)
+__global__ void __launch_bounds__(128) range_verdict_kernel(unsigned int* __restrict__ trailer, const float* __restrict__ blob)
+{
+    __shared__ float b1u[128], red[128];
+    const int t = threadIdx.x;
+    {
+        const float bound = blob[OFF_RNG + t] + __uint_as_float(trailer[t]) + __uint_as_float(trailer[128 + t]);     // t = hu
+        b1u[acc_row((t & 63) >> 4, t & 15, t >> 6)] = bound;
+        red[t] = (bound < HAV_FP16_LIMIT) ? bound : __builtin_inff();
+    }
+    __syncthreads();
+    for (int st = 64; st > 0; st >>= 1) { if (t < st) red[t] = fmaxf(red[t], red[t + st]); __syncthreads(); }
+    const float m1 = red[0];
+    __syncthreads();
+    {
+        const int m = t >> 5, l31 = t & 31;             // row v = t of W2 in the fp32 fragment section: [ks][m][lane]
+        float bound = fabsf(blob[OFF_B2 + t]);
+        for (int ks = 0; ks < K2_STEPS; ++ks)
+            for (int hh = 0; hh < 2; ++hh)
+                bound += fabsf(blob[OFF_W2 + (ks * 4 + m) * 64 + hh * 32 + l31]) * b1u[acc_row(ks >> 4, ks & 15, hh)];
+        red[t] = (bound < HAV_FP16_LIMIT) ? bound : __builtin_inff();
+    }
+    __syncthreads();
+    for (int st = 64; st > 0; st >>= 1) { if (t < st) red[t] = fmaxf(red[t], red[t + st]); __syncthreads(); }
+    if (t == 0) {
+        const float m2 = red[0], wmax = blob[OFF_RNG + 128];
+        const bool safe = (m1 < HAV_FP16_LIMIT) && (m2 < HAV_FP16_LIMIT) && (wmax < HAV_FP16_LIMIT);
+        trailer[256] = safe ? 0u : 1u;
+        trailer[257] = __float_as_uint(m1);
+        trailer[258] = __float_as_uint(m2);
+    }
+}
+
+extern "C" int64_t hav_triplane_prepared_bytes(int B, int H, int W) { return ((int64_t)2 * B * H * W * 128 + PREP_TRAILER_WORDS) * 4; }
+
+// one bit per device id: which devices already have the dynamic-LDS attribute of this file's kernels raised
+static bool attr_done(std::atomic<unsigned long long>& mask, int& dev)
+{
+    dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
+    return (mask.load(std::memory_order_acquire) >> dev) & 1ull;
+}
 
 extern "C" int hav_triplane_prepare(float* dst, const float* src_nchw, const void* mlp_blob, int B, int C, int H, int W,
                                     void* stream)
@@ -272,14 +361,20 @@ extern "C" int hav_triplane_prepare(float* dst, const float* src_nchw, const voi
     if (C != HAV_PC || (W & ((1 << HAV_TG) - 1)) || (W & ((1 << HAV_TG1) - 1))) return HAV_EUNSUP;
     const int HW = H * W;
     const size_t lds = (64 * 64 + 128 * 65 + 64 * 129) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_mask{0};
+    int dev;
+    if (!attr_done(attr_mask, dev)) {
         hipError_t e = hipFuncSetAttribute((const void*)plane_project_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        attr_mask.fetch_or(1ull << dev, std::memory_order_release);
     }
+    unsigned int* trailer = reinterpret_cast<unsigned int*>(dst + (size_t)2 * B * HW * 128);
+    hipError_t me = hipMemsetAsync(trailer, 0, PREP_TRAILER_WORDS * 4, (hipStream_t)stream);
+    if (me != hipSuccess) return (int)me;
     hipLaunchKernelGGL(plane_project_kernel, dim3((HW + 63) / 64, 2 * B), dim3(256), lds, (hipStream_t)stream, dst, src_nchw,
-                       (const float*)mlp_blob, HW);
+                       (const float*)mlp_blob, HW, trailer);
+    HAV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(range_verdict_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, trailer, (const float*)mlp_blob);
     HAV_LAUNCH_CHECK();
     return 0;
 }
@@ -396,6 +491,9 @@ struct MarchArgs {
     int scr_floats;         // per-wave LDS scratch
     int o_w, o_cdf, o_cand, o_zf, o_racc, s_pad_c, s_pad_f;
     const float* pplanes;   // projected tri-planes [2,B,H,W,128] (hav_triplane_prepare)
+    const unsigned int* guard;   // fp16 range verdict word in the prepared planes' trailer (nullptr: no guard on this launch)
+    int guard_run_if;       // the launch proceeds iff (*guard != 0) == (guard_run_if != 0): fp16 kernel 0, its bf16 fallback 1
+    unsigned int* status;   // optional HavRenderParams.status
 };
 
 enum { STREAM_XI = 0, STREAM_ZETA = 1, STREAM_EPS_C = 2, STREAM_EPS_F = 3 };
@@ -550,7 +648,8 @@ __device__ __forceinline__ void relu_tiles(f32x16 (&acc)[4])
 // MFMAs it separates: the compiler does reorder register-only MFMAs across a plain asm volatile.
 #define KEEP(acc, x) asm volatile("" : "+v"(acc) : "v"(x))
 
-template <int NCH, typename GetV>
+// HARD (see mfma_split2h below): wait the last MFMA of a k-chunk out before the splitting code of the next chunk may write registers.
+template <int NCH, bool HARD = true, typename GetV>
 __device__ __forceinline__ void mfma_split3(f32x16 (&acc)[4], const uint4* frag /* [NCH][4 m][3 parts][64 lanes] */, int lane, GetV getv)
 {
     uint4 A[2][3];
@@ -586,6 +685,7 @@ __device__ __forceinline__ void mfma_split3(f32x16 (&acc)[4], const uint4* frag 
         acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh, acc[m], 0, 0, 0);
         KEEP(acc[m], xm);
         pa = ah; pb = xh;
+        if (HARD && m == 3 && g + 1 < NCH * 4) asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[m]) : "v"(pa), "v"(pb));
         __builtin_amdgcn_sched_barrier(0);
     }
     asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[3]) : "v"(pa), "v"(pb));      // the last MFMA's operands outlive it by 32 wait states
@@ -1285,6 +1385,11 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
     // (8 rows of 1 KB per wave) instead of its 128 hidden units (16 rows): half the parking traffic for 48 more MFMAs per parked tile
     constexpr bool FEATPARK = (PREC == 2) && (CACHE != 0);
     constexpr int H2F = FEATPARK ? WS_H2_FLOATS / 2 : WS_H2_FLOATS, ENTF = H2F + 128 + 32;      // floats of one parked entry
+    if (a.guard) {          // fp16 range guard: the fp16 kernel and its bf16 fallback are both launched, one of them proceeds
+        const unsigned int unsafe = __builtin_amdgcn_readfirstlane(*a.guard);
+        if ((unsafe != 0) != (a.guard_run_if != 0)) return;
+        if (a.guard_run_if && a.status && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.status, HAV_STATUS_FP16_FALLBACK);
+    }
     const uint32_t call_off = RANDOM ? rng_call_off(a) : 0u;      // one memory read per kernel, not per draw
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int WLDS = PREC == 2 ? LDSH_FLOATS : (PREC == 1 ? LDS3_FLOATS : LDS_FLOATS);     // LDS image: fp32 | split-bf16 | split-fp16 fragments
@@ -1678,14 +1783,23 @@ extern "C" int hav_debug_read_prof(unsigned long long* out12)
     return (int)e;
 }
 #endif
-static float* g_dbg_zfine = nullptr;
-// test hook: next hav_render_rays call also dumps the merged fine depths [B*R,S_fp] to this device buffer
-extern "C" void hav_debug_set_zfine(float* dev_ptr) { g_dbg_zfine = dev_ptr; }
+// Process-wide knobs of timing experiments (results are wrong when set), read from the environment ONCE: HAV_ABLATE bit mask,
+// HAV_STAGGER.  Everything that selects behaviour per call travels in HavRenderParams (mlp_mode, flags, dbg_zfine, status).
+struct EnvKnobs { int ablate, stagger; };
+static const EnvKnobs& env_knobs()
+{
+    static const EnvKnobs k = [] {
+        EnvKnobs r{0, 0};
+        if (const char* e = getenv("HAV_ABLATE")) r.ablate = atoi(e);
+        if (const char* e = getenv("HAV_STAGGER")) r.stagger = atoi(e);
+        return r;
+    }();
+    return k;
+}
 
 static bool use_block_kernel(const HavRenderParams* p)
 {
-    const char* e = getenv("HAV_MARCH");                 // "pair" forces the ray-pair kernel (A/B runs)
-    if (e && e[0] == 'p') return false;
+    if (p->flags & HAV_FLAG_PAIR_KERNEL) return false;    // A/B runs and the pair kernel's own parity tests
     return p->S_f == 0 || p->S_c <= 67;                   // coarse weights are parked in the 67-float rgb_fine row
 }
 
@@ -1697,59 +1811,84 @@ static int march_grid_blocks(const HavRenderParams* p)
     if (needb < gridb) gridb = (int)((needb + 7) / 8 * 8);
     return gridb;
 }
-static int mlp_prec(const HavRenderParams* p);
+// 0 = exact f32 MFMA, 1 = bf16 triple split, 2 = fp16 double split
+static int mlp_prec(const HavRenderParams* p) { return p->mlp_mode == HAV_MLP_F32 ? 0 : (p->mlp_mode == HAV_MLP_SPLIT_F16 ? 2 : 1); }
 static long long fine_cache_slot_floats(const HavRenderParams* p)
 {
     const long long S_fp = (p->S_c + 1) / 2 + p->S_f;
     return S_fp * ((mlp_prec(p) == 2 ? WS_H2_FLOATS / 2 : WS_H2_FLOATS) + 128 + 32);      // features (fp16 mode) or hidden units
 }
-static bool use_split_mfma(const HavRenderParams* p);
-static bool use_block_kernel(const HavRenderParams* p);
-// fine-pass cache: block kernel, split-bf16 arithmetic, a fine pass, and a caller-provided workspace that is large enough
+// Would a workspace be used at all?  Measured on MI355X: with stratified jitter on (the production setting)
+// skipping the repeated samples is worth 10-15 % of the kernel; with deterministic depths the coarse tiles are so coherent (all 32
+// rays at the same depth) that in bf16 mode the 13 GB of parking traffic per frame cancel the gain.  With feature parking (fp16
+// mode) the parking stream is half as large and the cache pays with deterministic depths as well.
+// Default: fp16 -> always, bf16 -> iff perturb; HAV_FLAG_FINE_CACHE / HAV_FLAG_FINE_RECOMPUTE force either.
+static bool fine_cache_applies(const HavRenderParams* p)
+{
+    if (p->S_f <= 0 || p->S_c < 2 || !use_block_kernel(p) || mlp_prec(p) == 0) return false;
+    if (p->flags & HAV_FLAG_FINE_RECOMPUTE) return false;
+    if (p->flags & HAV_FLAG_FINE_CACHE) return true;
+    return p->perturb || mlp_prec(p) == 2;
+}
 static bool use_fine_cache(const HavRenderParams* p)
 {
-    // Measured on MI355X: with stratified jitter on (the production setting) skipping the repeated samples is
-    // worth 10-15 % of the kernel; with deterministic depths the coarse tiles are so coherent (all 32 rays at the same depth)
-    // that the 13 GB of parking traffic per frame cancels the gain.  Default: cache iff perturb; HAV_FINE=cache|recompute forces.
-    // With feature parking (fp16 mode) the parking stream is half as large and the cache pays with deterministic depths as well.
-    const char* e = getenv("HAV_FINE");
-    if (e && !strcmp(e, "recompute")) return false;
-    const bool forced = e && !strcmp(e, "cache");
-    if (!forced && !p->perturb && mlp_prec(p) != 2) return false;
-    if (!use_block_kernel(p) || !use_split_mfma(p) || p->S_f <= 0 || !p->workspace) return false;
+    if (!fine_cache_applies(p) || !p->workspace) return false;
     return p->workspace_bytes >= (uint64_t)march_grid_blocks(p) * MARCH_WAVES * fine_cache_slot_floats(p) * sizeof(float);
 }
 extern "C" int64_t hav_render_workspace_bytes(const HavRenderParams* p)
 {
-    if (!p || p->S_f <= 0 || p->S_c < 2 || p->R < 0 || p->B < 1) return 0;
-    if (!use_block_kernel(p) || !use_split_mfma(p)) return 0;
-    { const char* e = getenv("HAV_FINE"); if (e ? strcmp(e, "cache") != 0 : (!p->perturb && mlp_prec(p) != 2)) return 0; }
+    if (!p || p->R < 0 || p->B < 1 || !fine_cache_applies(p)) return 0;
     return (int64_t)march_grid_blocks(p) * MARCH_WAVES * fine_cache_slot_floats(p) * (int64_t)sizeof(float);
 }
 
-// 0 = exact f32 MFMA, 1 = bf16 triple split, 2 = fp16 double split
-static int mlp_prec(const HavRenderParams* p)
+// THE decision function: which kernel instantiation renders a call.  hav_render_rays launches what this returns and
+// hav_render_variant_name prints it, so a test that asserts a name asserts what ran.
+//   rm   0: no random numbers, 1: device streams only (production), 2: injected tensors where given (parity tests), else device
+//   prec 0: exact fp32 MFMA, 1: bf16 triple split, 2: fp16 double split
+//   cm   0: every merged fine sample is evaluated, 1: fine-pass cache, 2: cache + fine maps only (coarse outputs declined)
+// fp16 + cache + coarse outputs (<., 2, 1>) does not exist: that combination carries 64 more live accumulators through the
+// feature projection of parked tiles and ran into the MFMA operand hazard of DESIGN.md 3.5 under 240-280 spilled VGPRs; a
+// caller that wants the coarse maps in fp16 mode gets every merged sample evaluated instead.
+struct MarchVariant { bool blk; int rm, prec, cm; bool guard; };
+static MarchVariant pick_variant(const HavRenderParams* p, bool no_coarse_out, bool injected)
 {
-    const char* e = getenv("HAV_MLP");                   // A/B override: "f32" / "split" (bf16 x 3) / "half" (fp16 x 2)
-    if (e && e[0] == 'f') return 0;
-    if (e && e[0] == 's') return 1;
-    if (e && e[0] == 'h') return 2;
-    return p->mlp_mode == HAV_MLP_F32 ? 0 : (p->mlp_mode == HAV_MLP_SPLIT_F16 ? 2 : 1);
+    MarchVariant v{};
+    const bool random = p->perturb != 0 || p->noise_std > 0.f;
+    v.blk = use_block_kernel(p);
+    if (!v.blk) { v.rm = random ? 2 : 0; return v; }                       // ray-pair kernel: exact fp32 only
+    v.prec = mlp_prec(p);
+    v.rm = !random ? 0 : ((injected || v.prec == 0) ? 2 : 1);              // (the f32 mode only instantiates the injected-tensor RNG variant)
+    const bool cache = use_fine_cache(p);
+    v.cm = !cache ? 0 : (no_coarse_out ? 2 : (v.prec == 2 ? 0 : 1));
+    v.guard = v.prec == 2 && !(p->flags & HAV_FLAG_NO_FP16_GUARD);
+    return v;
 }
-static bool use_split_mfma(const HavRenderParams* p) { return mlp_prec(p) != 0; }
 
-extern "C" const char* hav_render_variant(const HavRenderParams* p, int coarse_outputs)
+extern "C" int hav_render_variant_name(const HavRenderParams* p, int coarse_outputs, int injected_rand, char* buf, int len)
 {
-    if (!p) return "";
-    const bool rnd = p->perturb != 0 || p->noise_std > 0.f;
-    if (!use_block_kernel(p)) return rnd ? "hav_march_f32_kernel<true>" : "hav_march_f32_kernel<false>";
-    static char name[64];
-    const int prec = mlp_prec(p);
-    const bool cache = use_fine_cache(p) && !(prec == 2 && coarse_outputs);      // (fp16: only the fine-maps-only kernels use the cache)
-    const int cm = (cache && !coarse_outputs && (rnd || prec == 2)) ? 2 : (cache ? 1 : 0);
-    const int rm = !rnd ? 0 : (prec == 0 ? 2 : 1);          // (the f32 mode only instantiates the injected-tensor RNG variant)
-    snprintf(name, sizeof(name), "hav_march_blk_kernel<%d, %d, %d>", rm, prec, cm);
-    return name;
+    if (!p || !buf || len < 40) return HAV_EINVAL;
+    const MarchVariant v = pick_variant(p, !coarse_outputs && p->S_f > 0, injected_rand != 0);
+    if (!v.blk) snprintf(buf, (size_t)len, "hav_march_f32_kernel<%s>", v.rm ? "true" : "false");
+    else snprintf(buf, (size_t)len, "hav_march_blk_kernel<%d, %d, %d>", v.rm, v.prec, v.cm);
+    return 0;
+}
+
+template <int R_, int P_, int C_>
+static void launch_blk(int gridb, size_t ldsb, hipStream_t s, const MarchArgs& a)
+{
+    hipLaunchKernelGGL((hav_march_blk_kernel<R_, P_, C_>), dim3(gridb), dim3(MARCH_THREADS), ldsb, s, a);
+}
+struct BlkEntry { int rm, prec, cm; const void* fn; void (*launch)(int, size_t, hipStream_t, const MarchArgs&); };
+#define BLK(R_, P_, C_) {R_, P_, C_, (const void*)hav_march_blk_kernel<R_, P_, C_>, launch_blk<R_, P_, C_>}
+static const BlkEntry kBlk[] = {
+    BLK(0, 0, 0), BLK(2, 0, 0),
+    BLK(0, 1, 0), BLK(1, 1, 0), BLK(2, 1, 0), BLK(0, 1, 1), BLK(1, 1, 1), BLK(2, 1, 1), BLK(0, 1, 2), BLK(1, 1, 2), BLK(2, 1, 2),
+    BLK(0, 2, 0), BLK(1, 2, 0), BLK(2, 2, 0), BLK(0, 2, 2), BLK(1, 2, 2), BLK(2, 2, 2)};
+#undef BLK
+static const BlkEntry* find_blk(int rm, int prec, int cm)
+{
+    for (const BlkEntry& e : kBlk) if (e.rm == rm && e.prec == prec && e.cm == cm) return &e;
+    return nullptr;
 }
 
 extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, const float* bg, const float* inv_T,
@@ -1762,7 +1901,8 @@ extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, cons
     if (p->plane_ch != HAV_PC) return HAV_EUNSUP;                 // Trainer hard-codes triPlane_feat_dim=64 (nerf_trainer.py:22)
     if (p->plane_res < 2 || p->vol_res < 2) return HAV_EINVAL;
     if (p->S_c > 256 || p->S_f > 128) return HAV_EUNSUP;
-    if (p->reserved != 0 || (p->mlp_mode != HAV_MLP_SPLIT_BF16 && p->mlp_mode != HAV_MLP_F32 && p->mlp_mode != HAV_MLP_SPLIT_F16)) return HAV_EINVAL;
+    if ((p->flags & ~HAV_FLAGS_ALL) || ((p->flags & HAV_FLAG_FINE_CACHE) && (p->flags & HAV_FLAG_FINE_RECOMPUTE))) return HAV_EINVAL;
+    if (p->mlp_mode != HAV_MLP_SPLIT_BF16 && p->mlp_mode != HAV_MLP_F32 && p->mlp_mode != HAV_MLP_SPLIT_F16) return HAV_EINVAL;
     // the coarse pass's composited outputs may be declined (all three NULL) when there is a fine pass: Trainer.forward then only
     // uses the fine ones, and the kernel drops the accumulators that exist for them
     const bool no_coarse_out = !out->rgb_coarse && !out->depth_coarse && !out->acc_coarse;
@@ -1771,6 +1911,7 @@ extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, cons
     if (no_coarse_out && !use_block_kernel(p)) return HAV_EUNSUP;          // the ray-pair kernel always writes them
     if (p->S_f > 0 && (!out->rgb_fine || !out->depth_fine || !out->acc_fine)) return HAV_EINVAL;
     if (p->R == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
 
     MarchArgs a;
     a.p = *p;
@@ -1778,9 +1919,11 @@ extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, cons
     a.blob = (const float*)mlp_blob;
     a.t_rand = t_rand; a.u_rand = u_rand; a.noise_c = noise_c; a.noise_f = noise_f;
     a.out = *out;
-    a.dbg_zfine = g_dbg_zfine; g_dbg_zfine = nullptr;
-    { const char* e = getenv("HAV_ABLATE"); a.ablate = e ? atoi(e) : 0; }
-    { const char* e = getenv("HAV_STAGGER"); a.stagger = e ? atoi(e) : 0; }
+    a.dbg_zfine = p->dbg_zfine;
+    a.ablate = env_knobs().ablate;
+    a.stagger = env_knobs().stagger;
+    a.guard = nullptr; a.guard_run_if = 0; a.status = p->status;
+    a.ws = nullptr; a.ws_slot = 0; a.rng_base = 0;
     a.NR = (long long)p->B * p->R;
     a.S_fp = p->S_f > 0 ? (p->S_c + 1) / 2 + p->S_f : 0;
     a.s_pad_c = (p->S_c + 15) & ~15;
@@ -1791,69 +1934,64 @@ extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, cons
     a.o_cand = a.o_cdf + 2 * a.s_pad_c;
     a.o_zf = a.o_cand + 2 * a.s_pad_f;
     a.scr_floats = (a.o_zf + 2 * a.s_pad_f + 3) & ~3;
-    const size_t lds = ((size_t)LDS_FLOATS + (size_t)MARCH_WAVES * a.scr_floats) * sizeof(float);
-    if (lds > 160 * 1024) return HAV_EUNSUP;
 
     const bool random = p->perturb != 0 || p->noise_std > 0.f;
-    static bool attr_set = false;
-    if (!attr_set) {
-        const void* ks[16] = {(const void*)hav_march_f32_kernel<false>, (const void*)hav_march_f32_kernel<true>,
-                              (const void*)hav_march_blk_kernel<0, 0, 0>, (const void*)hav_march_blk_kernel<2, 0, 0>,
-                              (const void*)hav_march_blk_kernel<0, 1, 0>, (const void*)hav_march_blk_kernel<1, 1, 0>,
-                              (const void*)hav_march_blk_kernel<2, 1, 0>, (const void*)hav_march_blk_kernel<0, 1, 1>,
-                              (const void*)hav_march_blk_kernel<1, 1, 1>, (const void*)hav_march_blk_kernel<2, 1, 1>,
-                              (const void*)hav_march_blk_kernel<1, 1, 2>,
-                              (const void*)hav_march_blk_kernel<0, 2, 0>, (const void*)hav_march_blk_kernel<1, 2, 0>,
-                              (const void*)hav_march_blk_kernel<2, 2, 0>,
-                              (const void*)hav_march_blk_kernel<1, 2, 2>, (const void*)hav_march_blk_kernel<0, 2, 2>};
-        for (int i = 0; i < 16; ++i) {
-            hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return (int)e;
+    static std::atomic<unsigned long long> attr_mask{0};
+    int dev;
+    if (!attr_done(attr_mask, dev)) {               // per device: a second GPU driven from the same process needs its own attributes
+        for (const BlkEntry& e : kBlk) {
+            hipError_t er = hipFuncSetAttribute(e.fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (er != hipSuccess) return (int)er;
         }
-        attr_set = true;
+        const void* pk[2] = {(const void*)hav_march_f32_kernel<false>, (const void*)hav_march_f32_kernel<true>};
+        for (int i = 0; i < 2; ++i) {
+            hipError_t er = hipFuncSetAttribute(pk[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (er != hipSuccess) return (int)er;
+        }
+        attr_mask.fetch_or(1ull << dev, std::memory_order_release);
     }
-    if (use_block_kernel(p)) {
+    const bool injected = t_rand || u_rand || noise_c || noise_f;     // parity tests; production draws everything on the device
+    const MarchVariant v = pick_variant(p, no_coarse_out, injected);
+    if (v.blk) {
         a.scr_floats = ((p->S_f > 0 ? p->S_f : 1) * 32 + 3) & ~3;
-        const bool split = use_split_mfma(p);
-        const int precl = mlp_prec(p);
-        const size_t ldsb = ((size_t)(precl == 2 ? LDSH_FLOATS : (precl == 1 ? LDS3_FLOATS : LDS_FLOATS)) + 256 + (size_t)MARCH_WAVES * a.scr_floats) * sizeof(float);
-        if (ldsb > 160 * 1024) return HAV_EUNSUP;
+        auto lds_of = [&](int prec) {
+            return ((size_t)(prec == 2 ? LDSH_FLOATS : (prec == 1 ? LDS3_FLOATS : LDS_FLOATS)) + 256 + (size_t)MARCH_WAVES * a.scr_floats) * sizeof(float);
+        };
+        if (lds_of(v.prec) > 160 * 1024 || (v.guard && lds_of(1) > 160 * 1024)) return HAV_EUNSUP;
         const int gridb = march_grid_blocks(p);
-        const bool injected = t_rand || u_rand || noise_c || noise_f;     // parity tests; production draws everything on the device
-        const int rm = !random ? 0 : (injected ? 2 : 1);
-        // fp16 mode uses the cache only through the fine-maps-only kernels <.,2,2>: the fp16 kernels that carry the composited
-        // coarse outputs AND project parked tiles (<.,2,1>) are not launched -- at full occupancy ~0.4 % of their rays came out
-        // different from run to run (tools/stress_determinism.py, columns 16-31 of a tile: the MFMA operand hazard of DESIGN.md
-        // 3.5 under 240-280 spilled VGPRs); callers that want the coarse maps get every merged sample evaluated instead.
-        const bool cache = use_fine_cache(p) && !(mlp_prec(p) == 2 && !(no_coarse_out && rm != 2));
-        a.ws = cache ? (float*)p->workspace : nullptr;
+        const BlkEntry* main_k = find_blk(v.rm, v.prec, v.cm);
+        if (!main_k) return HAV_EUNSUP;
+        a.ws = v.cm ? (float*)p->workspace : nullptr;
         a.ws_slot = fine_cache_slot_floats(p);
-#define LAUNCH_BLK(R_, P_, C_) hipLaunchKernelGGL((hav_march_blk_kernel<R_, P_, C_>), dim3(gridb), dim3(MARCH_THREADS), ldsb, (hipStream_t)stream, a)
-        const int prec = mlp_prec(p);
-#define LAUNCH_SPLIT(P_)                                                                                                          \
-        do {                                                                                                                      \
-            if (cache && no_coarse_out && rm == 1) LAUNCH_BLK(1, P_, 2);          /* production: jitter, cache, fine maps only */ \
-            else if (cache && no_coarse_out && rm == 0 && P_ == 2) LAUNCH_BLK(0, 2, 2);                                           \
-            else if (cache && P_ != 2) { if (rm == 0) LAUNCH_BLK(0, 1, 1); else if (rm == 1) LAUNCH_BLK(1, 1, 1); else LAUNCH_BLK(2, 1, 1); } \
-            else { if (rm == 0) LAUNCH_BLK(0, P_, 0); else if (rm == 1) LAUNCH_BLK(1, P_, 0); else LAUNCH_BLK(2, P_, 0); }        \
-        } while (0)
-        if (prec == 2) LAUNCH_SPLIT(2);
-        else if (prec == 1) LAUNCH_SPLIT(1);
-        else { if (rm == 0) LAUNCH_BLK(0, 0, 0); else LAUNCH_BLK(2, 0, 0); }
-#undef LAUNCH_SPLIT
-#undef LAUNCH_BLK
+        if (v.guard) {
+            // fp16 range guard (include/havatar.h): the verdict hav_triplane_prepare left in the planes' trailer decides ON THE DEVICE
+            // whether the fp16 kernel or its bf16 stand-in (every merged sample evaluated, no workspace) does the work; the other
+            // one returns at once.  No host round trip, so a captured hipGraph keeps working when weights or planes change.
+            a.guard = reinterpret_cast<const unsigned int*>(planes_prepared + (size_t)2 * p->B * p->plane_res * p->plane_res * 128) + 256;
+            a.guard_run_if = 0;
+        }
+        main_k->launch(gridb, lds_of(v.prec), st, a);
         HAV_LAUNCH_CHECK();
-        if (p->rng_counter && random) { hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)p->rng_counter); HAV_LAUNCH_CHECK(); }
-        return 0;
+        if (v.guard) {
+            const BlkEntry* fb = find_blk(v.rm, 1, 0);
+            if (!fb) return HAV_EUNSUP;
+            a.guard_run_if = 1;
+            a.ws = nullptr;
+            fb->launch(gridb, lds_of(1), st, a);
+            HAV_LAUNCH_CHECK();
+        }
+    } else {
+        const size_t lds = ((size_t)LDS_FLOATS + (size_t)MARCH_WAVES * a.scr_floats) * sizeof(float);
+        if (lds > 160 * 1024) return HAV_EUNSUP;
+        const long long npairs = (a.NR + 1) / 2;
+        int grid = hav_num_cus();
+        const long long need = (npairs + MARCH_WAVES - 1) / MARCH_WAVES;
+        if (need < grid) grid = (int)((need + 7) / 8 * 8);
+        if (random) hipLaunchKernelGGL(hav_march_f32_kernel<true>, dim3(grid), dim3(MARCH_THREADS), lds, st, a);
+        else hipLaunchKernelGGL(hav_march_f32_kernel<false>, dim3(grid), dim3(MARCH_THREADS), lds, st, a);
+        HAV_LAUNCH_CHECK();
     }
-    const long long npairs = (a.NR + 1) / 2;
-    int grid = hav_num_cus();
-    const long long need = (npairs + MARCH_WAVES - 1) / MARCH_WAVES;
-    if (need < grid) grid = (int)((need + 7) / 8 * 8);
-    if (random) hipLaunchKernelGGL(hav_march_f32_kernel<true>, dim3(grid), dim3(MARCH_THREADS), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(hav_march_f32_kernel<false>, dim3(grid), dim3(MARCH_THREADS), lds, (hipStream_t)stream, a);
-    HAV_LAUNCH_CHECK();
-    if (p->rng_counter && random) { hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)p->rng_counter); HAV_LAUNCH_CHECK(); }
+    if (p->rng_counter && random) { hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, st, (unsigned long long*)p->rng_counter); HAV_LAUNCH_CHECK(); }
     return 0;
 }
 

@@ -94,6 +94,16 @@ def make_optimizer(cfg, trainer, graph):
     return getattr(torch.optim, cfg.optimizer.type)([{"params": list(trainer.parameters())}], lr=cfg.optimizer.lr, **kw)
 
 
+def portable_optimizer_state(optimizer):
+    """optimizer.state_dict() with plain-float learning rates: what the reference's checkpoints hold (train_avatar.py:303-316), and
+    what every loader -- eager, graph mode, the reference itself -- restores correctly."""
+    sd = optimizer.state_dict()
+    for g in sd["param_groups"]:
+        if torch.is_tensor(g.get("lr")):
+            g["lr"] = float(g["lr"])
+    return sd
+
+
 def set_learning_rate(optimizer, lr_new):
     for g in optimizer.param_groups:
         if torch.is_tensor(g["lr"]):
@@ -111,9 +121,11 @@ class StepRunner:
         self.graph, self.eager_left, self.graphed, self.side = graph, eager_steps, None, None
         if graph:
             dev = next(trainer.parameters()).device
-            for g in optimizer.param_groups:          # capturable Adam reads a tensor learning rate inside the graph
-                if not torch.is_tensor(g["lr"]):
-                    g["lr"] = torch.tensor(float(g["lr"]), device=dev)
+            for g in optimizer.param_groups:          # capturable Adam reads a DEVICE tensor learning rate inside the graph
+                # always re-made: a rate restored from a checkpoint is a float or a CPU tensor (map_location="cpu"), and a CPU
+                # 0-dim tensor would be baked into the captured graph as a constant -- set_learning_rate() would never reach it
+                if not (torch.is_tensor(g["lr"]) and g["lr"].device == dev):
+                    g["lr"] = torch.as_tensor(float(g["lr"]), dtype=torch.float32, device=dev)
                 if "capturable" in g:
                     g["capturable"] = True            # a checkpoint written by an eager run (or by the reference) restores False
             for st in optimizer.state.values():
@@ -291,7 +303,7 @@ def main(argv=None, device=None):
                 print("Validation loss: %06f Validation PSNR: %06f" % (vloss, vpsnr))
                 trainer.train()
             if i % cfg.experiment.save_every == 0 or i == cfg.experiment.train_iters - 1 or i == start_iter + 1:
-                torch.save({"iter": i, "optimizer_state_dict": optimizer.state_dict(), "loss": loss.detach().clone(), "psnr": psnr,
+                torch.save({"iter": i, "optimizer_state_dict": portable_optimizer_state(optimizer), "loss": loss.detach().clone(), "psnr": psnr,
                             "trainer_state_dict": trainer.state_dict()}, os.path.join(args.logdir, "checkpoint" + str(i).zfill(5) + ".ckpt"))
                 trainer.headpose_skin_net.visualize_motion_weight_vol(os.path.join(args.logdir, "vis_motionWeightVol" + str(i).zfill(5) + ".obj"))
                 print("================== Saved Checkpoint =================")

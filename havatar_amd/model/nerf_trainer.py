@@ -99,8 +99,18 @@ class Trainer(torch.nn.Module):
 
     # ---------------------------------------------------------------------------------------------------------------
     def _use_hip(self, ray_batch):
-        """HIP tensors that do not need gradients go to the fused kernel; there is no silent fallback for them."""
-        return ray_batch.is_cuda and not (torch.is_grad_enabled() and any(p.requires_grad for p in self.model_coarse.layers_xyz.parameters()))
+        """HIP tensors that do not need gradients go to the fused (forward-only) kernel; there is no silent fallback for them.
+        "Do not need gradients" = autograd is off, or nothing this call could differentiate exists: no parameter of the Trainer
+        (MLP, encoders, latent codes, skinning volume) and no input requires grad.  Anything else takes the autograd statement,
+        as the reference would backpropagate there."""
+        if not ray_batch.is_cuda:
+            return False
+        if not torch.is_grad_enabled():
+            return True
+        planes = getattr(self.model_coarse, "triPlane_embeddings", None)
+        if ray_batch.requires_grad or (planes is not None and planes.requires_grad):
+            return False
+        return not any(p.requires_grad for p in self.parameters())
 
     def predict_and_render_radiance(self, mode, ray_batch, background_prior, inv_head_T):
         opt = getattr(self.cfg.nerf, mode)

@@ -56,6 +56,14 @@ class RayMarcher:
         # fine-pass cache: re-use the coarse pass's field values for the even coarse samples the merged list repeats
         self.fine_cache = os.environ.get("HAVATAR_FINE_CACHE", "1") != "0"
         self._workspace = None
+        # per-call switches of the library (HavRenderParams.flags).  The A/B environment variables are read HERE, once per
+        # marcher; the library itself reads no environment on the launch path.
+        self.flags = 0
+        if os.environ.get("HAV_MARCH", "")[:1] == "p":
+            self.flags |= _lib.HAV_FLAG_PAIR_KERNEL
+        self.flags |= {"cache": _lib.HAV_FLAG_FINE_CACHE, "recompute": _lib.HAV_FLAG_FINE_RECOMPUTE}.get(os.environ.get("HAV_FINE", ""), 0)
+        self._status = None          # device word the library ORs HAV_STATUS_* bits into
+        self.last_variant = None     # name of the kernel instantiation the last render() launched
 
     # -- constants -----------------------------------------------------------------------------
     def set_mlp(self, W1, b1, W2, b2, Wa, ba, Wf, bf, Wc, bc, force=False):
@@ -86,8 +94,10 @@ class RayMarcher:
         if two != 2 or Cc != self.plane_ch or H != W:
             raise RuntimeError(f"unsupported tri-plane shape {tuple(p.shape)}")
         self.plane_res = H
-        if self.planes_cl is None or self.planes_cl.shape != (2, B, H, W, 128) or self.planes_cl.device != p.device:
-            self.planes_cl = torch.empty((2, B, H, W, 128), dtype=torch.float32, device=p.device)
+        need = int(_lib.lib().hav_triplane_prepared_bytes(B, H, W)) // 4        # planes + the range-guard trailer
+        if self.planes_cl is None or self.planes_cl.numel() != need or self.planes_cl.device != p.device:
+            self.planes_cl = torch.empty(need, dtype=torch.float32, device=p.device)
+        self._planes_B = B
         with torch.cuda.device(p.device):
             _lib.check(_lib.lib().hav_triplane_prepare(_ptr(self.planes_cl), _ptr(p), _ptr(self.blob), B, Cc, H, W, _stream()),
                        "hav_triplane_prepare")
@@ -113,7 +123,7 @@ class RayMarcher:
         vol = _chk_f32_cuda("canonical_W", skin_vol)
         if vol.dim() == 5:
             vol = vol[0]
-        if self.planes_cl.shape[1] != B or inv_T.shape[0] != B:
+        if self._planes_B != B or inv_T.shape[0] != B:
             raise RuntimeError("batch mismatch between rays, inv_head_T and the tri-plane")
         dev = rays.device
         S_fp = (S_c + 1) // 2 + S_f if S_f > 0 else 0
@@ -125,7 +135,10 @@ class RayMarcher:
             p.nerf_scale[i], p.nerf_trans[i] = self.nerf_scale[i], self.nerf_trans[i]
             p.skin_scale[i], p.skin_trans[i] = self.skin_scale[i], self.skin_trans[i]
         p.seed, p.rng_offset = self.seed, self.rng_offset
-        p.mlp_mode, p.reserved = self.mlp_mode, 0
+        p.mlp_mode, p.flags = self.mlp_mode, self.flags
+        if self._status is None or self._status.device != dev:
+            self._status = torch.zeros(1, dtype=torch.int32, device=dev)
+        p.status = self._status.data_ptr()
         if self.rng_counter is None or self.rng_counter.device != dev:
             self.rng_counter = torch.zeros(1, dtype=torch.int64, device=dev)      # device-side call counter (graph-replay safe)
         p.rng_counter = self.rng_counter.data_ptr()
@@ -163,24 +176,42 @@ class RayMarcher:
         with torch.cuda.device(dev):
             if dbg_zfine and S_fp > 0:
                 zf = e(B * R, S_fp)
-                L.hav_debug_set_zfine(_ptr(zf))
+                p.dbg_zfine = zf.data_ptr()
             rc = L.hav_render_rays(C.byref(p), _ptr(rays), _ptr(bg), _ptr(inv_T), _ptr(self.planes_cl), _ptr(vol),
                                    _ptr(self.blob), _ptr(t_rand), _ptr(u_rand), _ptr(noise_c), _ptr(noise_f),
                                    C.byref(out), _stream())
             _lib.check(rc, "hav_render_rays")
             if _DEBUG_SYNC:
                 torch.cuda.synchronize()
+        self.last_variant = self._variant_of(p, rgb_c is not None, any(t is not None for t in (t_rand, u_rand, noise_c, noise_f)))
         res = (rgb_c, d_c, a_c, wmax, rgb_f, d_f, a_f)
         return res + (zf,) if dbg_zfine else res
 
-    def variant(self, S_c, S_f, perturb=False, noise_std=0.0, coarse_outputs=True):
+    def fp16_fallback_happened(self):
+        """True if, since the last call of this method, the fp16 range guard made the bf16-split kernel render a call
+        (HAV_STATUS_FP16_FALLBACK).  Synchronises: for tests and diagnostics, not for the frame loop."""
+        if self._status is None:
+            return False
+        v = int(self._status.item())
+        self._status.zero_()
+        return bool(v & _lib.HAV_STATUS_FP16_FALLBACK)
+
+    @staticmethod
+    def _variant_of(p, coarse_outputs, injected):
+        buf = C.create_string_buffer(64)
+        _lib.check(_lib.lib().hav_render_variant_name(C.byref(p), int(bool(coarse_outputs)), int(bool(injected)), buf, 64),
+                   "hav_render_variant_name")
+        return buf.value.decode()
+
+    def variant(self, S_c, S_f, perturb=False, noise_std=0.0, coarse_outputs=True, injected=False):
+        """Kernel instantiation a render() with these settings launches (the library's own decision function)."""
         p = _lib.HavRenderParams()
         p.S_c, p.S_f, p.perturb, p.noise_std = S_c, S_f, int(bool(perturb)), float(noise_std)
-        p.mlp_mode = self.mlp_mode
+        p.mlp_mode, p.flags = self.mlp_mode, self.flags
         p.B, p.R = 1, 1 << 18
         if self.fine_cache and S_f > 0:                  # same decision as render(): a workspace is always provided when useful
             p.workspace, p.workspace_bytes = 1, 1 << 62
-        return _lib.lib().hav_render_variant(C.byref(p), int(bool(coarse_outputs))).decode()
+        return self._variant_of(p, coarse_outputs, injected)
 
 
 def gen_rays(H, W, intr, c2w, near, far, device, out=None):

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define HAV_ABI_VERSION 2
+#define HAV_ABI_VERSION 3
 
 #define HAV_EINVAL   (-1) /* bad size / null pointer / inconsistent arguments            */
 #define HAV_EUNSUP   (-2) /* valid for the reference, not supported by this build        */
@@ -160,7 +160,7 @@ typedef struct HavRenderParams {
     uint64_t seed;        /* key of the on-device xi/zeta/eps streams used when the rand pointers are NULL */
     uint64_t rng_offset;  /* counter base of the on-device streams (advance per call)          */
     int32_t mlp_mode;     /* HAV_MLP_SPLIT_BF16 (0), HAV_MLP_F32 (1) or HAV_MLP_SPLIT_F16 (2)   */
-    int32_t reserved;     /* must be 0                                                         */
+    int32_t flags;        /* HAV_FLAG_* bit mask (0 = library defaults); unknown bits -> HAV_EINVAL */
     uint64_t* rng_counter; /* optional DEVICE counter: the call uses rng_offset + *rng_counter and increments the counter
                             * on the stream afterwards, so a hipGraph replay of a captured call draws fresh jitter    */
     void*    workspace;    /* optional DEVICE scratch, hav_render_workspace_bytes() bytes: the fine pass then re-uses the
@@ -169,7 +169,19 @@ typedef struct HavRenderParams {
                             * NULL / too small: every merged sample is evaluated, like the reference does.  In the fp16
                             * mode the workspace is used by calls that decline the coarse outputs (HavRenderOut) only.    */
     uint64_t workspace_bytes;
+    float*   dbg_zfine;    /* optional DEVICE [B*R, S_fp] (tests): the call also dumps the merged, sorted fine depths here  */
+    uint32_t* status;      /* optional DEVICE word; the call ORs HAV_STATUS_* bits into it on the stream (the caller zeroes it) */
 } HavRenderParams;
+
+/* HavRenderParams.flags */
+#define HAV_FLAG_PAIR_KERNEL     1   /* force the ray-pair kernel (otherwise only used when num_coarse > 67); A/B runs and tests */
+#define HAV_FLAG_FINE_CACHE      2   /* force the fine-pass cache on where a workspace is offered (default: see workspace above)   */
+#define HAV_FLAG_FINE_RECOMPUTE  4   /* never use the fine-pass cache                                                               */
+#define HAV_FLAG_NO_FP16_GUARD   8   /* HAV_MLP_SPLIT_F16 only: skip the range guard below (the caller vouches for the range)       */
+#define HAV_FLAGS_ALL           15
+
+/* HavRenderParams.status bits */
+#define HAV_STATUS_FP16_FALLBACK 1u  /* the fp16-split kernel declined (range guard) and the bf16-split kernel rendered the call  */
 
 /* How the two dense layers run on the matrix cores.  All three produce fp32-sgemm-class results (parity tests run all):
  *  HAV_MLP_SPLIT_BF16: each fp32 operand is split exactly into 3 bf16 parts and the 6 leading bf16 x bf16 products are
@@ -179,8 +191,15 @@ typedef struct HavRenderParams {
 #define HAV_MLP_F32        1
 #define HAV_MLP_SPLIT_F16  2     /* each fp32 operand = hi + lo fp16 (both rounded to nearest: <= 2^-22 relative -- the size of the
                                   * fp32 accumulation error of a 128-term dot product), 3 products on v_mfma_f32_32x32x16_f16:
-                                  * half the matrix time and two thirds of the LDS of the bf16 triple split.  Needs weights and
-                                  * hidden activations below 65504 in magnitude (fp16 range); the Python layer's default. */
+                                  * half the matrix time and two thirds of the LDS of the bf16 triple split; the Python layer's
+                                  * default.  RANGE: fp16 tops out at 65504.  hav_triplane_prepare derives a rigorous bound on
+                                  * every value this mode converts to fp16 (weights, relu(h1), relu(h2)) from the weights and the
+                                  * projected planes -- |h1_u| <= |b1_u| + sum_k |W1pe_uk| + max_texel |P0_u| + max_texel |P1_u|,
+                                  * |h2_v| <= |b2_v| + sum_u |W2_vu| bound(h1_u) -- and stores the verdict next to the planes; when
+                                  * the bound reaches 60000 (or is not finite) the fp16 kernel declines ON THE DEVICE and the
+                                  * bf16-split kernel (fp32 range) renders the call instead: same launch sequence, no host sync,
+                                  * hipGraph-safe; HavRenderParams.status reports it.  Values below 2^-14 use fp16 subnormals for
+                                  * their low part: absolute operand error <= 2^-25 there instead of 2^-22 relative. */
 
 /* Bytes of scratch with which hav_render_rays can skip the repeated even coarse samples for these parameters
  * (0: not applicable -- no fine pass, exact-f32 mode, or num_coarse > 67). */
@@ -202,7 +221,8 @@ int64_t hav_mlp_blob_bytes(void);
 int hav_mlp_pack(void* blob, const HavMlpWeights* w, void* stream);
 
 /* Per-frame tri-plane preparation.  Input: NCHW [2,B,64,H,W] (Trainer.model_coarse.triPlane_embeddings,
- * model/nerf_model.py:85-86).  Output (device, hav_triplane_prepared_bytes(B,H,W) bytes): 128 floats per texel of
+ * model/nerf_model.py:85-86).  Output (device, hav_triplane_prepared_bytes(B,H,W) bytes: the planes + a 2-KB trailer holding the
+ * per-unit maxima and the fp16 range verdict described at HAV_MLP_SPLIT_F16): 128 floats per texel of
  * [2,B,H,W] in which every texel has already been multiplied by the 128x64 block of layers_xyz.0 that reads this
  * plane's channels (bilinear interpolation and the first linear layer commute), stored in the ray-march kernel's
  * accumulator order.  Needs the packed blob (hav_mlp_pack) of the CURRENT weights: re-run when planes OR weights change.
@@ -228,7 +248,7 @@ typedef struct HavRenderOut {      /* all device pointers, float32; fine pointer
  *                                                the only consumer is dead code, nerf_trainer.py:146-150)
  * bg        [B,R,3] or NULL                     (background_prior)
  * inv_T     [B,4,3]                             (inv_head_T: rows 0-2 = M, row 3 = tau)
- * planes    prepared planes, 2*B*H*W*128 floats (hav_triplane_prepare; layout private to the library)
+ * planes    prepared planes, hav_triplane_prepared_bytes() bytes (hav_triplane_prepare; layout private to the library)
  * skin_vol  [2,D,H,W]                           (canonical_W[0], shared by the batch)
  * mlp_blob  hav_mlp_pack output
  * t_rand    [B,R,S_c] or NULL                   (xi  = torch.rand at nerf_trainer.py:138)
@@ -244,13 +264,11 @@ int hav_render_rays(const HavRenderParams* p, const float* rays, const float* bg
                     const float* noise_c, const float* noise_f, const HavRenderOut* out,
                     void* stream);
 
-/* Test hook: the NEXT hav_render_rays call additionally dumps the merged, sorted fine depths
- * [B*R, S_fp] to `dev_ptr` (device memory); one-shot, cleared by that call. */
-void hav_debug_set_zfine(float* dev_ptr);
-
-/* Name of the ray-march kernel variant a call with these parameters would launch (for profiles); coarse_outputs = 0 if the
- * call declines the coarse pass's composited outputs (rgb/depth/acc_coarse NULL in HavRenderOut). */
-const char* hav_render_variant(const HavRenderParams* p, int coarse_outputs);
+/* Name of the ray-march kernel variant hav_render_rays launches for these parameters ("hav_march_blk_kernel<RNG, PREC, CACHE>",
+ * the same decision function the launch uses), written NUL-terminated into buf[len].  coarse_outputs = 0 if the call declines
+ * the coarse pass's composited outputs (rgb/depth/acc_coarse NULL in HavRenderOut); injected_rand != 0 if any of
+ * t_rand / u_rand / noise_c / noise_f is given.  Returns 0, or HAV_EINVAL (NULL arguments / buffer too small). */
+int hav_render_variant_name(const HavRenderParams* p, int coarse_outputs, int injected_rand, char* buf, int len);
 
 /* ------------------------------------------------------------------------------------------
  * get_rays on device (next-1; reference: dataloader/data_util.py:28-56 +

@@ -19,8 +19,9 @@ class HavRenderParams(C.Structure):
                 ("plane_res", C.c_int32), ("plane_ch", C.c_int32), ("vol_res", C.c_int32),
                 ("nerf_scale", C.c_float * 3), ("nerf_trans", C.c_float * 3),
                 ("skin_scale", C.c_float * 3), ("skin_trans", C.c_float * 3),
-                ("seed", C.c_uint64), ("rng_offset", C.c_uint64), ("mlp_mode", C.c_int32), ("reserved", C.c_int32),
-                ("rng_counter", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64)]
+                ("seed", C.c_uint64), ("rng_offset", C.c_uint64), ("mlp_mode", C.c_int32), ("flags", C.c_int32),
+                ("rng_counter", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64),
+                ("dbg_zfine", C.c_void_p), ("status", C.c_void_p)]
 
 
 class HavMlpWeights(C.Structure):

@@ -32,8 +32,9 @@ def load_render_fixture(name):
 
 
 def hip_render(sc, S_c, S_f, perturb=False, noise_std=0.0, t_rand=None, u_rand=None, noise_c=None, noise_f=None,
-               dbg_zfine=False, mlp="half"):
-    """Run the HIP ray march (through the C ABI) on a synth-style scene; returns numpy outputs keyed like OUT_KEYS."""
+               dbg_zfine=False, mlp="half", coarse_outputs=True, flags=None):
+    """Run the HIP ray march (through the C ABI) on a synth-style scene; returns numpy outputs keyed like OUT_KEYS, plus
+    "variant" (the kernel instantiation that was launched) and "fp16_fallback" (did the fp16 range guard hand over to bf16)."""
     import torch
     from havatar_amd.render import RayMarcher
     dev = torch.device("cuda:0")
@@ -41,16 +42,20 @@ def hip_render(sc, S_c, S_f, perturb=False, noise_std=0.0, t_rand=None, u_rand=N
     from havatar_amd import _lib
     rm = RayMarcher(sc["nerf_scale"], sc["nerf_trans"], sc["skin_scale"], sc["skin_trans"])
     rm.mlp_mode = {"f32": _lib.HAV_MLP_F32, "half": _lib.HAV_MLP_SPLIT_F16}.get(mlp, _lib.HAV_MLP_SPLIT_BF16)
+    if flags is not None:
+        rm.flags = flags
     m = sc["mlp"]
     rm.set_mlp(*[t(m[k]) for k in ("W1", "b1", "W2", "b2", "Wa", "ba", "Wf", "bf", "Wc", "bc")])
     rm.set_triplane(t(sc["planes"]))
     res = rm.render(t(sc["rays"]), t(sc["bg"]), t(sc["inv_T"]), t(sc["vol"]), S_c, S_f, perturb=perturb,
                     noise_std=noise_std, t_rand=t(t_rand), u_rand=t(u_rand), noise_c=t(noise_c), noise_f=t(noise_f),
-                    dbg_zfine=dbg_zfine)
+                    dbg_zfine=dbg_zfine, coarse_outputs=coarse_outputs)
     torch.cuda.synchronize()
     out = {k: (None if v is None else v.cpu().numpy().reshape(v.shape[0], v.shape[1], -1)) for k, v in zip(OUT_KEYS, res)}
     if dbg_zfine:
         out["z_fine"] = res[7].cpu().numpy()
+    out["variant"] = rm.last_variant
+    out["fp16_fallback"] = rm.fp16_fallback_happened()
     return out
 
 

@@ -40,12 +40,35 @@ def test_out_size_helper_matches_reference_formula():
     assert L.hav_upfirdn2d_out_size(4, 4, 9, 9, 1, 1, 1, 1, 0, 0, 0, 0, ctypes.byref(oh), ctypes.byref(ow)) == -1
 
 
-def test_struct_layouts_match_header():
+def test_struct_layouts_match_header(tmp_path):
+    """The ctypes mirrors (product binding and the oracle's) against the C compiler's view of include/havatar.h:
+    sizeof and the offset of every field."""
+    import subprocess
     from havatar_amd import _lib
     from oracle import oracle
-    assert ctypes.sizeof(_lib.HavRenderParams) == 136 == ctypes.sizeof(oracle.HavRenderParams)
-    assert ctypes.sizeof(_lib.HavMlpWeights) == 80
-    assert ctypes.sizeof(_lib.HavRenderOut) == 56
+    structs = {"HavRenderParams": (_lib.HavRenderParams, oracle.HavRenderParams), "HavMlpWeights": (_lib.HavMlpWeights, oracle.HavMlpWeights),
+               "HavRenderOut": (_lib.HavRenderOut,), "HavFieldParams": (_lib.HavFieldParams,)}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "havatar.h"', 'int main(void) {']
+    for name, mirrors in structs.items():
+        lines.append('printf("%s sizeof %%zu\\n", sizeof(%s));' % (name, name))
+        for f, _ in mirrors[0]._fields_:
+            lines.append('printf("%s %s %%zu\\n", offsetof(%s, %s));' % (name, f, name, f))
+    lines.append("return 0; }")
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    seen = 0
+    for ln in subprocess.check_output([str(exe)]).decode().split("\n"):
+        if not ln:
+            continue
+        name, field, val = ln.split()
+        for m in structs[name]:
+            got = ctypes.sizeof(m) if field == "sizeof" else getattr(m, field).offset
+            assert got == int(val), (name, field, m.__module__, got, int(val))
+            seen += 1
+    assert seen > 60
+    assert ctypes.sizeof(_lib.HavRenderParams) == 152
 
 
 def test_product_never_imports_oracle():

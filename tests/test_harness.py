@@ -201,11 +201,67 @@ def test_training_cli_gpu_graph_mode_runs_validates_and_resumes(tmp_path, datase
     assert last == 4
     ck = torch.load(log / "checkpoint00000.ckpt", map_location="cpu", weights_only=False)
     assert set(ck) == {"iter", "optimizer_state_dict", "loss", "psnr", "trainer_state_dict"} and np.isfinite(float(ck["loss"]))
+    assert all(isinstance(g["lr"], float) for g in ck["optimizer_state_dict"]["param_groups"])     # reference-compatible: plain floats
     last = train.main(["--logdir", str(log), "--datadir", dataset[0], "--config", cfg_path, "--ckpt", str(log / "checkpoint00000.ckpt"),
                        "--max-steps", "4"], device="cuda")
     assert last == 4
     out = capsys.readouterr().out
     assert "Validation loss" in out and "nan" not in out.lower()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("restored_lr", ["float", "cpu_tensor"])
+def test_graph_mode_learning_rate_reaches_the_replayed_step_after_resume(restored_lr):
+    """A resumed run's optimiser state holds the rate as a float (this harness, the reference) or as a CPU tensor (graph-mode
+    checkpoints of the previous revision, loaded with map_location="cpu").  StepRunner must turn either into a DEVICE tensor before
+    capture: a CPU 0-dim rate is baked into the captured Adam update as a constant and the exponential decay is lost.  Checked on
+    the parameter trajectory: with the rate set to 0 a replayed step must not move the weights; with it restored it must."""
+    from havatar_amd.harness import train
+    from havatar_amd.utils.cfgnode import CfgNode
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net = torch.nn.Linear(8, 8).to(dev)
+
+    class _T(torch.nn.Module):                   # the smallest "trainer" StepRunner's graph path accepts
+        def __init__(self):
+            super().__init__()
+            self.net = net
+    cfg = CfgNode({"optimizer": {"type": "Adam", "lr": 1e-2}})
+    tr = _T()
+    opt = train.make_optimizer(cfg, tr, graph=True)
+    sd = opt.state_dict()
+    for g in sd["param_groups"]:
+        g["lr"] = 1e-2 if restored_lr == "float" else torch.tensor(1e-2)
+        g["capturable"] = False                    # what an eager / reference checkpoint restores
+    opt.load_state_dict(sd)
+    runner = train.StepRunner(tr, cfg, opt, torch.nn.functional.mse_loss, graph=True)
+    assert all(torch.is_tensor(g["lr"]) and g["lr"].is_cuda for g in opt.param_groups)
+    from havatar_amd.graph import GraphedTrainStep
+    x = torch.randn(4, 8, device=dev)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            opt.zero_grad(set_to_none=True)
+            net(x).square().mean().backward()
+            opt.step()
+        opt.zero_grad(set_to_none=True)
+    torch.cuda.current_stream().wait_stream(side)
+    g = GraphedTrainStep(lambda x: (net(x).square().mean(), {}), opt, {"x": x})
+    w0 = net.weight.detach().clone()
+    g(x=x)
+    torch.cuda.synchronize()
+    moved = (net.weight.detach() - w0).abs().max().item()
+    assert moved > 1e-4
+    train.set_learning_rate(opt, 0.0)
+    w1 = net.weight.detach().clone()
+    g(x=x)
+    torch.cuda.synchronize()
+    assert torch.equal(net.weight.detach(), w1), "the replayed update ignored the new learning rate"
+    train.set_learning_rate(opt, 1e-2)
+    g(x=x)
+    torch.cuda.synchronize()
+    assert not torch.equal(net.weight.detach(), w1)
 
 
 @pytest.mark.gpu

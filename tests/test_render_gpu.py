@@ -19,12 +19,42 @@ TOL = dict(rgb_coarse=2e-5, depth_coarse=1e-4, acc_coarse=2e-5, weights_max=1e-3
 MLP_MODES = ("half", "split", "f32")      # the three matrix-core modes of the MLP (include/havatar.h: HAV_MLP_SPLIT_F16 / _SPLIT_BF16 / _F32)
 
 
+PREC = {"f32": 0, "split": 1, "half": 2}
+FINE_KEYS = ("weights_max", "rgb_fine", "depth_fine", "acc_fine")
+
+
+def expected_variant(cfg, kw, mlp, coarse_outputs, cache=None):
+    """The instantiation hav_render_rays must pick (include/havatar.h + pick_variant in hav_render.hip), spelled out independently:
+    <RNG mode, arithmetic, cache mode>.  cache=None: the library default (fp16: always, bf16: iff jitter, f32: never)."""
+    random = cfg["perturb"] or cfg["noise_std"] > 0
+    prec = PREC[mlp]
+    rm = 0 if not random else (2 if (kw or prec == 0) else 1)
+    if cache is None:
+        cache = prec == 2 or (prec == 1 and cfg["perturb"])
+    cache = cache and prec != 0 and cfg["S_f"] > 0
+    cm = 0 if not cache else (2 if not coarse_outputs else (0 if prec == 2 else 1))
+    return "hav_march_blk_kernel<%d, %d, %d>" % (rm, prec, cm)
+
+
+@pytest.mark.parametrize("coarse_outputs", [True, False])
 @pytest.mark.parametrize("mlp", MLP_MODES)
 @pytest.mark.parametrize("name", RENDER)
-def test_hip_vs_reference_golden(name, mlp):
+def test_hip_vs_reference_golden(name, mlp, coarse_outputs):
+    """Every reference fixture (incl. stress, white noise, wide FOV, B=2 with injected jitter + density noise) through every kernel
+    family: with the coarse maps (<., ., 0|1>) and declining them (<., ., 2>: the production path -- fine-pass cache, feature parking,
+    stage A/B), in all three arithmetic modes, with the injected random tensors reaching the cache kernels (<2, ., 2>)."""
     g, sc, cfg, kw = load_render_fixture(name)
-    o = hip_render(sc, mlp=mlp, **cfg, **kw)
+    if not coarse_outputs and cfg["S_f"] == 0:
+        pytest.skip("coarse outputs can only be declined when there is a fine pass")
+    o = hip_render(sc, mlp=mlp, coarse_outputs=coarse_outputs, **cfg, **kw)
+    assert o["variant"] == expected_variant(cfg, kw, mlp, coarse_outputs), o["variant"]
+    assert not o["fp16_fallback"], "the fixtures are far inside the fp16 range: the guard must not trip"
+    declined = o["variant"].endswith(", 2>")          # (without a cache kernel the library hands the coarse maps out anyway)
+    assert declined == (not coarse_outputs and (mlp == "half" or (mlp == "split" and cfg["perturb"])))
     for k in OUT_KEYS:
+        if declined and k not in FINE_KEYS:
+            assert o[k] is None, k
+            continue
         if "ref_" + k in g.files:
             assert np.isfinite(o[k]).all(), k
             assert linf(o[k], g["ref_" + k]) <= TOL[k], (k, linf(o[k], g["ref_" + k]))
@@ -83,15 +113,17 @@ def test_split_and_f32_mlp_modes_agree():
 
 
 @pytest.mark.parametrize("kernel", ["blk", "pair"])
-def test_pair_kernel_still_matches(kernel, monkeypatch):
-    """HAV_MARCH=pair forces the ray-pair kernel (used when S_c > 67): same results within the path tolerance."""
+def test_pair_kernel_still_matches(kernel):
+    """HAV_FLAG_PAIR_KERNEL forces the ray-pair kernel (used when S_c > 67): same results within the path tolerance."""
     from oracle import oracle
-    monkeypatch.setenv("HAV_MARCH", kernel)
+    from havatar_amd import _lib
     sc = synth.scene(12, 12, "primary")
-    o = hip_render(sc, 64, 16, mlp="f32")
+    o = hip_render(sc, 64, 16, mlp="f32", flags=_lib.HAV_FLAG_PAIR_KERNEL if kernel == "pair" else 0)
+    assert o["variant"] == ("hav_march_f32_kernel<false>" if kernel == "pair" else "hav_march_blk_kernel<0, 0, 0>")
     r = oracle.render_rays(sc, 64, 16, nthreads=4)
     assert linf(o["rgb_coarse"], r["rgb_coarse"]) <= 2e-5 and linf(o["rgb_fine"], r["rgb_fine"]) <= 1e-3
     big = hip_render(sc, 80, 16, mlp="f32")           # S_c = 80 > 67: the library itself falls back to the pair kernel
+    assert big["variant"] == "hav_march_f32_kernel<false>"
     rb = oracle.render_rays(sc, 80, 16, nthreads=4)
     assert linf(big["rgb_coarse"], rb["rgb_coarse"]) <= 2e-5 and linf(big["rgb_fine"], rb["rgb_fine"]) <= 1e-3
 
@@ -110,7 +142,7 @@ def test_bitwise_reproducible_and_ray_order_invariant():
 
 
 @pytest.mark.parametrize("coarse_outputs", [True, False])
-@pytest.mark.parametrize("perturb", [False, True])
+@pytest.mark.parametrize("perturb", [False, True, "injected"])
 @pytest.mark.parametrize("mlp", MLP_MODES)
 def test_full_occupancy_runs_are_bitwise_identical(mlp, perturb, coarse_outputs):
     """Eight launches of a 256x256 frame (every CU busy, thousands of tiles per SIMD) give bit-identical outputs, for every
@@ -121,8 +153,8 @@ def test_full_occupancy_runs_are_bitwise_identical(mlp, perturb, coarse_outputs)
     import torch
     from havatar_amd import _lib
     from havatar_amd.render import RayMarcher
-    if mlp == "f32" and perturb:
-        pytest.skip("the exact-f32 kernels only take injected jitter tensors")
+    if mlp == "f32" and perturb is True:
+        pytest.skip("the exact-f32 kernels only instantiate the injected-tensor RNG variant (covered by perturb='injected')")
     N = 256
     sc = synth.scene(8, 8, "primary")
     dev = torch.device("cuda:0")
@@ -134,18 +166,23 @@ def test_full_occupancy_runs_are_bitwise_identical(mlp, perturb, coarse_outputs)
     rays = t(synth.camera_rays(N, N))[None]
     bg = torch.ones(1, N * N, 3, device=dev)
     args = (rays, bg, t(sc["inv_T"]), t(sc["vol"]), 64, 16)
+    kw = {}
+    if perturb == "injected":         # the variants the parity tests run (<2, ., .>), at full occupancy
+        gen = torch.Generator(device="cpu").manual_seed(11)
+        kw = dict(t_rand=torch.rand(1, N * N, 64, generator=gen).to(dev), u_rand=torch.rand(N * N, 16, generator=gen).to(dev))
 
     def launch():
         if rm.rng_counter is not None:
             rm.rng_counter.zero_()
-        out = rm.render(*args, perturb=perturb, coarse_outputs=coarse_outputs)
+        out = rm.render(*args, perturb=bool(perturb), coarse_outputs=coarse_outputs, **kw)
         torch.cuda.synchronize()
         return [o.clone() if o is not None else None for o in out]
 
     ref = launch()
+    assert ("<2," in rm.last_variant) == (perturb == "injected"), rm.last_variant
     for _ in range(7):
         for a, b in zip(ref, launch()):
-            assert (a is None and b is None) or torch.equal(a, b), rm.variant(64, 16, perturb=perturb, coarse_outputs=coarse_outputs)
+            assert (a is None and b is None) or torch.equal(a, b), rm.last_variant
 
 
 def test_background_linearity_and_ranges():
@@ -245,31 +282,39 @@ def test_bad_arguments_raise():
         rm.render(t(sc["rays"]), t(sc["bg"]), t(sc["inv_T"]), t(sc["vol"]), 64, 16, t_rand=t(np.zeros((3,))), perturb=True)
 
 
+@pytest.mark.parametrize("coarse_outputs", [True, False])
+@pytest.mark.parametrize("mlp", ["half", "split"])
 @pytest.mark.parametrize("name", [n for n in RENDER if "coarse_only" not in n])
-def test_fine_pass_cache_matches_reference_and_the_recompute_path(name, monkeypatch):
+def test_fine_pass_cache_matches_reference_and_the_recompute_path(name, mlp, coarse_outputs):
     """HavRenderParams.workspace: the fine pass re-uses the coarse pass's field values for the even coarse samples the merged list
-    repeats (model/nerf_trainer.py:170) instead of evaluating them again.  Forced on for every fixture (the default enables it only
-    with stratified jitter): same golden tolerances, and against the recompute path only fp32 summation-order noise."""
+    repeats (model/nerf_trainer.py:170) instead of evaluating them again.  Forced on (HAV_FLAG_FINE_CACHE) and off
+    (HAV_FLAG_FINE_RECOMPUTE) for every fixture and both split modes, with and without the coarse maps; the names of the two kernels
+    that ran are asserted, so the comparison cannot silently be of a kernel with itself.  Same golden tolerances, and against the
+    recompute path only fp32 summation-order noise."""
+    from havatar_amd import _lib
     g, sc, cfg, kw = load_render_fixture(name)
-    monkeypatch.setenv("HAV_FINE", "cache")
-    o = hip_render(sc, dbg_zfine=cfg["S_f"] > 0, **cfg, **kw)
-    monkeypatch.setenv("HAV_FINE", "recompute")
-    r = hip_render(sc, dbg_zfine=cfg["S_f"] > 0, **cfg, **kw)
-    for k in OUT_KEYS:
+    if mlp == "half" and coarse_outputs:
+        pytest.skip("fp16 mode has no cache kernel that also carries the coarse maps (DESIGN.md 3.5): nothing to compare")
+    o = hip_render(sc, dbg_zfine=True, mlp=mlp, coarse_outputs=coarse_outputs, flags=_lib.HAV_FLAG_FINE_CACHE, **cfg, **kw)
+    r = hip_render(sc, dbg_zfine=True, mlp=mlp, coarse_outputs=coarse_outputs, flags=_lib.HAV_FLAG_FINE_RECOMPUTE, **cfg, **kw)
+    assert o["variant"] == expected_variant(cfg, kw, mlp, coarse_outputs, cache=True), o["variant"]
+    assert r["variant"] == expected_variant(cfg, kw, mlp, coarse_outputs, cache=False), r["variant"]
+    assert o["variant"] != r["variant"]
+    for k in (OUT_KEYS if coarse_outputs else FINE_KEYS):
         if "ref_" + k in g.files:
             assert linf(o[k], g["ref_" + k]) <= TOL[k], (k, linf(o[k], g["ref_" + k]))
             # the two kernel instantiations round the coarse weights differently by an ulp, which the inverse CDF amplifies
             assert linf(o[k], r[k]) <= (2e-6 if "coarse" in k else 0.25 * TOL[k]), (k, linf(o[k], r[k]))
-    if cfg["S_f"] > 0:
-        assert linf(o["z_fine"], r["z_fine"]) <= 2e-3 and np.median(np.abs(o["z_fine"] - r["z_fine"])) <= 1e-6
+    assert linf(o["z_fine"], r["z_fine"]) <= 2e-3 and np.median(np.abs(o["z_fine"] - r["z_fine"])) <= 1e-6
 
 
 def test_fine_pass_cache_is_the_default_with_jitter_and_needs_a_workspace(monkeypatch):
     import torch
+    monkeypatch.delenv("HAV_FINE", raising=False)
+    monkeypatch.delenv("HAV_MARCH", raising=False)
     from havatar_amd.render import RayMarcher
     sc = synth.scene(8, 8, "primary")
     rm = RayMarcher(sc["nerf_scale"], sc["nerf_trans"], sc["skin_scale"], sc["skin_trans"])
-    monkeypatch.delenv("HAV_FINE", raising=False)
     from havatar_amd import _lib
     # fp16 mode (default): the cache serves the fine-maps-only calls (with or without jitter); a call that also wants the coarse
     # maps evaluates every merged sample (the fp16 kernels that would do both are not dispatched, DESIGN.md 3.5).
@@ -277,7 +322,9 @@ def test_fine_pass_cache_is_the_default_with_jitter_and_needs_a_workspace(monkey
     assert rm.variant(64, 16, perturb=True).endswith("2, 0>") and rm.variant(64, 16, perturb=False).endswith("2, 0>")
     assert rm.variant(64, 16, perturb=True, coarse_outputs=False).endswith("<1, 2, 2>")      # production: jitter, cache, fine maps only
     assert rm.variant(64, 16, perturb=False, coarse_outputs=False).endswith("<0, 2, 2>")
+    assert rm.variant(64, 16, perturb=True, coarse_outputs=False, injected=True).endswith("<2, 2, 2>")   # injected jitter reaches the cache path
     rm.mlp_mode = _lib.HAV_MLP_SPLIT_BF16
+    assert rm.variant(64, 16, perturb=True, coarse_outputs=False, injected=True).endswith("<2, 1, 2>")
     assert rm.variant(64, 16, perturb=True).endswith("1, 1>") and rm.variant(64, 16, perturb=False).endswith("1, 0>")
     rm.mlp_mode = _lib.HAV_MLP_SPLIT_F16
     rm.fine_cache = False                                          # no workspace offered -> every merged sample is evaluated
@@ -307,3 +354,80 @@ def test_declined_coarse_outputs_leave_the_fine_maps_unchanged():
             assert lean[0] is None and lean[1] is None and lean[2] is None
         for a_, b_ in zip(full[4:7], lean[4:7]):
             assert (a_ - b_).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("jitter", [False, True])
+def test_full_frame_512_fine_maps_only_cache_kernels_vs_oracle(jitter):
+    """BASELINE config 2 size through the PRODUCTION kernel family (fp16 split, fine-pass cache, feature parking, coarse maps
+    declined): <0, 2, 2> with deterministic depths and <2, 2, 2> with injected jitter (= <1, 2, 2> with the random numbers supplied
+    by the test instead of the device streams), 64 scattered pixels of the 512x512 frame against the oracle on the same inputs."""
+    import torch
+    from oracle import oracle
+    from havatar_amd.render import RayMarcher
+    H = W = 512
+    sc = synth.scene(8, 8, "stress")
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
+    rm = RayMarcher(sc["nerf_scale"], sc["nerf_trans"], sc["skin_scale"], sc["skin_trans"])
+    rm.set_mlp(*[t(sc["mlp"][k]) for k in ("W1", "b1", "W2", "b2", "Wa", "ba", "Wf", "bf", "Wc", "bc")])
+    rm.set_triplane(t(sc["planes"]))
+    rays = t(synth.camera_rays(H, W))[None]
+    bg = torch.ones(1, H * W, 3, device=dev)
+    kw = {}
+    if jitter:
+        gen = torch.Generator(device="cpu").manual_seed(21)
+        kw = dict(t_rand=torch.rand(1, H * W, 64, generator=gen), u_rand=torch.rand(H * W, 16, generator=gen))
+    out = rm.render(rays, bg, t(sc["inv_T"]), t(sc["vol"]), 64, 16, perturb=jitter, coarse_outputs=False,
+                    **{k: v.to(dev) for k, v in kw.items()})
+    torch.cuda.synchronize()
+    assert rm.last_variant == ("hav_march_blk_kernel<2, 2, 2>" if jitter else "hav_march_blk_kernel<0, 2, 2>")
+    assert out[0] is None and all(torch.isfinite(o).all() for o in out[3:7])
+    idx = np.random.default_rng(2).choice(H * W, 64, replace=False)
+    sub = dict(sc)
+    sub["rays"] = rays[:, idx].cpu().numpy()
+    sub["bg"] = np.ones((1, 64, 3), np.float32)
+    okw = {k: (v[:, idx] if k == "t_rand" else v[idx]).numpy() for k, v in kw.items()}
+    r = oracle.render_rays(sub, 64, 16, perturb=jitter, nthreads=4, **okw)
+    r64 = oracle.render_rays(sub, 64, 16, perturb=jitter, nthreads=4, f64=True, **okw)
+    # per-ray bar = the path tolerance + 3x the fp32 oracle's own deviation from fp64 at that ray (ill-conditioned rays, SURVEY B-11)
+    for i, k in ((4, "rgb_fine"), (6, "acc_fine")):
+        got = out[i][:, idx].cpu().numpy().astype(np.float64).reshape(64, -1)
+        err = np.abs(got - r64[k].reshape(64, -1)).max(-1)                       # per ray
+        floor = np.abs(r[k].astype(np.float64).reshape(64, -1) - r64[k].reshape(64, -1)).max(-1)
+        assert (err <= 1e-3 + 3.0 * floor).all(), (k, err.max(), floor.max())
+        assert np.median(err) <= 1e-4, (k, np.median(err))
+
+
+def _homogeneous_rescale(mlp, s):
+    """relu is positively homogeneous: (s W1, s b1, W2 / s) is the same network with hidden layer 1 scaled by s."""
+    m = dict(mlp)
+    m["W1"], m["b1"], m["W2"] = mlp["W1"] * np.float32(s), mlp["b1"] * np.float32(s), mlp["W2"] / np.float32(s)
+    return m
+
+
+@pytest.mark.parametrize("coarse_outputs", [True, False])
+def test_fp16_range_guard_hands_over_to_the_bf16_split(coarse_outputs):
+    """HAV_MLP_SPLIT_F16 converts relu(h1), relu(h2) and the weights to fp16 (max 65504).  A checkpoint whose first hidden layer
+    runs at 1e5 (same function as the fixture's: the layer is rescaled homogeneously) must not silently produce inf/NaN pixels:
+    hav_triplane_prepare's rigorous bound trips, the fp16 kernel declines on the device and the bf16-split kernel (fp32 range)
+    renders the call -- bit-identical to asking for the bf16 mode outright -- and the status word says so.  With the guard
+    switched off (HAV_FLAG_NO_FP16_GUARD) the same call really is wrong, i.e. the test scene does leave the fp16 range."""
+    from oracle import oracle
+    from havatar_amd import _lib
+    sc = synth.scene(16, 16, "primary")
+    big = dict(sc)
+    big["mlp"] = _homogeneous_rescale(sc["mlp"], 1.0e5)
+    ok = hip_render(sc, 64, 16, coarse_outputs=coarse_outputs)
+    assert not ok["fp16_fallback"] and ", 2, " in ok["variant"]
+    o = hip_render(big, 64, 16, coarse_outputs=coarse_outputs)
+    assert o["fp16_fallback"] and ", 2, " in o["variant"]          # the fp16 kernel was launched, and declined
+    b = hip_render(big, 64, 16, mlp="split", coarse_outputs=True, flags=_lib.HAV_FLAG_FINE_RECOMPUTE)
+    assert b["variant"] == "hav_march_blk_kernel<0, 1, 0>" and not b["fp16_fallback"]
+    r = oracle.render_rays(big, 64, 16, nthreads=4)
+    for k in (OUT_KEYS if coarse_outputs else FINE_KEYS):
+        assert np.isfinite(o[k]).all(), k
+        assert np.array_equal(o[k], b[k]), k                         # the fallback IS the bf16 kernel
+        assert linf(o[k], r[k]) <= TOL[k], (k, linf(o[k], r[k]))
+    raw = hip_render(big, 64, 16, coarse_outputs=coarse_outputs, flags=_lib.HAV_FLAG_NO_FP16_GUARD)
+    assert not raw["fp16_fallback"]
+    assert (not np.isfinite(raw["rgb_fine"]).all()) or linf(raw["rgb_fine"], r["rgb_fine"]) > 1e-2
