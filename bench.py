@@ -29,6 +29,69 @@ DTYPE = {"half": "f32 (2 x fp16 split-operand MFMA, fp32 accumulate; fp32-sgemm-
 # matrix-core work the kernel actually executes per 32-sample tile: 11 k-chunks x 4 row tiles x 6 products of
 # v_mfma_f32_32x32x16_bf16 (32768 FLOP each), or 352 v_mfma_f32_32x32x2_f32 (4096 FLOP each) in the exact-fp32 mode
 EXEC_FLOP_PER_TILE = {"half": 132 * 32768, "split": 264 * 32768, "f32": 352 * 4096}       # MFMA instructions per 32-query tile x FLOP each
+# feature parking (fp16 cache kernels): the 48 parked tiles of the 80 evaluated per ray block also run fc_rgbFeat on
+# the matrix cores, 8 chunks x 2 row tiles x 3 products = 48 more -> 132 + 48 * 48/80 = 160.8 per evaluated tile (= SQ_INSTS_MFMA)
+PARK_FLOP_PER_TILE = 48 * 32768
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def live_pmc_traffic():
+    """HBM-side bytes per launch of the march kernel, MEASURED NOW: two `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE: they do
+    not fit one pass) over tools/march_once.py, which launches the production kernel on a 512x512 frame and a streaming launch of
+    known size; the counters are scaled by the factors that launch calibrates (MI355X_MICROARCH.md, HBM section: on gfx950
+    FETCH_SIZE reports half the bytes of a 16 B/lane streaming read, WRITE_SIZE is uncalibrated).  None if rocprofv3 is unusable."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None
+    got, cal_meta = {}, None
+    env = dict(os.environ, TMPDIR="/tmp")
+    env.pop("HAV_ABLATE", None)
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="hav_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+                                sys.executable, os.path.join(ROOT, "tools", "march_once.py")], cwd="/tmp", env=env, timeout=300,
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+            for ln in r.stdout.decode(errors="replace").splitlines():
+                if ln.startswith("{") and "calib_kernel" in ln:
+                    cal_meta = json.loads(ln)
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] != counter:
+                        continue
+                    # by full name: in fp16 mode every call also dispatches the range guard's bf16 stand-in, which returns at once
+                    name = row["Kernel_Name"].replace("void ", "").split("(")[0].strip()
+                    key = "calib" if "fba_vec_kernel" in name else name
+                    got.setdefault((key, counter), []).append(float(row["Counter_Value"]))
+        except (subprocess.SubprocessError, OSError, ValueError, KeyError):
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    try:
+        mean = lambda k: sum(got[k]) / len(got[k])
+        mk = cal_meta["march_kernel"]
+        rd = mean((mk, "FETCH_SIZE")) * cal_meta["calib_read_bytes"] / mean(("calib", "FETCH_SIZE"))
+        wr = mean((mk, "WRITE_SIZE")) * cal_meta["calib_write_bytes"] / mean(("calib", "WRITE_SIZE"))
+    except (KeyError, TypeError, ZeroDivisionError):
+        return None
+    return {"bytes": int(rd + wr), "read": int(rd), "write": int(wr), "kernel": cal_meta["march_kernel"],
+            "source": "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/march_once.py in this run, %d launches, "
+                      "calibrated on %s (%.0f B per FETCH KB, %.0f B per WRITE KB)" % (
+                          len(got[(mk, "FETCH_SIZE")]), cal_meta["calib_kernel"],
+                          cal_meta["calib_read_bytes"] / mean(("calib", "FETCH_SIZE")), cal_meta["calib_write_bytes"] / mean(("calib", "WRITE_SIZE")))}
 
 
 def cpu_baseline(sc, rows, threads):
@@ -56,6 +119,7 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=0, help="image rows timed on the CPU (0 = auto, ~15 s)")
     ap.add_argument("--perturb", type=int, default=1, help="stratified jitter on (reference default for inference)")
     ap.add_argument("--graph", type=int, default=1, help="replay the frame as one hipGraph (0 = eager launches)")
+    ap.add_argument("--live-pmc", type=int, default=1, help="measure roofline.traffic in this run (2 rocprofv3 --pmc passes, ~1 min; N=1 only)")
     args = ap.parse_args()
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         # one MIOpen user database / kernel cache per rank: N processes selecting solvers for the same ~40 convolution shapes at
@@ -162,30 +226,78 @@ def main():
     MODE = {"f32": "f32", "split": "split", "bf16": "split"}.get(os.environ.get("HAVATAR_MLP", "half"), "half")
     F32 = MODE == "f32"
 
-    def pmc_traffic(kernel):
-        """HBM-side bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (profiles/*_pmc.json, written by
-        tools/profile.sh: FETCH_SIZE and WRITE_SIZE in separate passes, scaled by the factors calibrated in the same run on a
-        streaming launch of known size -- MI355X_MICROARCH.md, HBM section).  None when no profile of this kernel is committed."""
+    def committed_pmc(kernel):
+        """Newest committed rocprofv3 PMC summary (profiles/*_pmc.json, written by tools/profile.sh) that holds `kernel`."""
         import glob
         import re
         natural = lambda f: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(f))]      # r01_v11 after r01_v9
-        for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc.json")), key=natural, reverse=True):
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), key=natural, reverse=True):
             try:
                 d = json.load(open(f))
-                k, cal = d[kernel.split("(")[0].strip()], d["calibration"]
-                return {"bytes": int(k["FETCH_SIZE"] * cal["read_bytes_per_FETCH_KB"] + k["WRITE_SIZE"] * cal["write_bytes_per_WRITE_KB"]),
-                        "read": int(k["FETCH_SIZE"] * cal["read_bytes_per_FETCH_KB"]), "write": int(k["WRITE_SIZE"] * cal["write_bytes_per_WRITE_KB"]),
-                        "source": "profiles/" + os.path.basename(f)}
+                return d[kernel.split("(")[0].strip()], d["calibration"], "profiles/" + os.path.basename(f)
             except (KeyError, OSError, ValueError):
                 continue
-        return None
+        return None, None, None
+
+    def pmc_traffic(kernel):
+        """HBM-side bytes per launch of `kernel` from the committed summary (FETCH_SIZE and WRITE_SIZE in separate passes, scaled by
+        the factors calibrated in the same run on a streaming launch of known size).  None when no profile of this kernel exists."""
+        k, cal, src = committed_pmc(kernel)
+        if k is None or "FETCH_SIZE" not in k or "WRITE_SIZE" not in k:
+            return None
+        return {"bytes": int(k["FETCH_SIZE"] * cal["read_bytes_per_FETCH_KB"] + k["WRITE_SIZE"] * cal["write_bytes_per_WRITE_KB"]),
+                "read": int(k["FETCH_SIZE"] * cal["read_bytes_per_FETCH_KB"]), "write": int(k["WRITE_SIZE"] * cal["write_bytes_per_WRITE_KB"]),
+                "source": src + " (committed profile, not this run)"}
+
+    def unit_busy(kernel):
+        """Busy fraction of the three units that share this kernel, from the committed counters (per launch; 256 CUs = 1024 SIMDs;
+        GRBM_GUI_ACTIVE is summed over the 8 XCDs): matrix cores SQ_VALU_MFMA_BUSY_CYCLES / 1024, vector ALU SQ_ACTIVE_INST_VALU
+        (quad-cycles) x 4 / 1024, texture addresser (the L1 gather path) TA_TA_BUSY_sum / 256 -- each over the kernel's cycles."""
+        k, _, src = committed_pmc(kernel)
+        if k is None or "GRBM_GUI_ACTIVE" not in k:
+            return None
+        cyc = k["GRBM_GUI_ACTIVE"] / 8.0
+        u = {}
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in k:
+            u["mfma"] = round(k["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / cyc, 3)
+        if "SQ_ACTIVE_INST_VALU" in k:
+            u["valu"] = round(k["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / cyc, 3)
+        if "TA_TA_BUSY_sum" in k:
+            u["ta"] = round(k["TA_TA_BUSY_sum"] / 256.0 / cyc, 3)
+        if "SQ_INSTS_MFMA" in k:
+            u["mfma_instructions_per_launch"] = int(k["SQ_INSTS_MFMA"])
+        u["source"] = src
+        return u
+
+    # exact-fp32 arithmetic mode (v_mfma_f32_32x32x2_f32, bit-for-bit an fmaf chain) beside the headline: same frame, same jitter setting
+    f32_ms = None
+    if rank == 0 and MODE != "f32":
+        from havatar_amd import _lib
+        from havatar_amd.render import RayMarcher
+        mf = RayMarcher(m.nerf_scale, m.nerf_trans, m.skin_scale, m.skin_trans)
+        mf.mlp_mode = _lib.HAV_MLP_F32
+        with torch.no_grad():
+            mf.set_mlp(*[t_.detach() for t_ in tr.model_coarse.mlp_tensors()])
+            mf.set_triplane(tr.model_coarse.triPlane_embeddings.detach())
+            f32_ms = timed(lambda: mf.render(rays, bg, poses[0], vol, S_C, S_F, perturb=perturb, coarse_outputs=False), 3)
+        f32_variant = mf.last_variant
 
     if rank == 0:
         kname = rm.variant(S_C, S_F, perturb=perturb, coarse_outputs=False)
-        traffic = pmc_traffic(kname)
+        traffic = (live_pmc_traffic() if (args.live_pmc and world == 1) else None) or pmc_traffic(kname)
+        busy = unit_busy(kname)
         # field evaluations the kernel actually executes per ray: with the fine-pass cache (variants <.., 1> / <.., 2>, DESIGN.md 3.7)
         # the 32 even coarse samples that the merged fine list repeats are not evaluated again
-        q_exec = (S_C + S_F) if kname.endswith((", 1>", ", 2>")) else Q_PER_RAY
+        cached = kname.endswith((", 1>", ", 2>"))
+        q_exec = (S_C + S_F) if cached else Q_PER_RAY
+        tiles = H * W * q_exec // 32
+        exec_flop = EXEC_FLOP_PER_TILE[MODE] * tiles
+        if MODE == "half" and cached:                  # feature parking: fc_rgbFeat on the matrix cores for the 48 parked tiles of a block
+            exec_flop += PARK_FLOP_PER_TILE * (H * W // 32) * ((S_C + 1) // 2 + S_F)
+        peak = PEAK_FP32_MFMA if F32 else PEAK_BF16_MFMA
+        # which unit is actually busiest (committed counters of this variant): the label the fraction below must be read with
+        names = {"ta": "ta (texture addresser = the L1 gather path of the 8 tri-plane taps)", "mfma": "mfma", "valu": "valu"}
+        busiest = max((k for k in ("ta", "mfma", "valu") if busy and k in busy), key=lambda k: busy[k], default=None)
         res = {
             "metric": "rendered frames/sec @512^2, 64 samples/ray", "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
@@ -196,26 +308,36 @@ def main():
                        "phase_ms": {"encoders_P3": round(enc_ms, 3), "plane_prepare": round(prep_ms, 3), "ray_march_kernel": round(kern_ms, 3)},
                        "rays_per_frame": H * W, "num_coarse": S_C, "num_fine": S_F, "perturb": perturb, "hipgraph": bool(args.graph),
                        "parallelism": "frames sharded, %d rank(s), no data-path collective" % world,
-                       "kernel": rm.variant(S_C, S_F, perturb=perturb, coarse_outputs=False)},
-            "roofline": {"bound": "mfma", "achieved": round(FLOP_PER_FRAME / (kern_ms * 1e-3) / 1e12, 3),
-                         "peak": (PEAK_FP32_MFMA if F32 else PEAK_BF16_MFMA) / 1e12,
-                         "unit": "TFLOP/s", "frac": round(FLOP_PER_FRAME / (kern_ms * 1e-3) / (PEAK_FP32_MFMA if F32 else PEAK_BF16_MFMA), 4),
+                       "kernel": kname},
+            "roofline": {"bound": "mfma", "busiest_unit": names.get(busiest), "unit_busy": busy,
+                         "achieved": round(FLOP_PER_FRAME / (kern_ms * 1e-3) / 1e12, 3), "peak": peak / 1e12,
+                         "unit": "TFLOP/s", "frac": round(FLOP_PER_FRAME / (kern_ms * 1e-3) / peak, 4),
                          "traffic": traffic["bytes"] if traffic else None, "traffic_detail": traffic,
                          "kernel_ms": round(kern_ms, 3), "flop_per_launch": FLOP_PER_FRAME,
                          "frac_of_fp32_mfma_peak": round(FLOP_PER_FRAME / (kern_ms * 1e-3) / PEAK_FP32_MFMA, 4),
-                         "note": "achieved = ALGORITHMIC fp32 FLOP of the reference network (94848/query) / kernel time; peak = the dense peak "
-                                 "of the matrix pipe the kernel runs on (16-bit MFMA 2.5 PFLOP/s in the split modes, where one fp32 product "
-                                 "costs 3 (fp16) or 6 (bf16) 16-bit products; fp32 MFMA 157.3 TFLOP/s in exact mode).  Against the fp32 MFMA "
-                                 "peak the same number is frac_of_fp32_mfma_peak (> 1: the kernel removes 52% of the reference's work by "
-                                 "linearity, DESIGN.md 3.3, re-uses the even coarse samples in the fine pass, 3.7, and runs the rest on the "
-                                 "16-bit pipe)",
+                         "note": "the path's only dense contraction is the radiance MLP, so the roofline is priced in FLOP ('bound': mfma): "
+                                 "achieved = ALGORITHMIC fp32 FLOP of the reference network (94848/query x 112 x 262144) / kernel time; peak = the "
+                                 "dense peak of the matrix pipe the kernel runs on (16-bit MFMA 2.5 PFLOP/s in the split modes, where one fp32 "
+                                 "product costs 3 (fp16) or 6 (bf16) 16-bit products; fp32 MFMA 157.3 TFLOP/s in exact mode).  The matrix cores "
+                                 "are NOT what limits the kernel: unit_busy (rocprofv3 counters of the committed profile) names the busiest "
+                                 "unit -- the texture addresser serving the tri-plane gather -- and mfma_executed_* counts what the matrix "
+                                 "cores really execute (SQ_INSTS_MFMA).  Against the fp32 MFMA peak the algorithmic number is "
+                                 "frac_of_fp32_mfma_peak (> 1: 52% of the reference's matrix work is removed by linearity, DESIGN.md 3.3, the "
+                                 "fine pass re-uses the even coarse samples, 3.7, and the rest runs on the 16-bit pipe)",
                          "field_evaluations_per_ray": {"reference": Q_PER_RAY, "executed": q_exec},
-                         "mfma_executed_TFLOPs": round(EXEC_FLOP_PER_TILE[MODE] * (H * W * q_exec // 32) / (kern_ms * 1e-3) / 1e12, 2),
-                         "mfma_executed_frac_of_peak": round(EXEC_FLOP_PER_TILE[MODE] * (H * W * q_exec // 32) / (kern_ms * 1e-3) /
-                                                             (PEAK_FP32_MFMA if F32 else PEAK_BF16_MFMA), 4),
+                         "mfma_executed_TFLOPs": round(exec_flop / (kern_ms * 1e-3) / 1e12, 2),
+                         "mfma_executed_frac_of_peak": round(exec_flop / (kern_ms * 1e-3) / peak, 4),
+                         "mfma_instructions_per_launch_model": exec_flop // (4096 if F32 else 32768),
                          "hbm_algorithmic_bytes_per_launch": BYTES_PER_FRAME,
                          "hbm_achieved_GBps": round(BYTES_PER_FRAME / (kern_ms * 1e-3) / 1e9, 2), "hbm_frac_of_8TBps": round(BYTES_PER_FRAME / (kern_ms * 1e-3) / 8e12, 5)},
         }
+        if f32_ms is not None:
+            step_ms = 1e3 * dt / args.steps
+            res["exact_f32_mode"] = {"kernel": f32_variant, "kernel_ms": round(f32_ms, 3),
+                                     "frames_per_s_est": round(1e3 / (step_ms - kern_ms + f32_ms), 2),
+                                     "roofline_frac_of_fp32_mfma_peak": round(FLOP_PER_FRAME / (f32_ms * 1e-3) / PEAK_FP32_MFMA, 4),
+                                     "note": "HAVATAR_MLP=f32: v_mfma_f32_32x32x2_f32 (an fmaf chain per dot product) instead of the emulated-fp32 "
+                                             "split; same frame; estimate = this run's step time with the march kernel time swapped"}
         if not args.no_cpu_baseline:
             threads = os.cpu_count() or 1
             rows = args.cpu_rows or 4
@@ -223,9 +345,15 @@ def main():
             if not args.cpu_rows and took < 5.0:             # scale the sample to ~15 s of CPU work
                 rows = int(min(H, max(4, rows * 15.0 / max(took, 1e-3)))) // 4 * 4
                 est, took = cpu_baseline(sc, rows, threads)
+            # one core: rows scaled so that it is ~10 s of work for one thread
+            rows1 = max(1, min(rows, int(round(rows * 10.0 / max(took * threads * 0.6, 1e-3)))))
+            est1, took1 = cpu_baseline(sc, rows1, 1)
             res["cpu_baseline"] = {"value": round(1.0 / est, 5), "unit": "frames/s", "cores": threads, "kind": "port",
+                                   "cpu_model": cpu_model(),
                                    "sample": "%d of %d image rows (%d rays) of the same frame, oracle/hav_oracle.c with OpenMP, "
-                                             "%.1f s measured, scaled to a full frame" % (rows, H, rows * W, took)}
+                                             "%.1f s measured, scaled to a full frame" % (rows, H, rows * W, took),
+                                   "one_core": {"value": round(1.0 / est1, 6), "unit": "frames/s", "cores": 1,
+                                                "sample": "%d image row(s) (%d rays), 1 thread, %.1f s measured, scaled to a full frame" % (rows1, rows1 * W, took1)}}
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
