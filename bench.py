@@ -6,6 +6,14 @@ torch.distributed.run with one rank per GPU (backend nccl == RCCL).  One "step" 
 frame of synthetic input per rank: 512x512 rays x (64 coarse + 48 fine) MLP queries (BASELINE.json configs[1]);
 frames are independent, so N ranks render N frames per step with no data-path collective ("weak" scaling).
 Rank 0 prints ONE JSON line.
+
+Other workloads (not what the driver runs; same JSON contract):
+  --workload cfg3 [--frames 64]   BASELINE configs[2]: a batch of 64 frames dealt round-robin to the ranks (8 per GPU on 8 GPUs), finished
+                                  RGB frames all-gathered round by round over RCCL WHILE the next frame renders
+                                  (frames.OverlappedFrameGather); one step = one batch, total work fixed -> "scaling": "strong".
+  --workload cfg5                 BASELINE configs[4]: train_avatar.py's optimisation step, 2 frames x 4096 rays x (64 + 48) samples,
+                                  forward + backward + Adam as one hipGraph launch, radiance MLP forward/backward on bf16 MFMA.
+  --device cpu [--size 16]        plumbing mode for the tests: CPU tensors, gloo, no HIP library; exercises the N > 1 branch without GPUs.
 """
 import argparse
 import json
@@ -16,7 +24,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-H = W = 512
+H = W = 512                                            # (--size overrides, plumbing mode only)
 S_C, S_F = 64, 16
 Q_PER_RAY = S_C + (S_C + 1) // 2 + S_F                 # 112 MLP queries per ray
 FLOP_PER_QUERY = 2 * (176 * 128 + 128 * 128 + 128 * 1 + 128 * 64 + 64 * 3)      # 94 848
@@ -32,6 +40,8 @@ EXEC_FLOP_PER_TILE = {"half": 132 * 32768, "split": 264 * 32768, "f32": 352 * 40
 # feature parking (fp16 cache kernels): the 48 parked tiles of the 80 evaluated per ray block also run fc_rgbFeat on
 # the matrix cores, 8 chunks x 2 row tiles x 3 products = 48 more -> 132 + 48 * 48/80 = 160.8 per evaluated tile (= SQ_INSTS_MFMA)
 PARK_FLOP_PER_TILE = 48 * 32768
+CFG3_NOTE = ("cfg3: one step = a batch of %d frames dealt round-robin to %d rank(s) (%d per rank); each frame is the cfg2 workload below; the "
+             "finished RGB frame of round r ([3,512,512] fp32 = 3.1 MB per rank) is all-gathered over RCCL while round r+1 renders")
 
 
 def cpu_model():
@@ -110,6 +120,74 @@ def cpu_baseline(sc, rows, threads):
     return dt * (H / rows), dt
 
 
+def run_cfg5(args):
+    """BASELINE configs[4]: one optimisation step of train_avatar.py (reference train_avatar.py:106-158) -- B = 2 frames x 4096 rays
+    (a 64x64 patch each) x (64 coarse + 48 fine) samples = 917 504 radiance-MLP queries, forward + backward + Adam, stratified
+    jitter and density noise on -- replayed as ONE hipGraph launch.  The radiance MLP runs forward and backward on hand-written
+    bf16-MFMA kernels (hav_mlp_*), recomputing activations in the backward; the rest of the step is DESIGN.md section 7."""
+    import tempfile
+
+    import numpy as np
+    import torch
+    from havatar_amd import synth
+    from havatar_amd.dataloader.dataloader import Loader
+    from havatar_amd.harness import train
+    from havatar_amd.model.nerf_trainer import Trainer
+    from havatar_amd.utils.cfgnode import CfgNode
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        raise SystemExit("cfg5 is a single-GPU workload (the reference trains on one GPU; DP is not part of the north star)")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    torch.backends.cudnn.benchmark = True
+    tmp = tempfile.mkdtemp()
+    split = synth.write_dataset(tmp, n_frames=2, img_res=512)
+    cfgd = synth.harness_config(render_size=128, gen_size=512, img_res=512, perturb=True, noise_std=0.1, rays=4096)
+    cfgd["experiment"]["patch_rgb"] = True            # 64x64 patch = 4096 rays per frame, as the reference trains (dataloader.py:43)
+    cfg = CfgNode(cfgd)
+    np.random.seed(0)
+    torch.manual_seed(0)
+    tl = Loader(split_file=split, mode="train", batch_size=2, num_workers=0, down_sample=cfg.dataset.down_sample, options=cfg,
+                white_bg=True, shuffle=False)
+    idx, batch = next(iter(tl))
+    trainer = synth.fill_state_dict(Trainer(cfg, len(tl.dataset))).to(dev).train()
+    use_graph = bool(args.graph) and train.graph_training_enabled(dev)
+    opt = train.make_optimizer(cfg, trainer, use_graph)
+    inp, target, mask = train.step_inputs(idx, batch, dev)
+    runner = train.StepRunner(trainer, cfg, opt, torch.nn.functional.mse_loss, graph=use_graph)
+    for _ in range(max(args.warmup, 4)):              # 2 eager steps (solver search, optimiser state), capture, first replays
+        runner(inp, target, mask)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = runner(inp, target, mask)[0]
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    rays = inp["ray_batch"].shape[0] * inp["ray_batch"].shape[1]
+    queries = rays * Q_PER_RAY
+    from havatar_amd.native import mlp_train
+    info = mlp_train.bench_kernels(trainer.model_coarse, queries, dev)          # HIP events around the MLP kernels alone, same shapes
+    flop = 3 * FLOP_PER_QUERY * queries                                        # forward + (data + weight) gradients = 3x forward (SURVEY 8a)
+    kern_s = info["fwd_ms"] * 1e-3 + info["bwd_ms"] * 1e-3
+    res = {"metric": "train_avatar.py optimisation steps/s (2 x 4096 rays x 64+48 samples, fwd + bwd + Adam)", "value": round(1.0 / dt, 3),
+           "unit": "steps/s", "n_gpus": 1, "steps": args.steps, "warmup": max(args.warmup, 4), "ms_per_step": round(1e3 * dt, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "bf16 (radiance MLP operands, fp32 accumulate and fp32 master weights; encoders / compositing / optimiser fp32)",
+           "data": "synthetic",
+           "config": {"workload": "cfg5: Trainer.forward(mode=train) + loss (train_avatar.py:121-146 without LPIPS) + backward + Adam, "
+                                  "B=2 x 4096 rays, perturb on, radiance_field_noise_std 0.1", "rays": rays, "queries": queries,
+                      "hipgraph": use_graph, "loss": round(float(loss), 6), "mlp_mode": info["mode"],
+                      "phase_ms": {"mlp_forward_2_passes": round(info["fwd_ms"], 3), "mlp_backward_2_passes": round(info["bwd_ms"], 3)}},
+           "roofline": {"bound": "mfma", "achieved": round(flop / kern_s / 1e12, 2), "peak": PEAK_BF16_MFMA / 1e12, "unit": "TFLOP/s",
+                        "frac": round(flop / kern_s / PEAK_BF16_MFMA, 4), "traffic": None, "flop_per_step": flop,
+                        "hbm_algorithmic_bytes": info["bytes"], "hbm_achieved_GBps": round(info["bytes"] / kern_s / 1e9, 1),
+                        "hbm_frac_of_8TBps": round(info["bytes"] / kern_s / 8e12, 4),
+                        "note": "the dominant kernels of the path under training = the radiance MLP forward + backward (hav_mlp_fwd / "
+                                "hav_mlp_bwd_data / hav_mlp_bwd_weights); achieved = 3 x 94848 FLOP x queries / their summed time; at 917 504 "
+                                "queries the contraction is small (261 GFLOP) and the kernels stream X / dX / activations: both fractions "
+                                "are reported"}}
+    print(json.dumps(res))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,7 +198,20 @@ def main():
     ap.add_argument("--perturb", type=int, default=1, help="stratified jitter on (reference default for inference)")
     ap.add_argument("--graph", type=int, default=1, help="replay the frame as one hipGraph (0 = eager launches)")
     ap.add_argument("--live-pmc", type=int, default=1, help="measure roofline.traffic in this run (2 rocprofv3 --pmc passes, ~1 min; N=1 only)")
+    ap.add_argument("--workload", choices=["cfg2", "cfg3", "cfg5"], default="cfg2")
+    ap.add_argument("--frames", type=int, default=64, help="cfg3: frames per batch (one step = one batch)")
+    ap.add_argument("--device", choices=["cuda", "cpu"], default="cuda")
+    ap.add_argument("--size", type=int, default=512, help="frame edge in pixels (plumbing mode)")
     args = ap.parse_args()
+    global H, W, FLOP_PER_FRAME, BYTES_PER_FRAME
+    H = W = args.size
+    FLOP_PER_FRAME = FLOP_PER_QUERY * Q_PER_RAY * H * W
+    BYTES_PER_FRAME = 600 * H * W + 8388608 + 2097152 + 190992
+    if args.workload == "cfg5":
+        return run_cfg5(args)
+    cpu = args.device == "cpu"
+    if cpu:
+        args.graph, args.live_pmc, args.no_cpu_baseline = 0, 0, True
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         # one MIOpen user database / kernel cache per rank: N processes selecting solvers for the same ~40 convolution shapes at
         # the same time otherwise queue on the locks of one shared sqlite file
@@ -141,11 +232,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     torch.backends.cudnn.benchmark = True                      # MIOpen: pick the fastest solver per conv shape during warm-up
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if cpu:
+        dev = torch.device("cpu")
+        torch.set_num_threads(max(1, (os.cpu_count() or 2) // max(world, 1) // 2))
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if cpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)        # backend "nccl" IS RCCL on ROCm
+    sync = (lambda: None) if cpu else torch.cuda.synchronize
 
     from havatar_amd import synth
     from havatar_amd.model.nerf_trainer import Trainer
@@ -177,32 +276,63 @@ def main():
         from havatar_amd.graph import GraphedForward
         frame = GraphedForward(tr, data)                       # the whole frame = one hipGraph launch (+ the pose copy)
 
+        def render(pose):
+            return frame(inv_head_T=pose)
+    else:
+        def render(pose):
+            with torch.no_grad():
+                return tr(**{**data, "inv_head_T": pose})
+
+    if args.workload == "cfg3":
+        # one step = one batch of --frames frames: this rank renders frames rank, rank + N, ...; the finished RGB frame of round r is
+        # all-gathered (RCCL over xGMI) while round r + 1 renders; every rank ends the step holding the whole batch
+        from havatar_amd.frames import OverlappedFrameGather
+        gather = OverlappedFrameGather(args.frames, (3, H, W), device=dev)
+        batch_poses = {k: t(synth.frame_pose(k % 64))[None] for k in range(rank, args.frames, world)}
+
         def step(i):
-            return frame(inv_head_T=poses[i % len(poses)])
+            for r in range(gather.rounds):
+                k = gather.my_frame(r)
+                gather.submit(r, None if k is None else render(batch_poses[k])[0][0, :3])
+            return gather.finalize()
+        frames_per_step = args.frames
     else:
         def step(i):
-            with torch.no_grad():
-                return tr(**{**data, "inv_head_T": poses[i % len(poses)]})
+            return render(poses[i % len(poses)])
+        frames_per_step = world
 
     for i in range(args.warmup):
         step(i)
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(i)
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    fps = world * args.steps / dt
+    fps = frames_per_step * args.steps / dt
+    if cpu:
+        # plumbing mode: no kernels to profile; report the contract fields and what the collective moved
+        if rank == 0:
+            print(json.dumps({"metric": "rendered frames/sec @%d^2, 64 samples/ray" % H, "value": round(fps, 4), "unit": "frames/s",
+                              "n_gpus": 0, "ranks": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+                              "scaling": "strong" if args.workload == "cfg3" else "weak", "vs_baseline": None, "dtype": "f32",
+                              "data": "synthetic", "config": {"workload": args.workload + " (CPU plumbing mode: PyTorch statement of the path, gloo)",
+                                                               "frames_per_step": frames_per_step, "size": H,
+                                                               "gathered": list(out.shape) if args.workload == "cfg3" else None}}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     # ---- outside the timed region: per-phase device times (HIP events on the launch stream = torch's current stream) ----
     def timed(fn, n):
@@ -301,13 +431,16 @@ def main():
         res = {
             "metric": "rendered frames/sec @512^2, 64 samples/ray", "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE[MODE], "data": "synthetic",
-            "config": {"workload": "cfg2: Trainer.forward(render_full_img=True) for one 512x512 frame per GPU per step: tri-plane encoders "
+            "higher_is_better": True, "scaling": "strong" if args.workload == "cfg3" else "weak", "vs_baseline": None, "dtype": DTYPE[MODE],
+            "data": "synthetic",
+            "config": {"batch": CFG3_NOTE % (args.frames, world, -(-args.frames // world)) if args.workload == "cfg3" else None,
+                       "workload": "cfg2: Trainer.forward(render_full_img=True) for one 512x512 frame per GPU per step: tri-plane encoders "
                                    "(P3: 2x StyleGAN_zxc, MIOpen convs + HIP upfirdn2d/fused_bias_act) -> per-frame plane projection -> fused "
                                    "ray march (P5-P12) over 262144 rays x (64 coarse + 48 fine) = 29.36M radiance-MLP queries -> [1,67,512,512]",
                        "phase_ms": {"encoders_P3": round(enc_ms, 3), "plane_prepare": round(prep_ms, 3), "ray_march_kernel": round(kern_ms, 3)},
                        "rays_per_frame": H * W, "num_coarse": S_C, "num_fine": S_F, "perturb": perturb, "hipgraph": bool(args.graph),
-                       "parallelism": "frames sharded, %d rank(s), no data-path collective" % world,
+                       "parallelism": ("frames sharded, %d rank(s), one overlapped all_gather of finished frames per round" if args.workload == "cfg3"
+                                       else "frames sharded, %d rank(s), no data-path collective") % world,
                        "kernel": kname},
             "roofline": {"bound": "mfma", "busiest_unit": names.get(busiest), "unit_busy": busy,
                          "achieved": round(FLOP_PER_FRAME / (kern_ms * 1e-3) / 1e12, 3), "peak": peak / 1e12,
@@ -332,7 +465,7 @@ def main():
                          "hbm_achieved_GBps": round(BYTES_PER_FRAME / (kern_ms * 1e-3) / 1e9, 2), "hbm_frac_of_8TBps": round(BYTES_PER_FRAME / (kern_ms * 1e-3) / 8e12, 5)},
         }
         if f32_ms is not None:
-            step_ms = 1e3 * dt / args.steps
+            step_ms = 1e3 * dt / args.steps / (frames_per_step / world)           # per frame of this rank
             res["exact_f32_mode"] = {"kernel": f32_variant, "kernel_ms": round(f32_ms, 3),
                                      "frames_per_s_est": round(1e3 / (step_ms - kern_ms + f32_ms), 2),
                                      "roofline_frac_of_fp32_mfma_peak": round(FLOP_PER_FRAME / (f32_ms * 1e-3) / PEAK_FP32_MFMA, 4),

@@ -66,9 +66,98 @@ def test_frame_sharding_two_ranks_gloo(n_frames):
     assert sorted(seen) == list(range(n_frames))          # every frame rendered exactly once
 
 
+def _trainer_worker(rank, world, port, n_frames, q):
+    """Every rank builds the SAME Trainer (key-derived weights) and renders its frames of the batch through the real CPU path
+    (Trainer.forward: encoders -> planes -> march), handing each finished frame to OverlappedFrameGather."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(2)
+    from havatar_amd.frames import OverlappedFrameGather
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    render_one, S = _trainer_renderer()
+    g = OverlappedFrameGather(n_frames, (3, S, S), device="cpu")
+    for r in range(g.rounds):
+        k = g.my_frame(r)
+        g.submit(r, None if k is None else render_one(k))
+    out = g.finalize()
+    q.put((rank, out.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _trainer_renderer(S=6):
+    from havatar_amd import synth
+    from havatar_amd.model.nerf_trainer import Trainer
+    from havatar_amd.utils.cfgnode import CfgNode
+    cfg = CfgNode(synth.harness_config(render_size=S, gen_size=4 * S, img_res=S))
+    v = cfg.nerf.validation
+    v.num_coarse, v.num_fine, v.perturb, v.radiance_field_noise_std = 16, 8, False, 0.0
+    torch.manual_seed(0)
+    tr = synth.fill_state_dict(Trainer(cfg, 1).requires_grad_(False)).eval()
+    tr.headpose_skin_net.fix_canonical_W()
+    front, left, right = [torch.from_numpy(a) for a in synth.cond_images()]
+    rays = torch.from_numpy(synth.camera_rays(S, S))[None]
+    bg = torch.ones(1, S * S, 3)
+
+    def render_one(k):
+        with torch.no_grad():
+            render, _, _ = tr(ray_batch=rays, background_prior=bg, inv_head_T=torch.from_numpy(synth.frame_pose(k))[None],
+                              front_render_cond=front, left_render_cond=left, right_render_cond=right, mode="validation", fidx=0,
+                              render_full_img=True)
+        return render[0, :3].contiguous()
+    return render_one, S
+
+
+@pytest.mark.parametrize("n_frames", [3, 4])
+def test_real_trainer_frames_through_the_overlapped_gather_two_ranks_gloo(n_frames):
+    """cfg3 as the product runs it, at toy size on CPU: 2 processes, each renders its round-robin share of the batch with the real
+    Trainer and the round-r all_gather overlaps round r+1; every rank ends up with the whole batch, equal to a single-process
+    render of the same frames (3 frames: the last round has an idle rank that contributes padding)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_trainer_worker, args=(r, 2, port, n_frames, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=240) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    render_one, S = _trainer_renderer()
+    ref = torch.stack([render_one(k) for k in range(n_frames)], 0).numpy()
+    assert np.abs(ref[0] - ref[1]).max() > 1e-4            # the frames of the batch really differ (head pose)
+    assert np.array_equal(res[0][1], res[1][1])             # every rank holds the same batch, bit for bit
+    for rank, out in res:                                   # (the single-process reference runs with another thread count: fp32 noise)
+        assert out.shape == ref.shape and np.abs(out - ref).max() <= 2e-5, rank
+
+
 def test_shard_frames_partition():
     from havatar_amd.frames import shard_frames
     for n, w in ((64, 8), (7, 3), (1, 1), (3, 8)):
         parts = [shard_frames(n, r, w) for r in range(w)]
         assert sorted(sum(parts, [])) == list(range(n))
         assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+@pytest.mark.parametrize("workload", ["cfg2", "cfg3"])
+def test_bench_multi_rank_branch_runs_under_gloo(workload):
+    """bench.py's N > 1 branch (process group, barrier-bracketed timing, MAX over ranks, rank 0 prints one JSON line; for cfg3 the
+    round-by-round overlapped all_gather) executed for real: 2 processes under torch.distributed.run, CPU tensors, gloo."""
+    import json
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--device", "cpu", "--size", "8", "--workload", workload, "--frames", "3"]
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d["ranks"] == 2 and d["steps"] == 1 and d["value"] > 0 and d["unit"] == "frames/s"
+    if workload == "cfg3":
+        assert d["scaling"] == "strong" and d["config"]["frames_per_step"] == 3 and d["config"]["gathered"] == [3, 3, 8, 8]
+    else:
+        assert d["scaling"] == "weak" and d["config"]["frames_per_step"] == 2
