@@ -36,6 +36,10 @@ class HavMlpWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("W1", "b1", "W2", "b2", "Wa", "ba", "Wf", "bf", "Wc", "bc")]
 
 
+class HavMlpGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("W1", "b1", "W2", "b2", "Wa", "ba", "Wf", "bf", "Wc", "bc")]
+
+
 class HavRenderOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("rgb_coarse", "depth_coarse", "acc_coarse", "weights_max",
                                           "rgb_fine", "depth_fine", "acc_fine")]
@@ -88,6 +92,17 @@ def lib():
     L.hav_mlp_blob_bytes.restype = i64
     L.hav_mlp_pack.argtypes = [vp, C.POINTER(HavMlpWeights), vp]
     L.hav_mlp_pack.restype = i32
+    L.hav_mlp_train_blob_bytes.restype = i64
+    L.hav_mlp_train_ops_bytes.argtypes = [i64]
+    L.hav_mlp_train_ops_bytes.restype = i64
+    L.hav_mlp_train_partial_bytes.argtypes = [i64]
+    L.hav_mlp_train_partial_bytes.restype = i64
+    L.hav_mlp_train_pack.argtypes = [vp, C.POINTER(HavMlpWeights), vp]
+    L.hav_mlp_train_pack.restype = i32
+    L.hav_mlp_train_fwd.argtypes = [vp, vp, vp, i64, vp]
+    L.hav_mlp_train_fwd.restype = i32
+    L.hav_mlp_train_bwd.argtypes = [vp, C.POINTER(HavMlpGrads), i32, vp, vp, vp, vp, vp, i64, vp]
+    L.hav_mlp_train_bwd.restype = i32
     L.hav_triplane_prepare.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
     L.hav_triplane_prepare.restype = i32
     L.hav_triplane_prepared_bytes.argtypes = [i32, i32, i32]

@@ -128,7 +128,15 @@ class ConditionalTriplaneNeRFModel_multiRender_split_view(nn.Module):
         return self.mlp(torch.cat([pts_feat, self.pos_embedder(xyz)], -1), dirs)
 
     def mlp(self, x, dirs=None):
-        """x [n, 2C+48] = cat(features, encoding) -> [n, rgb(3) | feat(64) | alpha(1)]: the layers of forward() (:106-117)."""
+        """x [n, 2C+48] = cat(features, encoding) -> [n, rgb(3) | feat(64) | alpha(1)]: the layers of forward() (:106-117).
+
+        HIP tensors in the training path (HAVATAR_TRAIN_MLP=bf16, the default; BASELINE config 5): one autograd node on the bf16
+        matrix cores, activations recomputed in the backward (native/mlp_train.py).  HAVATAR_TRAIN_MLP=torch keeps the fp32
+        nn.Linear statement (rocBLAS), which is what CPU tensors always take."""
+        if (x.is_cuda and x.dtype == torch.float32 and x.ndim == 2 and x.shape[1] == 176 and self.sh_deg == 0 and x.shape[0] >= 1024
+                and torch.is_grad_enabled() and os.environ.get("HAVATAR_TRAIN_MLP", "bf16") == "bf16"):
+            from ..native.mlp_train import fused_mlp
+            return fused_mlp(x, self.mlp_tensors())
         for layer in self.layers_xyz:
             x = self.relu(_linear(layer, x))
         alpha = _linear(self.fc_alpha, x)

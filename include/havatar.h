@@ -135,6 +135,30 @@ int hav_composite_bwd(float* d_rf, const float* d_rgb, const float* d_acc, const
                       int S, int CH, int n_sigmoid, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Radiance MLP of the training path on the bf16 matrix cores (BASELINE config 5) -- replaces, under
+ * autograd, the five nn.Linear calls of ConditionalTriplaneNeRFModel_multiRender_split_view.forward (model/nerf_model.py:104-117):
+ *   X [n,176] = cat(tri-plane features, positional encoding)  ->  rf [n,68] = [rgb(3) | feature(64) | alpha(1)]
+ * and their backward with the activations RECOMPUTED from X (nothing is saved between forward and backward but X itself):
+ *   d_rf [n,68]  ->  dX [n,176] (nullable), gradients of all ten parameter tensors in nn.Linear layout.
+ * Operands (weights and activations) are rounded to bf16, accumulation / inputs / outputs / master weights are fp32.
+ * The weight gradients are summed over fixed query slices in a fixed order: bit-reproducible, no atomics.
+ * Scratch (caller-allocated, contents irrelevant): `ops` hav_mlp_train_ops_bytes(n) bytes, `partial` hav_mlp_train_partial_bytes(n).
+ * `blob` = hav_mlp_train_pack(weights), hav_mlp_train_blob_bytes() bytes; re-pack whenever the weights change.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct HavMlpGrads {           /* device pointers, float32, nn.Linear layouts (same order as HavMlpWeights) */
+    float* W1; float* b1; float* W2; float* b2; float* Wa; float* ba; float* Wf; float* bf; float* Wc; float* bc;
+} HavMlpGrads;
+struct HavMlpWeights;
+int64_t hav_mlp_train_blob_bytes(void);
+int64_t hav_mlp_train_ops_bytes(int64_t n);
+int64_t hav_mlp_train_partial_bytes(int64_t n);
+int hav_mlp_train_pack(void* blob, const struct HavMlpWeights* w, void* stream);
+int hav_mlp_train_fwd(float* rf, const float* X, const void* blob, int64_t n, void* stream);
+/* accumulate != 0: grads += (autograd's accumulation into .grad); 0: grads = */
+int hav_mlp_train_bwd(float* dX, const HavMlpGrads* grads, int accumulate, const float* X, const float* d_rf, const void* blob,
+                      void* ops, void* partial, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Ray march -- replaces Trainer.predict_and_render_radiance (model/nerf_trainer.py:120-201) and
  * everything it calls: ray sampling (:129-141), Deformation_Field_new.forward
  * (model/Skinning_Field.py:70-98), sample_pts_triplane_feat (model/nerf_model.py:88-99),

@@ -289,9 +289,13 @@ def test_reenactment_cli_gpu(tmp_path, dataset, gold):
 
 
 @pytest.mark.gpu
-def test_training_step_gpu(dataset, gold):
-    """H2 on the device (autograd through the PyTorch statement of the march + the HIP custom ops of the encoders)."""
-    _check_step(*_train_step(dataset, gold, "det", "cuda"), gold, "det", rtol=2e-3)
+@pytest.mark.parametrize("mlp,rtol", [("torch", 2e-3), ("bf16", 2e-2)])
+def test_training_step_gpu(dataset, gold, monkeypatch, mlp, rtol):
+    """H2 on the device against the reference's autograd (loss, its parts, gradients of MLP / planes / latent codes / volume decoder /
+    encoder convs): with the fp32 nn.Linear statement of the radiance MLP at 2e-3, and with the bf16-MFMA kernels of BASELINE
+    config 5 (hav_mlp_train_*, the default) at the relaxed 2e-2 SURVEY 8(a) H2 states for the bf16 build."""
+    monkeypatch.setenv("HAVATAR_TRAIN_MLP", mlp)
+    _check_step(*_train_step(dataset, gold, "det", "cuda"), gold, "det", rtol=rtol)
 
 
 @pytest.mark.gpu
@@ -299,6 +303,7 @@ def test_training_step_gpu_fused_field_ops_equal_the_aten_statement(dataset, gol
     """The same jittered, noisy step (same device RNG stream) through hav_field_inputs / hav_composite and through the ATen
     statement of the march: loss, parts and every gradient agree to fp32 noise."""
     runs = []
+    monkeypatch.setenv("HAVATAR_TRAIN_MLP", "torch")          # isolate the field / compositing kernels: the MLP is fp32 nn.Linear on both sides
     for flag in ("0", "1"):
         monkeypatch.setenv("HAVATAR_HIP_TRAIN", flag)
         trainer, loss, parts, _ = _train_step(dataset, gold, "rnd", "cuda")
