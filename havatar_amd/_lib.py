@@ -92,6 +92,10 @@ def lib():
     L.hav_mlp_blob_bytes.restype = i64
     L.hav_mlp_pack.argtypes = [vp, C.POINTER(HavMlpWeights), vp]
     L.hav_mlp_pack.restype = i32
+    L.hav_upsample3d_2x_fwd.argtypes = [vp, vp, i64, i32, i32, i32, vp]
+    L.hav_upsample3d_2x_fwd.restype = i32
+    L.hav_upsample3d_2x_bwd.argtypes = [vp, vp, i64, i32, i32, i32, vp]
+    L.hav_upsample3d_2x_bwd.restype = i32
     L.hav_mlp_train_blob_bytes.restype = i64
     L.hav_mlp_train_ops_bytes.argtypes = [i64]
     L.hav_mlp_train_ops_bytes.restype = i64

@@ -330,3 +330,108 @@ extern "C" int hav_composite_bwd(float* d_rf, const float* d_rgb, const float* d
     HAV_LAUNCH_CHECK();
     return 0;
 }
+
+// ================================================================================================
+// Trilinear x2 up-sampling of a [N,C,D,H,W] volume, forward and adjoint -- the parameter-free first stage of every
+// UpConv3DBlock of the skinning-volume decoder (reference model/network/voxel_encoder.py:183-210: nn.Upsample(scale_factor=2,
+// mode='trilinear'), align_corners=False).  Per axis  out[2i] = 0.25 x[i-1] + 0.75 x[i],  out[2i+1] = 0.75 x[i] + 0.25 x[i+1]
+// with indices clamped at the borders; the 3-D operator is the tensor product.  One thread per output element, gather form both
+// ways (no atomics): the adjoint collects, per axis, the <= 4 outputs an input voxel feeds (2i-1, 2i, 2i+1, 2i+2 with the border
+// terms folded back).  Replaces ~30 ATen launches per block forward and ~60 backward (six blocks, evaluated per training step).
+// ================================================================================================
+__device__ __forceinline__ void up2_taps(int o, int n, int& i0, int& i1, float& w0, float& w1)
+{
+    const int i = o >> 1;
+    if (o & 1) { i0 = i; i1 = min(i + 1, n - 1); w0 = 0.75f; w1 = 0.25f; }
+    else { i0 = max(i - 1, 0); i1 = i; w0 = 0.25f; w1 = 0.75f; }
+}
+
+__global__ void __launch_bounds__(256) up3d_fwd_kernel(float* __restrict__ out, const float* __restrict__ in, int64_t NC, int D, int H, int W)
+{
+    const int64_t total = NC * 8 * D * H * W;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        int64_t t = idx;
+        const int ox = (int)(t % (2 * W)); t /= 2 * W;
+        const int oy = (int)(t % (2 * H)); t /= 2 * H;
+        const int oz = (int)(t % (2 * D));
+        const int64_t nc = t / (2 * D);
+        int x0, x1, y0, y1, z0, z1; float wx0, wx1, wy0, wy1, wz0, wz1;
+        up2_taps(ox, W, x0, x1, wx0, wx1); up2_taps(oy, H, y0, y1, wy0, wy1); up2_taps(oz, D, z0, z1, wz0, wz1);
+        const float* p = in + nc * D * H * W;
+        auto at = [&](int z, int y, int x) { return p[((int64_t)z * H + y) * W + x]; };
+        // same association as three 1-D passes along D, then H, then W
+        const float a00 = wz0 * at(z0, y0, x0) + wz1 * at(z1, y0, x0), a01 = wz0 * at(z0, y0, x1) + wz1 * at(z1, y0, x1);
+        const float a10 = wz0 * at(z0, y1, x0) + wz1 * at(z1, y1, x0), a11 = wz0 * at(z0, y1, x1) + wz1 * at(z1, y1, x1);
+        const float b0 = wy0 * a00 + wy1 * a10, b1 = wy0 * a01 + wy1 * a11;
+        out[idx] = wx0 * b0 + wx1 * b1;
+    }
+}
+
+// adjoint along one axis: input index i collects  sum_o w(o -> i) g[o]  over the outputs that read it
+__device__ __forceinline__ int up2_adj(int i, int n, int (&o)[4], float (&w)[4])
+{
+    int k = 0;
+    // even output 2j reads (max(j-1,0): 0.25, j: 0.75); odd output 2j+1 reads (j: 0.75, min(j+1,n-1): 0.25)
+    o[k] = 2 * i; w[k++] = 0.75f;                           // out[2i]   <- 0.75 x[i]
+    o[k] = 2 * i + 1; w[k++] = 0.75f;                       // out[2i+1] <- 0.75 x[i]
+    if (i + 1 < n) { o[k] = 2 * (i + 1); w[k++] = 0.25f; }  // out[2(i+1)] <- 0.25 x[i]
+    else { o[k] = 2 * i + 1; w[k++] = 0.25f; }              // border: out[2n-1] <- 0.25 x[min(n, n-1)]
+    if (i > 0) { o[k] = 2 * (i - 1) + 1; w[k++] = 0.25f; }  // out[2(i-1)+1] <- 0.25 x[i]
+    else { o[k] = 0; w[k++] = 0.25f; }                      // border: out[0] <- 0.25 x[max(-1, 0)]
+    return k;
+}
+
+__global__ void __launch_bounds__(256) up3d_bwd_kernel(float* __restrict__ din, const float* __restrict__ dout, int64_t NC, int D, int H, int W)
+{
+    const int64_t total = NC * D * H * W;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        int64_t t = idx;
+        const int x = (int)(t % W); t /= W;
+        const int y = (int)(t % H); t /= H;
+        const int z = (int)(t % D);
+        const int64_t nc = t / D;
+        int ox[4], oy[4], oz[4]; float wx[4], wy[4], wz[4];
+        up2_adj(x, W, ox, wx); up2_adj(y, H, oy, wy); up2_adj(z, D, oz, wz);
+        const float* g = dout + nc * 8 * D * H * W;
+        float s = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            float sy = 0.f;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                float sx = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) sx += wx[c] * g[((int64_t)oz[a] * (2 * H) + oy[b]) * (2 * W) + ox[c]];
+                sy += wy[b] * sx;
+            }
+            s += wz[a] * sy;
+        }
+        din[idx] = s;
+    }
+}
+
+extern "C" int hav_upsample3d_2x_fwd(float* out, const float* in, int64_t NC, int D, int H, int W, void* stream)
+{
+    if (!out || !in || NC < 0 || D < 1 || H < 1 || W < 1) return HAV_EINVAL;
+    const int64_t total = NC * 8 * D * H * W;
+    if (total == 0) return 0;
+    int64_t blocks = (total + 255) / 256;
+    const int64_t cap = (int64_t)hav_num_cus() * 32;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(up3d_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, in, NC, D, H, W);
+    HAV_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int hav_upsample3d_2x_bwd(float* din, const float* dout, int64_t NC, int D, int H, int W, void* stream)
+{
+    if (!din || !dout || NC < 0 || D < 1 || H < 1 || W < 1) return HAV_EINVAL;
+    const int64_t total = NC * D * H * W;
+    if (total == 0) return 0;
+    int64_t blocks = (total + 255) / 256;
+    const int64_t cap = (int64_t)hav_num_cus() * 32;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(up3d_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, din, dout, NC, D, H, W);
+    HAV_LAUNCH_CHECK();
+    return 0;
+}

@@ -33,9 +33,27 @@ class Deformation_Field_new(nn.Module):
         w[:, 1:, :1, :w.shape[-1] // 8, :] = 1.0
         self.canonical_W = torch.cat([1 - w[:, 1:], w[:, 1:]], dim=1)
 
+    def volume_once(self):
+        """canonical_Wvolume() evaluated ONCE per set of decoder weights: the reference runs the same VolumeDecoder (no inputs, no
+        RNG) for the coarse pass, for the fine pass and again for the smoothness term of the loss (Skinning_Field.py:79,
+        train_avatar.py:124) -- three identical 64^3 evaluations and backward passes per step.  One node in the autograd graph
+        gives the same value and the same (summed) gradient.  Keyed on the parameters' version counters, the hipGraph weights epoch
+        and the grad mode, so an optimiser step, a load_state_dict or a no_grad validation render all re-evaluate."""
+        from ..graph import weights_epoch
+        key = (tuple(p._version for p in self.canonical_Wvolume.parameters()), tuple(p.data_ptr() for p in self.canonical_Wvolume.parameters()),
+               weights_epoch(), torch.is_grad_enabled())
+        c = self.__dict__.get("_vol_once")
+        if c is None or c[0] != key:
+            vol = self.canonical_Wvolume()
+            c = (key, vol)
+            self.__dict__["_vol_once"] = c
+            if vol.requires_grad:         # a backward pass consumes the node (its buffers are freed): never hand it out again
+                vol.register_hook(lambda g, d=self.__dict__, k=key: d.pop("_vol_once", None) if d.get("_vol_once", (None,))[0] == k else None)
+        return c[1]
+
     def current_volume(self):
         """[1,2,R,R,R] volume the forward pass samples (frozen copy if fix_canonical_W() was called)."""
-        return self.canonical_W if self.fix_canoW else self.canonical_Wvolume()
+        return self.canonical_W if self.fix_canoW else self.volume_once()
 
     def sample_volume(self, pts, padding_mode="border"):
         vol = self.canonical_Wvolume()

@@ -26,6 +26,9 @@ class Upsample2xTrilinear(nn.Module):
         return torch.stack([even, odd], dim + 1).reshape(shape)
 
     def forward(self, x):
+        if x.is_cuda and x.dtype == torch.float32 and x.dim() == 5:
+            from ...native.train_ops import upsample3d_2x            # one HIP launch each way (hav_upsample3d_2x_*)
+            return upsample3d_2x(x)
         for dim in (2, 3, 4):
             x = self._axis(x, dim)
         return x

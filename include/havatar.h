@@ -135,6 +135,14 @@ int hav_composite_bwd(float* d_rf, const float* d_rgb, const float* d_acc, const
                       int S, int CH, int n_sigmoid, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Trilinear x2 up-sampling of a [N,C,D,H,W] float32 volume and its adjoint -- nn.Upsample(scale_factor=2, mode='trilinear',
+ * align_corners=False), the first stage of every UpConv3DBlock of the skinning-volume decoder
+ * (model/network/voxel_encoder.py:183-210).  NC = N*C; out / dout are [NC, 2D, 2H, 2W].  Gather form both ways (no atomics).
+ * ------------------------------------------------------------------------------------------ */
+int hav_upsample3d_2x_fwd(float* out, const float* in, int64_t NC, int D, int H, int W, void* stream);
+int hav_upsample3d_2x_bwd(float* din, const float* dout, int64_t NC, int D, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Radiance MLP of the training path on the bf16 matrix cores (BASELINE config 5) -- replaces, under
  * autograd, the five nn.Linear calls of ConditionalTriplaneNeRFModel_multiRender_split_view.forward (model/nerf_model.py:104-117):
  *   X [n,176] = cat(tri-plane features, positional encoding)  ->  rf [n,68] = [rgb(3) | feature(64) | alpha(1)]

@@ -354,3 +354,24 @@ def test_composite_forward_and_gradients_match_volume_render_radiance_field():
             assert e_mine <= max(2.0 * e_aten, 4e-6), (name, e_mine, e_aten)
     with pytest.raises(RuntimeError):
         composite(torch.zeros(2, 65, 4, device=DEV), torch.zeros(2, 65, device=DEV), torch.ones(2, 3, device=DEV))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 3, 1, 1, 1), (2, 5, 1, 2, 3), (1, 4, 4, 4, 4), (1, 16, 16, 16, 16), (1, 2, 7, 5, 9)])
+def test_upsample3d_2x_matches_nn_upsample_and_its_autograd(shape):
+    """hav_upsample3d_2x_{fwd,bwd} == nn.Upsample(scale_factor=2, mode='trilinear', align_corners=False) (the first stage of every
+    UpConv3DBlock, reference model/network/voxel_encoder.py:183-210) and the adjoint ATen computes for it, fp64 as the truth."""
+    from havatar_amd.native.train_ops import upsample3d_2x
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(shape, generator=g)
+    xd = x.to(dev).requires_grad_(True)
+    y = upsample3d_2x(xd)
+    x64 = x.double().requires_grad_(True)
+    ref = torch.nn.functional.interpolate(x64, scale_factor=2, mode="trilinear", align_corners=False)
+    assert y.shape == ref.shape
+    assert (y.double().cpu() - ref).abs().max().item() <= 5e-7 * max(1.0, ref.abs().max().item())
+    go = torch.randn(ref.shape, generator=g)
+    y.backward(go.to(dev))
+    ref.backward(go.double())
+    assert (xd.grad.double().cpu() - x64.grad).abs().max().item() <= 3e-6 * max(1.0, x64.grad.abs().max().item())
