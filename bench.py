@@ -479,8 +479,11 @@ def main():
                 rows = int(min(H, max(4, rows * 15.0 / max(took, 1e-3)))) // 4 * 4
                 est, took = cpu_baseline(sc, rows, threads)
             # one core: rows scaled so that it is ~10 s of work for one thread
-            rows1 = max(1, min(rows, int(round(rows * 10.0 / max(took * threads * 0.6, 1e-3)))))
+            rows1 = 2
             est1, took1 = cpu_baseline(sc, rows1, 1)
+            if took1 < 5.0:
+                rows1 = int(max(2, min(H, rows1 * 10.0 / max(took1, 1e-3))))
+                est1, took1 = cpu_baseline(sc, rows1, 1)
             res["cpu_baseline"] = {"value": round(1.0 / est, 5), "unit": "frames/s", "cores": threads, "kind": "port",
                                    "cpu_model": cpu_model(),
                                    "sample": "%d of %d image rows (%d rays) of the same frame, oracle/hav_oracle.c with OpenMP, "
