@@ -91,6 +91,8 @@ def make_optimizer(cfg, trainer, graph):
     if graph and cfg.optimizer.type in ("Adam", "AdamW", "NAdam", "RAdam", "Adamax", "Adagrad", "RMSprop", "SGD", "ASGD", "Adadelta", "Rprop"):
         # capturable: the step counter and the learning rate live on the device, so the optimiser update can be replayed
         kw = {"capturable": True} if cfg.optimizer.type != "SGD" else {}
+        if cfg.optimizer.type in ("Adam", "AdamW") and os.environ.get("HAVATAR_FUSED_ADAM", "1") != "0":
+            kw["fused"] = True            # one multi-tensor kernel per parameter bucket instead of ~8 foreach passes (same update formula)
     return getattr(torch.optim, cfg.optimizer.type)([{"params": list(trainer.parameters())}], lr=cfg.optimizer.lr, **kw)
 
 

@@ -48,7 +48,11 @@ class Deformation_Field_new(nn.Module):
             c = (key, vol)
             self.__dict__["_vol_once"] = c
             if vol.requires_grad:         # a backward pass consumes the node (its buffers are freed): never hand it out again
-                vol.register_hook(lambda g, d=self.__dict__, k=key: d.pop("_vol_once", None) if d.get("_vol_once", (None,))[0] == k else None)
+                def _consumed(grad, d=self.__dict__, k=key):
+                    if d.get("_vol_once", (None,))[0] == k:
+                        d.pop("_vol_once", None)
+                    return None
+                vol.register_hook(_consumed)
         return c[1]
 
     def current_volume(self):

@@ -70,7 +70,10 @@ class Trainer(torch.nn.Module):
             out = list(self.predict_and_render_radiance(mode, rays, background_prior, inv_head_T=inv_head_T))
             self._decline_coarse = False
         else:
-            chunk = opt.chunksize // rays.shape[0]
+            # the reference's chunk loop (:66-71) only bounds activation memory.  HIP tensors under autograd take all rays of the call as ONE
+            # chunk: half the launches of a cfg5 step (4096 rays per frame = two 2048-ray chunks in the reference) and kernels twice
+            # the size; 288 GB of HBM hold the [n, 176] field inputs of 0.5 M queries many times over.  CPU tensors chunk as the reference.
+            chunk = rays.shape[1] if rays.is_cuda else opt.chunksize // rays.shape[0]
             rb = get_minibatches(rays, chunksize=chunk, dim=1)
             bg = get_minibatches(background_prior, chunksize=chunk, dim=1) if background_prior is not None else None
             pred = [self.predict_and_render_radiance(mode, r, None if bg is None else bg[i], inv_head_T=inv_head_T) for i, r in enumerate(rb)]
