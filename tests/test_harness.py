@@ -154,7 +154,8 @@ def _check_step(trainer, loss, parts, psnr, gold, tag, rtol, planes_rtol=None):
         assert scale > 0, n
         # the skinning-volume decoder normalises every layer (InstanceNorm3d): its tiny gradients (1e-5) are differences of
         # large cancelling terms and carry ~1e-3 relative fp32 noise; in fp64 this repo and the reference agree to 1e-9 on them
-        tol = max(rtol, 1e-2) if n.startswith("headpose_skin_net.") else rtol
+        # (in bf16 the volume's gradient arrives through dX, like the planes': planes_rtol applies, see test_training_step_gpu)
+        tol = max(planes_rtol or rtol, 1e-2) if n.startswith("headpose_skin_net.") else rtol
         assert np.abs(got - ref).max() <= tol * scale, (n, np.abs(got - ref).max() / scale)
     gp = trainer.model_coarse.triPlane_embeddings.grad.detach().cpu()
     ref = gold["h2_%s_grad_planes_slice" % tag]
@@ -295,8 +296,9 @@ def test_training_step_gpu(dataset, gold, monkeypatch, mlp, rtol):
     encoder convs): with the fp32 nn.Linear statement of the radiance MLP at 2e-3, and with the bf16-MFMA kernels of BASELINE
     config 5 (hav_mlp_train_*, the default) at the relaxed 2e-2 SURVEY 8(a) H2 states for the bf16 build."""
     monkeypatch.setenv("HAVATAR_TRAIN_MLP", mlp)
-    # per-texel plane gradients sum over few queries: in bf16 a relu unit within ~1e-3 of zero switches (tests/test_mlp_train_gpu.py)
-    # and the texels its query touches move by a few per cent of the largest entry; every gradient that sums over all queries is 2e-2
+    # gradients that reach their tensor through dX (per-texel plane gradients, the skinning volume) sum over few queries: in bf16 a
+    # relu unit within ~1e-3 of zero switches (tests/test_mlp_train_gpu.py) and the entries its query touches move by a few per cent
+    # of the largest one; every gradient that sums over all queries (MLP, latent codes, encoder convolutions) is held to 2e-2
     _check_step(*_train_step(dataset, gold, "det", "cuda"), gold, "det", rtol=rtol, planes_rtol=6e-2 if mlp == "bf16" else None)
 
 
