@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libhavatar_hip.so")
-SOURCES = ["hav_ops.hip", "hav_render.hip", "hav_train.hip", "hav_mlp_train.hip"]
+SOURCES = ["hav_ops.hip", "hav_render.hip", "hav_train.hip", "hav_mlp_train.hip", "hav_conv.hip"]
 HEADERS = ["hav_common.h", os.path.join("..", "..", "include", "havatar.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
 

@@ -1,0 +1,206 @@
+// hav_conv.hip -- 3x3 stride-1 convolution of the StyleGAN blocks as an implicit GEMM on the fp16 matrix cores with split
+// operands (fp32-class results), with the modulation, demodulation, noise, bias and leaky-ReLU of the block fused in.
+// SURVEY 8(f) next-4; reference: ModulatedConv2d / StyledConv / ConvLayer of model/styleUnet.py:165-297,326-368,565-599 in their
+// scale-input / shared-weight / scale-output form (the reference's own non-fused algebra, :200-227):
+//
+//   y[b,o,p] = act( d[b,o] * sum_{i,ky,kx} W[o,i,ky,kx] * (s[b,i] * x[b,i,p + (ky-1, kx-1)])  + nw * noise[p] + bias[o] ) * gain
+//
+// Every term but the convolution is optional (plain ConvLayer: bias + leaky-ReLU only).  Zero padding, NCHW fp32 in and out.
+//
+// Why not MIOpen: its fastest fp32 solver for these shapes (Winograd F(2,3)) runs at ~86 TFLOP/s effective; the 16-bit matrix pipe of
+// gfx950 is 16x faster per k than the fp32 one, and three fp16 products with fp32 accumulation (x = xh + xl, w = wh + wl:
+// wl.xh + wh.xl + wh.xh) reproduce the fp32 product to ~2^-22, the size of the fp32 accumulation error of a 4608-term dot product.
+//
+// GEMM view: M = Cout, N = pixels, K = 9 Cin.  Workgroup = 4 waves = a 64 (Cout) x [4 rows x 32 columns] output tile; wave (wm, wn)
+// owns one 32-row M tile and two 32-pixel rows.  K runs over 16-channel chunks: the chunk's input patch (6 x 34 pixels with halo,
+// modulated by s, split into fp16 hi / lo) is staged in LDS once and serves all 9 taps -- a tap is just a pixel offset into the patch
+// -- so the B operand of tap (ky, kx) is one conflict-free ds_read_b128 per part (pixel records are 80 bytes apart: 16 lanes hit 16
+// distinct bank groups).  The A operands (weights) are pre-split, pre-scaled by 2^8 (keeps the low parts out of the fp16 subnormals;
+// undone exactly in the epilogue) and pre-arranged per (chunk, tap, M tile, part) by hav_conv3x3_pack, and stream from L2 with the
+// 18 fragments of a chunk in flight at once.  Global loads of chunk c+1 are issued before the MFMAs of chunk c, converted and written
+// to the other LDS buffer after them: one barrier per chunk.
+#include "hav_common.h"
+
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+typedef float fl2_t __attribute__((ext_vector_type(2)));
+
+#define CV_ROWS 4
+#define CV_COLS 32
+#define CV_PR (CV_ROWS + 2)
+#define CV_PC (CV_COLS + 2)
+#define CV_PIX (CV_PR * CV_PC)           // 204 pixels of the staged patch
+#define CV_REC 20                        // dwords per pixel record: 8 (hi, 16 ch) + 8 (lo) + 4 pad = 80 bytes
+#define CV_TASKS (CV_PIX * 8)            // (pixel, channel pair) staging tasks per chunk
+#define CV_TPT ((CV_TASKS + 255) / 256)  // per thread
+#define CV_WSHIFT 256.0f
+
+extern "C" int64_t hav_conv3x3_packed_bytes(int Cout, int Cin) { return (int64_t)(Cin / 16) * 9 * (Cout / 32) * 2 * 64 * 16; }
+
+// fragment (chunk cc, tap t, M tile m, part): lane (i, h) holds W[32m + i][16cc + 8h + e][t] * wmul * 2^8, e = 0..7, as fp16 hi or lo
+__global__ void __launch_bounds__(256) conv3x3_pack_kernel(uint4* __restrict__ blob, const float* __restrict__ w, int Cout, int Cin, float wmul,
+                                                           int64_t total)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63), i = lane & 31, h = lane >> 5;
+    int64_t q = idx >> 6;
+    const int part = (int)(q & 1); q >>= 1;
+    const int MT = Cout / 32;
+    const int m = (int)(q % MT); q /= MT;
+    const int t = (int)(q % 9);
+    const int cc = (int)(q / 9);
+    uint32_t o[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        float v[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) v[u] = w[((int64_t)(32 * m + i) * Cin + 16 * cc + 8 * h + 2 * d + u) * 9 + t] * (wmul * CV_WSHIFT);
+        const fl2_t f = {v[0], v[1]};
+        const h2_t hi = __builtin_convertvector(f, h2_t);
+        const h2_t lo = __builtin_convertvector(f - __builtin_convertvector(hi, fl2_t), h2_t);
+        o[d] = __builtin_bit_cast(uint32_t, part ? lo : hi);
+    }
+    blob[idx] = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+extern "C" int hav_conv3x3_pack(void* blob, const float* w, int Cout, int Cin, float wmul, void* stream)
+{
+    if (!blob || !w || Cout < 32 || Cin < 16) return HAV_EINVAL;
+    if ((Cout % 32) || (Cin % 16)) return HAV_EUNSUP;
+    const int64_t total = hav_conv3x3_packed_bytes(Cout, Cin) / 16;
+    hipLaunchKernelGGL(conv3x3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (uint4*)blob, w, Cout, Cin,
+                       wmul, total);
+    HAV_LAUNCH_CHECK();
+    return 0;
+}
+
+struct ConvArgs {
+    float* y; const float* x; const uint4* blob;
+    const float* s; const float* d; const float* noise; const float* noise_weight; const float* bias;
+    float slope, gain;
+    int act, noise_batched;
+    int B, Cin, Cout, H, W;
+};
+
+__global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(ConvArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2][CV_PIX * CV_REC];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int bw = a.W / CV_COLS;
+    const int px = blockIdx.x % bw, py = blockIdx.x / bw;
+    const int x0 = px * CV_COLS, y0 = py * CV_ROWS;
+    const int mt = blockIdx.y * 2 + wm;          // this wave's 32-row tile of output channels
+    const int b = blockIdx.z;
+    const int H = a.H, W = a.W, Cin = a.Cin, NC = Cin / 16, MT = a.Cout / 32;
+    const float* xb = a.x + (int64_t)b * Cin * H * W;
+    const float* sb = a.s ? a.s + (int64_t)b * Cin : nullptr;
+
+    // staging tasks of this thread: (pixel of the patch, channel pair) -> one hi dword + one lo dword
+    int t_off[CV_TPT], t_lds[CV_TPT], t_cp[CV_TPT];
+    bool t_ok[CV_TPT];
+#pragma unroll
+    for (int q = 0; q < CV_TPT; ++q) {
+        const int task = tid + 256 * q;
+        const int cp = task / CV_PIX, p = task - cp * CV_PIX;
+        const int pr = p / CV_PC, pc = p - pr * CV_PC;
+        const int gy = y0 + pr - 1, gx = x0 + pc - 1;
+        t_ok[q] = task < CV_TASKS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        t_off[q] = (2 * cp) * H * W + gy * W + gx;
+        t_lds[q] = task < CV_TASKS ? p * CV_REC + cp : -1;
+        t_cp[q] = 2 * cp;
+    }
+    float sv[CV_TPT][2];
+    auto fetch = [&](int cc, float (&v)[CV_TPT][2]) {
+        const float* src = xb + (int64_t)(16 * cc) * H * W;
+#pragma unroll
+        for (int q = 0; q < CV_TPT; ++q) {
+            v[q][0] = t_ok[q] ? src[t_off[q]] : 0.f;
+            v[q][1] = t_ok[q] ? src[t_off[q] + H * W] : 0.f;
+            if (sb && t_ok[q]) { v[q][0] *= sb[16 * cc + t_cp[q]]; v[q][1] *= sb[16 * cc + t_cp[q] + 1]; }
+        }
+    };
+    auto stash = [&](int buf, const float (&v)[CV_TPT][2]) {
+#pragma unroll
+        for (int q = 0; q < CV_TPT; ++q) {
+            if (t_lds[q] < 0) continue;
+            const fl2_t f = {v[q][0], v[q][1]};
+            const h2_t hi = __builtin_convertvector(f, h2_t);
+            const h2_t lo = __builtin_convertvector(f - __builtin_convertvector(hi, fl2_t), h2_t);
+            lds[buf][t_lds[q]] = __builtin_bit_cast(uint32_t, hi);
+            lds[buf][t_lds[q] + 8] = __builtin_bit_cast(uint32_t, lo);
+        }
+    };
+    f32x16 acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+
+    fetch(0, sv);
+    stash(0, sv);
+    __syncthreads();
+    for (int cc = 0; cc < NC; ++cc) {
+        const int buf = cc & 1;
+        // weights of this chunk: 9 taps x (hi, lo), all in flight
+        const uint4* ab = a.blob + ((int64_t)(cc * 9) * MT + mt) * 128 + lane;
+        uint4 A[9][2];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) { A[t][0] = ab[(int64_t)t * MT * 128]; A[t][1] = ab[(int64_t)t * MT * 128 + 64]; }
+        if (cc + 1 < NC) fetch(cc + 1, sv);
+        const uint32_t* L = lds[buf];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ky = t / 3, kx = t - 3 * ky;
+            const f16x8_t ah = __builtin_bit_cast(f16x8_t, A[t][0]), al = __builtin_bit_cast(f16x8_t, A[t][1]);
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int p = (2 * wn + rr + ky) * CV_PC + j + kx;
+                const uint4 bh = *reinterpret_cast<const uint4*>(L + p * CV_REC + 4 * h);
+                const uint4 bl = *reinterpret_cast<const uint4*>(L + p * CV_REC + 8 + 4 * h);
+                const f16x8_t xh = __builtin_bit_cast(f16x8_t, bh), xl = __builtin_bit_cast(f16x8_t, bl);
+                acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh, acc[rr], 0, 0, 0);
+                acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl, acc[rr], 0, 0, 0);
+                acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh, acc[rr], 0, 0, 0);
+            }
+        }
+        // the matrix instructions keep reading their operand registers for a while after issue: wait them out before
+        // the conversion code below may recycle registers
+        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]));
+        if (cc + 1 < NC) stash(buf ^ 1, sv);
+        __syncthreads();
+    }
+
+    // epilogue: demodulate, inject noise, bias, leaky-ReLU, gain -- in the order of the unfused statement (hav_styled_epilogue)
+    const float nw = (a.noise && a.noise_weight) ? *a.noise_weight : 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int gy = y0 + 2 * wn + rr, gx = x0 + j;
+        const float nz = a.noise ? a.noise[(a.noise_batched ? (int64_t)b * H * W : 0) + (int64_t)gy * W + gx] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
+            float v = acc[rr][r] * (1.0f / CV_WSHIFT);
+            if (a.d) v = v * a.d[(int64_t)b * a.Cout + co];
+            if (a.noise) v = v + nw * nz;
+            if (a.bias) v = v + a.bias[co];
+            if (a.act) v = (v > 0.f ? v : v * a.slope) * a.gain;
+            a.y[(((int64_t)b * a.Cout + co) * H + gy) * W + gx] = v;
+        }
+    }
+}
+
+extern "C" int hav_conv3x3_split(float* y, const float* x, const void* packed, const float* s, const float* d, const float* noise,
+                                 const float* noise_weight, const float* bias, float slope, float gain, int act, int noise_batched, int B,
+                                 int Cin, int Cout, int H, int W, void* stream)
+{
+    if (!y || !x || !packed || B < 1 || Cin < 16 || Cout < 64 || H < 1 || W < 1) return HAV_EINVAL;
+    if ((Cin % 16) || (Cout % 64) || (H % CV_ROWS) || (W % CV_COLS)) return HAV_EUNSUP;
+    ConvArgs a;
+    a.y = y; a.x = x; a.blob = (const uint4*)packed; a.s = s; a.d = d; a.noise = noise; a.noise_weight = noise_weight; a.bias = bias;
+    a.slope = slope; a.gain = gain; a.act = act; a.noise_batched = noise_batched;
+    a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+    hipLaunchKernelGGL(conv3x3_split_kernel, dim3((unsigned)((W / CV_COLS) * (H / CV_ROWS)), (unsigned)(Cout / 64), (unsigned)B), dim3(256), 0,
+                       (hipStream_t)stream, a);
+    HAV_LAUNCH_CHECK();
+    return 0;
+}

@@ -16,8 +16,16 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+import os
+
 from .op import FusedLeakyReLU, conv2d_gradfix, fused_leaky_relu, upfirdn2d
 from ..graph import weights_epoch
+from ..native import conv as _conv
+
+
+def _fused_conv_enabled():
+    """HAVATAR_FUSED_CONV=0 keeps every convolution on MIOpen (A/B runs)."""
+    return os.environ.get("HAVATAR_FUSED_CONV", "1") != "0"
 
 _CHANNELS = lambda cm: {4: 512, 8: 512, 16: 512, 32: 512, 64: 256 * cm, 128: 128 * cm, 256: 64 * cm, 512: 32 * cm, 1024: 16 * cm}
 
@@ -150,6 +158,15 @@ class ModulatedConv2d(nn.Module, _InferenceCache):
     def _hip_inference(self, input):
         return input.is_cuda and input.dtype == torch.float32 and not torch.is_grad_enabled()
 
+    def fused_conv_ok(self, input):
+        """3x3, no re-sampling, a shape hav_conv3x3_split takes, and a map large enough to fill the GPU with its 64 x 128 tiles
+        (at 32^2 MIOpen's Winograd is the faster one: 67 vs 87 us for 512 -> 512)."""
+        return (self.kernel_size == 3 and not self.upsample and not self.downsample and _fused_conv_enabled()
+                and input.shape[-1] * input.shape[-2] >= 4096 and _conv.eligible(input, self.weight[0]))
+
+    def packed3x3(self):
+        return self._cached("w3x3", self.weight, lambda: _conv.pack(self.weight[0], self.scale))
+
     def style_vectors(self, style):
         """(s [B,Cin], d [B,Cout] | None).  HIP inference: one launch (hav_style_demod) instead of EqualLinear + bias + square +
         matmul + eps + rsqrt; otherwise the ATen sequence."""
@@ -225,6 +242,19 @@ class ConvLayer(nn.Sequential):
             layers.append(FusedLeakyReLU(out_channel, bias=bias))
         super().__init__(*layers)
 
+    def forward(self, input):
+        ec = self[0]
+        if (isinstance(ec, EqualConv2d) and input.is_cuda and input.dtype == torch.float32 and not torch.is_grad_enabled()
+                and _fused_conv_enabled() and input.shape[-1] * input.shape[-2] >= 4096
+                and _conv.eligible(input, ec.weight, ec.stride, ec.padding)):
+            # HIP inference: EqualConv2d 3x3 + bias + leaky-ReLU as one kernel (hav_conv3x3_split)
+            act = len(self) > 1
+            pk = ec._cached("w3x3", ec.weight, lambda: _conv.pack(ec.weight, ec.scale))
+            if act:
+                return _conv.conv3x3(input, pk, ec.weight.shape[0], bias=self[1].bias, slope=self[1].negative_slope, gain=self[1].scale, act=True)
+            return _conv.conv3x3(input, pk, ec.weight.shape[0], bias=ec.bias, act=False)
+        return super().forward(input)
+
 
 def get_haar_wavelet(in_channels):
     l = 1 / (2 ** 0.5) * torch.ones(1, 2)
@@ -294,6 +324,15 @@ class StyledConv(nn.Module):
         self.activate = FusedLeakyReLU(out_channel)
 
     def forward(self, input, style, noise=None):
+        if self.conv._hip_inference(input) and self.conv.fused_conv_ok(input):
+            # HIP inference, 3x3: modulation, the convolution (split-fp16 implicit GEMM on the matrix cores), demodulation, noise,
+            # bias and leaky-ReLU as ONE kernel (hav_conv3x3_split)
+            s, d = self.conv.style_vectors(style)
+            if noise is None:
+                b, _, h, w = input.shape
+                noise = input.new_empty(b, 1, h, w).normal_()
+            return _conv.conv3x3(input, self.conv.packed3x3(), self.conv.out_channel, s=s, d=d, noise=noise, noise_weight=self.noise.weight,
+                                 bias=self.activate.bias, slope=self.activate.negative_slope, gain=self.activate.scale, act=True)
         if self.conv._hip_inference(input):
             # HIP inference: demodulation * noise injection + bias + leaky-relu in ONE pass (hav_styled_epilogue) instead of four
             from ..native import fused

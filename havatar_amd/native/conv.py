@@ -1,0 +1,56 @@
+"""3x3 stride-1 convolution of the StyleGAN blocks on the fp16 matrix cores with split operands and the block's glue fused in
+(libhavatar_hip.so: hav_conv3x3_*; include/havatar.h).  Inference only (no autograd); HIP float32 tensors; no fallback in here --
+`eligible()` tells the caller whether the shape is supported, otherwise it keeps its MIOpen route."""
+import ctypes as C
+
+import torch
+
+from .. import _lib
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def eligible(x, weight, stride=1, padding=1):
+    """weight [Cout,Cin,3,3]; x [B,Cin,H,W] float32 on a HIP device."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and weight.dim() == 4):
+        return False
+    Cout, Cin, kh, kw = weight.shape
+    B, Ci, H, W = x.shape
+    return (kh == 3 and kw == 3 and stride == 1 and padding == 1 and Ci == Cin and Cin % 16 == 0 and Cout % 64 == 0
+            and H % 4 == 0 and W % 32 == 0)
+
+
+def pack(weight, wmul=1.0):
+    """[Cout,Cin,3,3] float32 -> fragment blob (uint8 tensor) with `wmul` folded in."""
+    w = weight.detach().contiguous()
+    Cout, Cin = w.shape[:2]
+    L = _lib.lib()
+    blob = torch.empty(int(L.hav_conv3x3_packed_bytes(Cout, Cin)), dtype=torch.uint8, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(L.hav_conv3x3_pack(_p(blob), _p(w), Cout, Cin, float(wmul), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                   "hav_conv3x3_pack")
+    return blob
+
+
+def conv3x3(x, packed, Cout, s=None, d=None, noise=None, noise_weight=None, bias=None, slope=0.2, gain=2 ** 0.5, act=True):
+    """y = act(d * conv3x3(s * x, W) + noise_weight * noise + bias) * gain; see include/havatar.h for the exact order."""
+    x = x.contiguous()
+    B, Cin, H, W = x.shape
+    y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device)
+    nb = 0
+    if noise is not None:
+        noise = noise.contiguous()
+        if noise.numel() == B * H * W and B > 1:
+            nb = 1
+        elif noise.numel() != H * W:
+            raise RuntimeError("conv3x3: noise must be [1,1,H,W] or [B,1,H,W]")
+    f = lambda t: None if t is None else t.contiguous()
+    s, d, bias = f(s), f(d), f(bias)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().hav_conv3x3_split(_p(y), _p(x), _p(packed), _p(s), _p(d), _p(noise), _p(noise_weight), _p(bias), float(slope),
+                                          float(gain), int(bool(act)), nb, B, Cin, Cout, H, W,
+                                          C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, "hav_conv3x3_split")
+    return y

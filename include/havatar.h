@@ -135,6 +135,25 @@ int hav_composite_bwd(float* d_rf, const float* d_rgb, const float* d_acc, const
                       int S, int CH, int n_sigmoid, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * 3x3, stride-1, zero-padded convolution of the StyleGAN blocks with the block's glue fused in -- replaces, at
+ * inference, ModulatedConv2d + NoiseInjection + FusedLeakyReLU of a StyledConv (model/styleUnet.py:165-297,300-310,565-599) and
+ * EqualConv2d + FusedLeakyReLU of a ConvLayer (:90-125,326-368), i.e. one MIOpen convolution plus 1-3 elementwise launches:
+ *   y[b,o,p] = act( d[b,o] * sum_{i,ky,kx} W[o,i,ky,kx] * (s[b,i] * x[b,i,p+(ky-1,kx-1)]) + (*noise_weight) * noise[p] + bias[o] ) * gain
+ * x, y NCHW float32; s [B,Cin], d [B,Cout], noise [H*W] or [B,H*W] (noise_batched), noise_weight (device scalar), bias [Cout] are
+ * all nullable; act != 0 applies leaky-ReLU(slope) * gain, act == 0 leaves the sum as is (gain ignored).
+ * Arithmetic: implicit GEMM on v_mfma_f32_32x32x16_f16 with split operands (x and W as hi + lo fp16, three products, fp32
+ * accumulation): fp32-class results (same reasoning and the same fp16 range limit as HAV_MLP_SPLIT_F16: |s x| < 65504).
+ * `packed` = hav_conv3x3_pack(W [Cout,Cin,3,3], wmul), hav_conv3x3_packed_bytes(Cout, Cin) bytes; wmul is folded into the weights
+ * (EqualConv2d / ModulatedConv2d scale 1/sqrt(9 Cin)).  Needs Cin % 16 == 0, Cout % 64 == 0, H % 4 == 0, W % 32 == 0
+ * (HAV_EUNSUP otherwise: the caller keeps its MIOpen route).
+ * ------------------------------------------------------------------------------------------ */
+int64_t hav_conv3x3_packed_bytes(int Cout, int Cin);
+int hav_conv3x3_pack(void* packed, const float* w, int Cout, int Cin, float wmul, void* stream);
+int hav_conv3x3_split(float* y, const float* x, const void* packed, const float* s, const float* d, const float* noise,
+                      const float* noise_weight, const float* bias, float slope, float gain, int act, int noise_batched, int B,
+                      int Cin, int Cout, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Trilinear x2 up-sampling of a [N,C,D,H,W] float32 volume and its adjoint -- nn.Upsample(scale_factor=2, mode='trilinear',
  * align_corners=False), the first stage of every UpConv3DBlock of the skinning-volume decoder
  * (model/network/voxel_encoder.py:183-210).  NC = N*C; out / dout are [NC, 2D, 2H, 2W].  Gather form both ways (no atomics).

@@ -375,3 +375,58 @@ def test_upsample3d_2x_matches_nn_upsample_and_its_autograd(shape):
     y.backward(go.to(dev))
     ref.backward(go.double())
     assert (xd.grad.double().cpu() - x64.grad).abs().max().item() <= 3e-6 * max(1.0, x64.grad.abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Cin,Cout,H,W,full", [(1, 16, 64, 4, 32, True), (2, 48, 64, 8, 64, True), (1, 64, 128, 12, 32, False),
+                                                 (1, 512, 512, 32, 32, True), (1, 256, 256, 128, 128, False)])
+def test_conv3x3_split_matches_fp64_convolution(B, Cin, Cout, H, W, full):
+    """hav_conv3x3_split (split-fp16 implicit GEMM + fused modulation / demodulation / noise / bias / leaky-ReLU) against the fp64
+    statement of the same StyledConv / ConvLayer arithmetic (model/styleUnet.py:165-297,326-368,565-599); the fp32 F.conv2d route's
+    own error against fp64 is the yardstick: the split product must be fp32-class."""
+    from havatar_amd.native import conv
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B * 1000 + Cin + Cout + H)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g)
+    wmul = 1.0 / (Cin * 9) ** 0.5
+    s = (1.0 + 0.3 * torch.randn(B, Cin, generator=g)) if full else None
+    d = (0.5 + torch.rand(B, Cout, generator=g)) if full else None
+    noise = torch.randn(B if B > 1 else 1, 1, H, W, generator=g) if full else None
+    nw = torch.tensor([0.37]) if full else None
+    bias = torch.randn(Cout, generator=g) * 0.1
+    assert conv.eligible(x.to(dev), w.to(dev))
+    t = lambda a: None if a is None else a.to(dev)
+    y = conv.conv3x3(t(x), conv.pack(t(w), wmul), Cout, s=t(s), d=t(d), noise=t(noise), noise_weight=t(nw), bias=t(bias), slope=0.2,
+                     gain=2 ** 0.5, act=True)
+
+    def ref(dt):
+        xx = x.to(dt) * (s.to(dt).view(B, Cin, 1, 1) if s is not None else 1.0)
+        o = torch.nn.functional.conv2d(xx, w.to(dt) * wmul, padding=1)
+        if d is not None:
+            o = o * d.to(dt).view(B, Cout, 1, 1)
+        if noise is not None:
+            o = o + nw.to(dt) * noise.to(dt)
+        o = o + bias.to(dt).view(1, Cout, 1, 1)
+        return torch.nn.functional.leaky_relu(o, 0.2) * 2 ** 0.5
+    r64, r32 = ref(torch.float64), ref(torch.float32)
+    scale = r64.abs().max().item()
+    err = (y.double().cpu() - r64).abs().max().item()
+    floor = (r32.double() - r64).abs().max().item()
+    assert y.shape == r64.shape and torch.isfinite(y).all()
+    assert err <= 3.0 * floor + 2e-6 * scale, (err / scale, floor / scale)
+    # plain ConvLayer flavours: bias only (no activation), and nothing at all
+    y2 = conv.conv3x3(t(x), conv.pack(t(w), wmul), Cout, bias=t(bias), act=False)
+    r2 = torch.nn.functional.conv2d(x.double(), w.double() * wmul, bias=bias.double(), padding=1)
+    assert (y2.double().cpu() - r2).abs().max().item() <= 3.0 * floor + 2e-6 * r2.abs().max().item()
+
+
+@pytest.mark.gpu
+def test_conv3x3_split_refuses_unsupported_shapes():
+    from havatar_amd.native import conv
+    dev = torch.device("cuda:0")
+    assert not conv.eligible(torch.zeros(1, 16, 4, 16, device=dev), torch.zeros(64, 16, 3, 3, device=dev))      # W % 32
+    assert not conv.eligible(torch.zeros(1, 16, 4, 32, device=dev), torch.zeros(32, 16, 3, 3, device=dev))      # Cout % 64
+    assert not conv.eligible(torch.zeros(1, 24, 4, 32, device=dev), torch.zeros(64, 24, 3, 3, device=dev))      # Cin % 16
+    with pytest.raises(RuntimeError):
+        conv.conv3x3(torch.zeros(1, 16, 4, 16, device=dev), conv.pack(torch.zeros(64, 16, 3, 3, device=dev)), 64)

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""hav_conv3x3_split vs MIOpen's fp32 convolution on the encoder's heavy 3x3 shapes (one frame, B=1): time and effective TFLOP/s."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from havatar_amd.native import conv
+dev = torch.device("cuda:0")
+torch.backends.cudnn.benchmark = True
+def timed(fn, n=10):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(n):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
+    return sorted(ts)[len(ts) // 2]
+for Cin, Cout, H in ((512, 512, 32), (1024, 512, 32), (512, 512, 64), (1024, 512, 64), (256, 256, 128), (512, 256, 128)):
+    x = torch.randn(1, Cin, H, H, device=dev); w = torch.randn(Cout, Cin, 3, 3, device=dev) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, device=dev)
+    pk = conv.pack(w)
+    t_ours = timed(lambda: conv.conv3x3(x, pk, Cout, bias=b))
+    t_mi = timed(lambda: torch.nn.functional.conv2d(x, w, padding=1))
+    fl = 2 * 9 * Cin * Cout * H * H
+    print("%4d -> %4d @ %3d^2: split-fp16 %7.1f us (%5.0f TF/s eff)   MIOpen fp32 %7.1f us (%5.0f TF/s eff)" % (Cin, Cout, H, t_ours * 1e3, fl / t_ours / 1e9, t_mi * 1e3, fl / t_mi / 1e9))
