@@ -77,6 +77,8 @@ extern "C" int hav_conv3x3_pack(void* blob, const float* w, int Cout, int Cin, f
 
 struct ConvArgs {
     float* y; const float* x; const uint4* blob;
+    float* partial;          // K-split: [ksplit][B,Cout,H,W] raw accumulators (already scaled back), reduced by conv3x3_finish_kernel
+    int ksplit;
     const float* s; const float* d; const float* noise; const float* noise_weight; const float* bias;
     float slope, gain;
     int act, noise_batched;
@@ -92,8 +94,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(ConvArgs a)
     const int px = blockIdx.x % bw, py = blockIdx.x / bw;
     const int x0 = px * CV_COLS, y0 = py * CV_ROWS;
     const int mt = blockIdx.y * 2 + wm;          // this wave's 32-row tile of output channels
-    const int b = blockIdx.z;
-    const int H = a.H, W = a.W, Cin = a.Cin, NC = Cin / 16, MT = a.Cout / 32;
+    const int b = blockIdx.z / a.ksplit, ks = blockIdx.z - b * a.ksplit;
+    const int H = a.H, W = a.W, Cin = a.Cin, NCT = Cin / 16, MT = a.Cout / 32;
+    // K-split (small maps: too few output tiles to fill the GPU): this workgroup covers the channel chunks [c_lo, c_hi)
+    const int c_lo = (NCT * ks) / a.ksplit, c_hi = (NCT * (ks + 1)) / a.ksplit, NC = c_hi - c_lo;
     const float* xb = a.x + (int64_t)b * Cin * H * W;
     const float* sb = a.s ? a.s + (int64_t)b * Cin : nullptr;
 
@@ -136,17 +140,17 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(ConvArgs a)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
 
-    fetch(0, sv);
+    fetch(c_lo, sv);
     stash(0, sv);
     __syncthreads();
-    for (int cc = 0; cc < NC; ++cc) {
-        const int buf = cc & 1;
+    for (int ci = 0; ci < NC; ++ci) {
+        const int cc = c_lo + ci, buf = ci & 1;
         // weights of this chunk: 9 taps x (hi, lo), all in flight
         const uint4* ab = a.blob + ((int64_t)(cc * 9) * MT + mt) * 128 + lane;
         uint4 A[9][2];
 #pragma unroll
         for (int t = 0; t < 9; ++t) { A[t][0] = ab[(int64_t)t * MT * 128]; A[t][1] = ab[(int64_t)t * MT * 128 + 64]; }
-        if (cc + 1 < NC) fetch(cc + 1, sv);
+        if (ci + 1 < NC) fetch(cc + 1, sv);
         const uint32_t* L = lds[buf];
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -166,8 +170,19 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(ConvArgs a)
         // the matrix instructions keep reading their operand registers for a while after issue: wait them out before
         // the conversion code below may recycle registers
         asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]));
-        if (cc + 1 < NC) stash(buf ^ 1, sv);
+        if (ci + 1 < NC) stash(buf ^ 1, sv);
         __syncthreads();
+    }
+    if (a.partial) {            // K-split: raw sums out, the epilogue runs in conv3x3_finish_kernel after the slices are added up
+        float* pp = a.partial + (int64_t)ks * a.B * a.Cout * H * W;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
+                pp[(((int64_t)b * a.Cout + co) * H + y0 + 2 * wn + rr) * W + x0 + j] = acc[rr][r] * (1.0f / CV_WSHIFT);
+            }
+        return;
     }
 
     // epilogue: demodulate, inject noise, bias, leaky-ReLU, gain -- in the order of the unfused statement (hav_styled_epilogue)
@@ -189,18 +204,61 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(ConvArgs a)
     }
 }
 
+// K-split epilogue: y = act(d * (sum of the slices, in slice order) + nw * noise + bias) * gain
+__global__ void __launch_bounds__(256) conv3x3_finish_kernel(ConvArgs a, int64_t total)
+{
+    const float nw = (a.noise && a.noise_weight) ? *a.noise_weight : 0.f;
+    const int64_t HW = (int64_t)a.H * a.W;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t plane = e / HW, p = e - plane * HW;
+        const int co = (int)(plane % a.Cout);
+        const int64_t b = plane / a.Cout;
+        float v = 0.f;
+        for (int k = 0; k < a.ksplit; ++k) v += a.partial[(int64_t)k * total + e];
+        if (a.d) v = v * a.d[plane];
+        if (a.noise) v = v + nw * a.noise[(a.noise_batched ? b * HW : 0) + p];
+        if (a.bias) v = v + a.bias[co];
+        if (a.act) v = (v > 0.f ? v : v * a.slope) * a.gain;
+        a.y[e] = v;
+    }
+}
+
+// scratch the K-split path needs for these sizes (0: no K-split, pass NULL)
+static int conv_ksplit(int B, int Cin, int Cout, int H, int W)
+{
+    const int64_t tiles = (int64_t)B * (Cout / 64) * (H / CV_ROWS) * (W / CV_COLS);
+    int ks = 1;
+    while (tiles * ks < hav_num_cus() && ks < 4 && (Cin / 16) / (ks * 2) >= 4) ks *= 2;
+    return ks;
+}
+extern "C" int64_t hav_conv3x3_scratch_bytes(int B, int Cin, int Cout, int H, int W)
+{
+    if (B < 1 || Cin < 16 || Cout < 64 || H < 1 || W < 1 || (Cin % 16) || (Cout % 64) || (H % CV_ROWS) || (W % CV_COLS)) return 0;
+    const int ks = conv_ksplit(B, Cin, Cout, H, W);
+    return ks > 1 ? (int64_t)ks * B * Cout * H * W * 4 : 0;
+}
+
 extern "C" int hav_conv3x3_split(float* y, const float* x, const void* packed, const float* s, const float* d, const float* noise,
                                  const float* noise_weight, const float* bias, float slope, float gain, int act, int noise_batched, int B,
-                                 int Cin, int Cout, int H, int W, void* stream)
+                                 int Cin, int Cout, int H, int W, void* scratch, void* stream)
 {
     if (!y || !x || !packed || B < 1 || Cin < 16 || Cout < 64 || H < 1 || W < 1) return HAV_EINVAL;
     if ((Cin % 16) || (Cout % 64) || (H % CV_ROWS) || (W % CV_COLS)) return HAV_EUNSUP;
     ConvArgs a;
+    a.ksplit = scratch ? conv_ksplit(B, Cin, Cout, H, W) : 1;
+    a.partial = a.ksplit > 1 ? (float*)scratch : nullptr;
     a.y = y; a.x = x; a.blob = (const uint4*)packed; a.s = s; a.d = d; a.noise = noise; a.noise_weight = noise_weight; a.bias = bias;
     a.slope = slope; a.gain = gain; a.act = act; a.noise_batched = noise_batched;
     a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
-    hipLaunchKernelGGL(conv3x3_split_kernel, dim3((unsigned)((W / CV_COLS) * (H / CV_ROWS)), (unsigned)(Cout / 64), (unsigned)B), dim3(256), 0,
-                       (hipStream_t)stream, a);
+    hipLaunchKernelGGL(conv3x3_split_kernel, dim3((unsigned)((W / CV_COLS) * (H / CV_ROWS)), (unsigned)(Cout / 64), (unsigned)(B * a.ksplit)),
+                       dim3(256), 0, (hipStream_t)stream, a);
     HAV_LAUNCH_CHECK();
+    if (a.partial) {
+        const int64_t total = (int64_t)B * Cout * H * W;
+        int64_t blocks = (total + 255) / 256;
+        if (blocks > (int64_t)hav_num_cus() * 16) blocks = (int64_t)hav_num_cus() * 16;
+        hipLaunchKernelGGL(conv3x3_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, total);
+        HAV_LAUNCH_CHECK();
+    }
     return 0;
 }

@@ -159,10 +159,9 @@ class ModulatedConv2d(nn.Module, _InferenceCache):
         return input.is_cuda and input.dtype == torch.float32 and not torch.is_grad_enabled()
 
     def fused_conv_ok(self, input):
-        """3x3, no re-sampling, a shape hav_conv3x3_split takes, and a map large enough to fill the GPU with its 64 x 128 tiles
-        (at 32^2 MIOpen's Winograd is the faster one: 67 vs 87 us for 512 -> 512)."""
+        """3x3, no re-sampling, a shape hav_conv3x3_split takes (32^2 and up; 32^2 maps run K-split over 4 workgroups per tile)."""
         return (self.kernel_size == 3 and not self.upsample and not self.downsample and _fused_conv_enabled()
-                and input.shape[-1] * input.shape[-2] >= 4096 and _conv.eligible(input, self.weight[0]))
+                and input.shape[-1] * input.shape[-2] >= 1024 and _conv.eligible(input, self.weight[0]))
 
     def packed3x3(self):
         return self._cached("w3x3", self.weight, lambda: _conv.pack(self.weight[0], self.scale))
@@ -245,7 +244,7 @@ class ConvLayer(nn.Sequential):
     def forward(self, input):
         ec = self[0]
         if (isinstance(ec, EqualConv2d) and input.is_cuda and input.dtype == torch.float32 and not torch.is_grad_enabled()
-                and _fused_conv_enabled() and input.shape[-1] * input.shape[-2] >= 4096
+                and _fused_conv_enabled() and input.shape[-1] * input.shape[-2] >= 1024
                 and _conv.eligible(input, ec.weight, ec.stride, ec.padding)):
             # HIP inference: EqualConv2d 3x3 + bias + leaky-ReLU as one kernel (hav_conv3x3_split)
             act = len(self) > 1

@@ -48,9 +48,12 @@ def conv3x3(x, packed, Cout, s=None, d=None, noise=None, noise_weight=None, bias
             raise RuntimeError("conv3x3: noise must be [1,1,H,W] or [B,1,H,W]")
     f = lambda t: None if t is None else t.contiguous()
     s, d, bias = f(s), f(d), f(bias)
+    L = _lib.lib()
+    need = int(L.hav_conv3x3_scratch_bytes(B, Cin, Cout, H, W))          # small maps: K-split slices, summed in a second pass
+    scratch = torch.empty(need, dtype=torch.uint8, device=x.device) if need else None
     with torch.cuda.device(x.device):
-        rc = _lib.lib().hav_conv3x3_split(_p(y), _p(x), _p(packed), _p(s), _p(d), _p(noise), _p(noise_weight), _p(bias), float(slope),
-                                          float(gain), int(bool(act)), nb, B, Cin, Cout, H, W,
-                                          C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        rc = L.hav_conv3x3_split(_p(y), _p(x), _p(packed), _p(s), _p(d), _p(noise), _p(noise_weight), _p(bias), float(slope),
+                                 float(gain), int(bool(act)), nb, B, Cin, Cout, H, W, _p(scratch),
+                                 C.c_void_p(torch.cuda.current_stream().cuda_stream))
     _lib.check(rc, "hav_conv3x3_split")
     return y

@@ -149,9 +149,12 @@ int hav_composite_bwd(float* d_rf, const float* d_rgb, const float* d_acc, const
  * ------------------------------------------------------------------------------------------ */
 int64_t hav_conv3x3_packed_bytes(int Cout, int Cin);
 int hav_conv3x3_pack(void* packed, const float* w, int Cout, int Cin, float wmul, void* stream);
+/* Maps with too few 64 x 128 output tiles to fill the GPU (32^2) split the channel range over 2-4 workgroups and add the slices up in a
+ * second, deterministic pass: hav_conv3x3_scratch_bytes() bytes of caller scratch (0: not needed; NULL: never split). */
+int64_t hav_conv3x3_scratch_bytes(int B, int Cin, int Cout, int H, int W);
 int hav_conv3x3_split(float* y, const float* x, const void* packed, const float* s, const float* d, const float* noise,
                       const float* noise_weight, const float* bias, float slope, float gain, int act, int noise_batched, int B,
-                      int Cin, int Cout, int H, int W, void* stream);
+                      int Cin, int Cout, int H, int W, void* scratch, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Trilinear x2 up-sampling of a [N,C,D,H,W] float32 volume and its adjoint -- nn.Upsample(scale_factor=2, mode='trilinear',
