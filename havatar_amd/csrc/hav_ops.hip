@@ -174,16 +174,26 @@ __global__ void __launch_bounds__(SD_OT * SD_SL) style_demod_kernel(float* __res
         while (G < D && G < 64) G <<= 1;
         const int lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
         const int gl = lane & (G - 1), grp = lane / G, gpw = 64 / G;
-        for (int i0 = wave * gpw; i0 < Cin; i0 += nw * gpw) {
-            const int i = i0 + grp;
-            float acc = 0.f;
-            if (i < Cin)
-                for (int k = gl; k < D; k += G) acc = fmaf(st[k], mod_w[(size_t)i * D + k], acc);
-            for (int o = G >> 1; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
-            if (i < Cin && gl == 0) {
-                const float v = acc + (mod_b ? mod_b[i] : 0.f);
-                if (blockIdx.x == 0) s_out[(size_t)b * Cin + i] = v;
-                s_sq[i] = v * v;
+        constexpr int UB = 8;              // rows per group in flight: the loads of a batch are all issued before the first reduction
+        for (int i0 = wave * gpw; i0 < Cin; i0 += nw * gpw * UB) {
+            float acc[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int i = i0 + u * nw * gpw + grp;
+                acc[u] = 0.f;
+                if (i < Cin)
+                    for (int k = gl; k < D; k += G) acc[u] = fmaf(st[k], mod_w[(size_t)i * D + k], acc[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int i = i0 + u * nw * gpw + grp;
+                float t = acc[u];
+                for (int o = G >> 1; o >= 1; o >>= 1) t += __shfl_xor(t, o, 64);
+                if (i < Cin && gl == 0) {
+                    const float v = t + (mod_b ? mod_b[i] : 0.f);
+                    if (blockIdx.x == 0) s_out[(size_t)b * Cin + i] = v;
+                    s_sq[i] = v * v;
+                }
             }
         }
     }
