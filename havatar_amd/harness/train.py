@@ -35,7 +35,9 @@ def lpips_loss(img0, img1, lpips_fn):
 
 def skin_weight_smoothness(trainer):
     """Mean absolute 6-neighbour difference of the second blend-weight channel (train_avatar.py:123-129)."""
-    vol = trainer.headpose_skin_net.volume_once()[0, 1]        # (the same evaluation the march samples: one decoder pass per step)
+    net = trainer.headpose_skin_net
+    # (the same evaluation the march samples: one decoder pass per step; a reference Trainer has no volume_once and re-evaluates)
+    vol = (net.volume_once() if hasattr(net, "volume_once") else net.canonical_Wvolume())[0, 1]
     core = vol[1:-1, 1:-1, 1:-1]
     nbrs = [vol[:-2, 1:-1, 1:-1], vol[2:, 1:-1, 1:-1], vol[1:-1, 2:, 1:-1], vol[1:-1, :-2, 1:-1], vol[1:-1, 1:-1, 2:], vol[1:-1, 1:-1, :-2]]
     return torch.mean(sum(torch.abs(core - v) for v in nbrs) / 6.0)

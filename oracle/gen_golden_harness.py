@@ -112,6 +112,45 @@ def main():
             out["h2_%s_gradcks_%s" % (tag, n)] = np.array([gr.double().sum().item(), gr.double().abs().sum().item()])
         n_with = sum(p.grad is not None for p in params.values())
         print("H2", tag, "loss %.6f psnr %.3f" % (loss.item(), psnr), {k: round(v.item(), 6) for k, v in parts.items()}, "params with grad", n_with, "/", len(params))
+    # ---------------- H2-ref: the reference SCRIPT's own step --------------------------------------------------------------
+    # train_avatar.py cannot be imported (top-level cv2 / lpips / tensorboard, body inside main()), but its per-step statements can
+    # be EXECUTED: the lines from `mv_rays = train_batch['mv_rays']` to the learning-rate update (train_avatar.py:108-158) are read
+    # from the reference checkout at generation time, dedented and exec'd against the reference Trainer, a real torch.optim.Adam and
+    # a batch of this repo's reader (pinned separately against the reference reader, tests/golden/small.npz).  What is stored are
+    # numbers only: loss, psnr, the new learning rate and parameter slices AFTER optimizer.step() -- the loss expression, the
+    # backward/step/zero_grad order and the decay formula are the reference's text, not a restatement.
+    import textwrap
+    src = open(os.path.join("/root/reference", "train_avatar.py")).read().split("\n")
+    a = next(i for i, ln in enumerate(src) if "mv_rays = train_batch['mv_rays'].to(device)" in ln)
+    b = next(i for i, ln in enumerate(src) if 'param_group["lr"] = lr_new' in ln)
+    step_code = textwrap.dedent("\n".join(src[a:b + 1]))
+    from utils.training_util import mse2psnr as ref_mse2psnr
+    cfg = CfgNode(synth.harness_config(perturb=False, noise_std=0.0))
+    np.random.seed(7)
+    tl = TrainLoader(split_file=split, mode="train", batch_size=2, num_workers=0, down_sample=cfg.dataset.down_sample, options=cfg,
+                     white_bg=True, shuffle=False)
+    idx, batch = next(iter(tl))
+    torch.manual_seed(5)
+    trainer = synth.fill_state_dict(Trainer(cfg, len(tl.dataset)))
+    trainer.train()
+    optimizer = getattr(torch.optim, cfg.optimizer.type)([{"params": trainer.parameters()}], lr=cfg.optimizer.lr)      # train_avatar.py:71
+    ns = {"train_batch": batch, "idx": idx, "device": "cpu", "trainer": trainer, "cfg": cfg, "optimizer": optimizer, "torch": torch,
+          "F": torch.nn.functional, "rgb_loss_func": torch.nn.functional.mse_loss, "mse2psnr": ref_mse2psnr, "i": 41}
+    for step in range(2):                          # two consecutive steps: the second one sees Adam's state and the decayed rate
+        ns["i"] += 1
+        exec(step_code, ns)
+        out["h2ref_loss_%d" % step] = np.array(ns["loss"].item())
+        out["h2ref_psnr_%d" % step] = np.array(ns["psnr"])
+        out["h2ref_lr_%d" % step] = np.array(ns["lr_new"])
+    out["h2ref_iter"] = np.array(ns["i"])
+    after = dict(trainer.named_parameters())
+    names = ["model_coarse.layers_xyz.0.weight", "model_coarse.fc_alpha.weight", "model_coarse.fc_rgb.bias", "latent_codes",
+             "headpose_skin_net.canonical_Wvolume.final_conv.weight", "model_coarse.XY_gen.conv1.conv.weight"]
+    out["h2ref_names"] = np.array(names)
+    for n in names:
+        t = after[n].detach()
+        out["h2ref_after_%s" % n] = t.numpy() if t.numel() <= 32768 else t.reshape(-1)[:: max(1, t.numel() // 4096)].numpy()
+    print("H2-ref", [float(out["h2ref_loss_%d" % k]) for k in range(2)], [float(out["h2ref_lr_%d" % k]) for k in range(2)])
     path = os.path.join(REPO, "tests", "golden", "harness.npz")
     np.savez_compressed(path, **out)
     print("harness.npz", os.path.getsize(path) // 1024, "KiB")
