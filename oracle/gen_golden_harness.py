@@ -5,9 +5,12 @@ train_avatar.py:106-148 and store the results in tests/golden/harness.npz.
 
 What is the reference here and what is not: `Trainer`, `SWGAN_unet`, autograd through them and the RNG stream are the
 reference's.  The two scripts themselves cannot be imported (top-level `import cv2`, `lpips`, tensorboard, and their body is
-`main()`), so the frames are read by this repo's dataset reader (cv2-free; its rays are pinned separately by
-tests/golden/get_rays.npz) and the loss expression of train_avatar.py:121-146 is evaluated by
-havatar_amd.harness.train.training_loss applied to the REFERENCE trainer object.
+`main()`), so the frames are read by this repo's dataset readers (cv2-free; pinned against the REFERENCE readers by
+tests/golden/small.npz, oracle/gen_golden_reader.py).  The scripts' per-frame / per-step STATEMENTS are executed from their text
+(read from /root/reference at generation time, never copied): avatarHD_reenactment.py:153-170 produces the H1 PNG arrays and file
+names (asserted equal to this repo's `to_png_array` path), train_avatar.py:108-158 produces the H2-ref step (loss expression,
+backward / step / zero_grad order, learning-rate decay).  The per-part loss values of H2 (`h2_*_part_*`) additionally evaluate
+havatar_amd.harness.train.training_loss on the REFERENCE trainer object.
 Weights are key-derived (synth.fill_state_dict), noise strengths zeroed so that unpinned per-call noise cannot matter."""
 import os
 import sys
@@ -60,6 +63,22 @@ def main():
     style = torch.mean(torch.randn(1000, 1, 64), dim=0)
     out["h1_style"] = style.numpy()
     loader = SRLoader(split_file=split, mode="test", batch_size=1, options=cfg, down_sample=cfg.dataset.down_sample)
+    # H1-ref: the reference SCRIPT's own per-frame statements (avatarHD_reenactment.py:153-170, from `name = ...` to `cv2.imwrite`),
+    # read from the checkout at generation time and exec'd; cv2 is a two-function stand-in that captures the image it is given.
+    import textwrap
+    import types
+    rsrc = open(os.path.join("/root/reference", "avatarHD_reenactment.py")).read().split("\n")
+    ra = next(i for i, ln in enumerate(rsrc) if "name = str(int(val_batch['fidx'][0].numpy()))" in ln)
+    rb = next(i for i, ln in enumerate(rsrc) if "cv2.imwrite(" in ln)
+    frame_code = textwrap.dedent("\n".join(rsrc[ra:rb + 1]))
+    written = {}
+    cv2s = types.SimpleNamespace(COLOR_RGB2BGR=4, cvtColor=lambda img, code: img[:, :, ::-1],
+                                 imwrite=lambda path, bgr: written.__setitem__(os.path.basename(path), np.ascontiguousarray(bgr[:, :, ::-1])))
+    with torch.no_grad():
+        for idx, batch in loader:
+            ns = {"val_batch": batch, "idx": idx, "device": "cpu", "nerf_render": nerf_render, "img_trans": img_trans, "style": style,
+                  "np": np, "os": os, "cv2": cv2s, "torch": torch, "configargs": types.SimpleNamespace(savedir="/tmp/h1ref")}
+            exec(frame_code, ns)
     with torch.no_grad():
         for idx, batch in loader:
             inp = reenact.frame_inputs(idx, batch, "cpu")
@@ -70,6 +89,9 @@ def main():
             out["h1_mask_%d" % k] = mask.numpy()
             out["h1_gen_%d" % k] = gen.numpy()
             out["h1_png_%d" % k] = reenact.to_png_array(gen)
+            fname = "%s_%02d.png" % (str(int(batch["fidx"][0])), int(batch["vidx"][0]))
+            assert np.array_equal(written[fname], out["h1_png_%d" % k]), "the reference script's frame statements and this repo's disagree"
+            out["h1ref_file_%d" % k] = np.array(fname)
             print("H1 frame", k, "render", tuple(render.shape), "acc", float(mask.min()), float(mask.max()), "gen range",
                   float(gen.min()), float(gen.max()))
 
