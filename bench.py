@@ -437,7 +437,10 @@ def main():
                        "workload": "cfg2: Trainer.forward(render_full_img=True) for one 512x512 frame per GPU per step: tri-plane encoders "
                                    "(P3: 2x StyleGAN_zxc, MIOpen convs + HIP upfirdn2d/fused_bias_act) -> per-frame plane projection -> fused "
                                    "ray march (P5-P12) over 262144 rays x (64 coarse + 48 fine) = 29.36M radiance-MLP queries -> [1,67,512,512]",
-                       "phase_ms": {"encoders_P3": round(enc_ms, 3), "plane_prepare": round(prep_ms, 3), "ray_march_kernel": round(kern_ms, 3)},
+                       "phase_ms": {"encoders_P3": round(enc_ms, 3), "plane_prepare": round(prep_ms, 3), "ray_march_kernel": round(kern_ms, 3),
+                                    "encoders_P3_inside_the_graph": round(1e3 * dt / args.steps / (frames_per_step / world) - kern_ms - prep_ms, 3),
+                                    "note": "encoders_P3 is timed eagerly on one stream; inside the frame's hipGraph the two encoders run "
+                                            "on two streams without launch gaps: step - march - preparation"},
                        "rays_per_frame": H * W, "num_coarse": S_C, "num_fine": S_F, "perturb": perturb, "hipgraph": bool(args.graph),
                        "parallelism": ("frames sharded, %d rank(s), one overlapped all_gather of finished frames per round" if args.workload == "cfg3"
                                        else "frames sharded, %d rank(s), no data-path collective") % world,

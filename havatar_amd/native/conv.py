@@ -57,3 +57,26 @@ def conv3x3(x, packed, Cout, s=None, d=None, noise=None, noise_weight=None, bias
                                  C.c_void_p(torch.cuda.current_stream().cuda_stream))
     _lib.check(rc, "hav_conv3x3_split")
     return y
+
+
+class _Conv3x3Split(torch.autograd.Function):
+    """conv2d(x, w, stride 1, padding 1) for training: the forward runs on hav_conv3x3_split (split-fp16 MFMA, fp32-class results,
+    ~2x MIOpen's fp32 Winograd on the encoder shapes); the backward is ATen's convolution_backward (MIOpen) on the saved fp32
+    operands, so gradients are exactly those of F.conv2d."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return conv3x3(x, pack(w, 1.0), w.shape[0], act=False)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        gx, gw, _ = torch.ops.aten.convolution_backward(g.contiguous(), x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                        [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
+        return gx, gw
+
+
+def conv3x3_autograd(x, w):
+    """x [B,Cin,H,W], w [Cout,Cin,3,3] (already scaled): differentiable 3x3 / stride 1 / padding 1 convolution, see _Conv3x3Split."""
+    return _Conv3x3Split.apply(x.contiguous(), w.contiguous())
