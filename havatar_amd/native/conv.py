@@ -61,8 +61,8 @@ def conv3x3(x, packed, Cout, s=None, d=None, noise=None, noise_weight=None, bias
 
 class _Conv3x3Split(torch.autograd.Function):
     """conv2d(x, w, stride 1, padding 1) for training: the forward runs on hav_conv3x3_split (split-fp16 MFMA, fp32-class results,
-    ~2x MIOpen's fp32 Winograd on the encoder shapes); the backward is ATen's convolution_backward (MIOpen) on the saved fp32
-    operands, so gradients are exactly those of F.conv2d."""
+    ~2x MIOpen's fp32 Winograd on the encoder shapes), and so does the data gradient, which is the same kind of convolution with
+    the transposed, flipped filters; the weight gradient is ATen's convolution_backward (MIOpen) on the saved fp32 operands."""
 
     @staticmethod
     def forward(ctx, x, w):
@@ -72,9 +72,17 @@ class _Conv3x3Split(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
-        gx, gw, _ = torch.ops.aten.convolution_backward(g.contiguous(), x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                                                        [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
-        return gx, gw
+        g = g.contiguous()
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        gx = None
+        if need_x:
+            # dL/dx is itself a 3x3 / stride 1 / padding 1 convolution of g with the transposed, flipped filters: the same kernel
+            wt = w.flip(2, 3).transpose(0, 1).contiguous()
+            if eligible(g, wt):
+                gx = conv3x3(g, pack(wt, 1.0), wt.shape[0], act=False)
+                need_x = False
+        r = torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [need_x, need_w, False])
+        return (gx if gx is not None else r[0]), r[1]
 
 
 def conv3x3_autograd(x, w):

@@ -430,3 +430,24 @@ def test_conv3x3_split_refuses_unsupported_shapes():
     assert not conv.eligible(torch.zeros(1, 24, 4, 32, device=dev), torch.zeros(64, 24, 3, 3, device=dev))      # Cin % 16
     with pytest.raises(RuntimeError):
         conv.conv3x3(torch.zeros(1, 16, 4, 16, device=dev), conv.pack(torch.zeros(64, 16, 3, 3, device=dev)), 64)
+
+
+@pytest.mark.gpu
+def test_conv3x3_autograd_node_matches_fp64_autograd():
+    """native/conv.py::conv3x3_autograd: value and both gradients against fp64 autograd of F.conv2d, the fp32 F.conv2d route's own
+    error as the yardstick (forward and data gradient run on hav_conv3x3_split, the weight gradient on MIOpen)."""
+    from havatar_amd.native import conv
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 64, 32, 32, generator=g)
+    w = torch.randn(128, 64, 3, 3, generator=g) / (64 * 9) ** 0.5
+    go = torch.randn(2, 128, 32, 32, generator=g)
+    xd, wd = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+    conv.conv3x3_autograd(xd, wd).backward(go.to(dev))
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    torch.nn.functional.conv2d(x64, w64, padding=1).backward(go.double())
+    x32, w32 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    torch.nn.functional.conv2d(x32, w32, padding=1).backward(go)
+    for got, r64, r32 in ((xd.grad, x64.grad, x32.grad), (wd.grad, w64.grad, w32.grad)):
+        floor = (r32.double() - r64).abs().max().item()
+        assert (got.double().cpu() - r64).abs().max().item() <= 3.0 * floor + 2e-6 * r64.abs().max().item()
