@@ -79,6 +79,9 @@ struct ConvArgs {
     float* y; const float* x; const uint4* blob;
     float* partial;          // K-split: [ksplit][B,Cout,H,W] raw accumulators (already scaled back), reduced by conv3x3_finish_kernel
     int ksplit;
+    const unsigned int* in_amax;   // optional: bits of max |x| (hav_absmax); the input is then scaled by the power of two that brings it to
+                                   // [512, 1024) before the fp16 split and the result scaled back -- exact, and it keeps tiny inputs
+                                   // (gradients: 1e-6 and below) out of the fp16 subnormals, where the hi + lo split loses its low part
     const float* s; const float* d; const float* noise; const float* noise_weight; const float* bias;
     float slope, gain;
     int act, noise_batched;
@@ -100,6 +103,15 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(ConvArgs a)
     const int c_lo = (NCT * ks) / a.ksplit, c_hi = (NCT * (ks + 1)) / a.ksplit, NC = c_hi - c_lo;
     const float* xb = a.x + (int64_t)b * Cin * H * W;
     const float* sb = a.s ? a.s + (int64_t)b * Cin : nullptr;
+    float in_sc = 1.0f, out_sc = 1.0f / CV_WSHIFT;
+    if (a.in_amax) {
+        const float am = __uint_as_float(*a.in_amax);
+        if (am > 0.f && am < 3.0e38f) {
+            const int e = 9 - ilogbf(am);
+            in_sc = ldexpf(1.0f, e);
+            out_sc = ldexpf(1.0f / CV_WSHIFT, -e);
+        }
+    }
 
     // staging tasks of this thread: (pixel of the patch, channel pair) -> one hi dword + one lo dword
     int t_off[CV_TPT], t_lds[CV_TPT], t_cp[CV_TPT];
@@ -120,8 +132,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(ConvArgs a)
         const float* src = xb + (int64_t)(16 * cc) * H * W;
 #pragma unroll
         for (int q = 0; q < CV_TPT; ++q) {
-            v[q][0] = t_ok[q] ? src[t_off[q]] : 0.f;
-            v[q][1] = t_ok[q] ? src[t_off[q] + H * W] : 0.f;
+            v[q][0] = t_ok[q] ? src[t_off[q]] * in_sc : 0.f;
+            v[q][1] = t_ok[q] ? src[t_off[q] + H * W] * in_sc : 0.f;
             if (sb && t_ok[q]) { v[q][0] *= sb[16 * cc + t_cp[q]]; v[q][1] *= sb[16 * cc + t_cp[q] + 1]; }
         }
     };
@@ -180,7 +192,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(ConvArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
-                pp[(((int64_t)b * a.Cout + co) * H + y0 + 2 * wn + rr) * W + x0 + j] = acc[rr][r] * (1.0f / CV_WSHIFT);
+                pp[(((int64_t)b * a.Cout + co) * H + y0 + 2 * wn + rr) * W + x0 + j] = acc[rr][r] * out_sc;
             }
         return;
     }
@@ -194,7 +206,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(ConvArgs a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
-            float v = acc[rr][r] * (1.0f / CV_WSHIFT);
+            float v = acc[rr][r] * out_sc;
             if (a.d) v = v * a.d[(int64_t)b * a.Cout + co];
             if (a.noise) v = v + nw * nz;
             if (a.bias) v = v + a.bias[co];
@@ -202,6 +214,45 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(ConvArgs a)
             a.y[(((int64_t)b * a.Cout + co) * H + gy) * W + gx] = v;
         }
     }
+}
+
+// max |x| over a tensor as the bit pattern of a non-negative float (atomicMax on the bits is a float max; NaNs are skipped)
+__global__ void __launch_bounds__(256) absmax_kernel(unsigned int* __restrict__ out, const float* __restrict__ x, int64_t n)
+{
+    __shared__ float red[4];
+    float m = 0.f;
+    const int64_t n4 = n >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = x4[i];
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[(n4 << 2) + threadIdx.x]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        // one atomic per workgroup, and only if it would raise the maximum (hundreds of atomics on one word are the kernel's whole cost)
+        const unsigned int bits = __float_as_uint(m);
+        if (bits > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, bits);
+    }
+}
+
+extern "C" int hav_absmax(void* out_bits, const float* x, int64_t n, void* stream)
+{
+    if (!out_bits || !x || n < 0) return HAV_EINVAL;
+    hipError_t e = hipMemsetAsync(out_bits, 0, 4, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    if (n == 0) return 0;
+    if (((uintptr_t)x & 15) != 0) return HAV_EUNSUP;          // float4 loads (every tensor this library is handed is 16-byte aligned)
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks > (int64_t)hav_num_cus() * 2) blocks = (int64_t)hav_num_cus() * 2;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (unsigned int*)out_bits, x, n);
+    HAV_LAUNCH_CHECK();
+    return 0;
 }
 
 // K-split epilogue: y = act(d * (sum of the slices, in slice order) + nw * noise + bias) * gain
@@ -240,11 +291,12 @@ extern "C" int64_t hav_conv3x3_scratch_bytes(int B, int Cin, int Cout, int H, in
 
 extern "C" int hav_conv3x3_split(float* y, const float* x, const void* packed, const float* s, const float* d, const float* noise,
                                  const float* noise_weight, const float* bias, float slope, float gain, int act, int noise_batched, int B,
-                                 int Cin, int Cout, int H, int W, void* scratch, void* stream)
+                                 int Cin, int Cout, int H, int W, void* scratch, const void* in_amax, void* stream)
 {
     if (!y || !x || !packed || B < 1 || Cin < 16 || Cout < 64 || H < 1 || W < 1) return HAV_EINVAL;
     if ((Cin % 16) || (Cout % 64) || (H % CV_ROWS) || (W % CV_COLS)) return HAV_EUNSUP;
     ConvArgs a;
+    a.in_amax = (const unsigned int*)in_amax;
     a.ksplit = scratch ? conv_ksplit(B, Cin, Cout, H, W) : 1;
     a.partial = a.ksplit > 1 ? (float*)scratch : nullptr;
     a.y = y; a.x = x; a.blob = (const uint4*)packed; a.s = s; a.d = d; a.noise = noise; a.noise_weight = noise_weight; a.bias = bias;

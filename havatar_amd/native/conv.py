@@ -2,6 +2,7 @@
 (libhavatar_hip.so: hav_conv3x3_*; include/havatar.h).  Inference only (no autograd); HIP float32 tensors; no fallback in here --
 `eligible()` tells the caller whether the shape is supported, otherwise it keeps its MIOpen route."""
 import ctypes as C
+import os
 
 import torch
 
@@ -34,8 +35,10 @@ def pack(weight, wmul=1.0):
     return blob
 
 
-def conv3x3(x, packed, Cout, s=None, d=None, noise=None, noise_weight=None, bias=None, slope=0.2, gain=2 ** 0.5, act=True):
-    """y = act(d * conv3x3(s * x, W) + noise_weight * noise + bias) * gain; see include/havatar.h for the exact order."""
+def conv3x3(x, packed, Cout, s=None, d=None, noise=None, noise_weight=None, bias=None, slope=0.2, gain=2 ** 0.5, act=True, autoscale=False):
+    """y = act(d * conv3x3(s * x, W) + noise_weight * noise + bias) * gain; see include/havatar.h for the exact order.
+    autoscale: inputs far from 1 (gradients) are brought into fp16's comfortable range by an exact power-of-two scale found on the
+    device (hav_absmax) and undone in the epilogue."""
     x = x.contiguous()
     B, Cin, H, W = x.shape
     y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device)
@@ -51,10 +54,14 @@ def conv3x3(x, packed, Cout, s=None, d=None, noise=None, noise_weight=None, bias
     L = _lib.lib()
     need = int(L.hav_conv3x3_scratch_bytes(B, Cin, Cout, H, W))          # small maps: K-split slices, summed in a second pass
     scratch = torch.empty(need, dtype=torch.uint8, device=x.device) if need else None
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    amax = None
     with torch.cuda.device(x.device):
+        if autoscale:
+            amax = torch.empty(1, dtype=torch.int32, device=x.device)
+            _lib.check(L.hav_absmax(_p(amax), _p(x), x.numel(), st), "hav_absmax")
         rc = L.hav_conv3x3_split(_p(y), _p(x), _p(packed), _p(s), _p(d), _p(noise), _p(noise_weight), _p(bias), float(slope),
-                                 float(gain), int(bool(act)), nb, B, Cin, Cout, H, W, _p(scratch),
-                                 C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                                 float(gain), int(bool(act)), nb, B, Cin, Cout, H, W, _p(scratch), _p(amax), st)
     _lib.check(rc, "hav_conv3x3_split")
     return y
 
@@ -75,11 +82,11 @@ class _Conv3x3Split(torch.autograd.Function):
         g = g.contiguous()
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         gx = None
-        if need_x:
+        if need_x and os.environ.get("HAVATAR_CONV_BWD", "1") != "0":
             # dL/dx is itself a 3x3 / stride 1 / padding 1 convolution of g with the transposed, flipped filters: the same kernel
             wt = w.flip(2, 3).transpose(0, 1).contiguous()
             if eligible(g, wt):
-                gx = conv3x3(g, pack(wt, 1.0), wt.shape[0], act=False)
+                gx = conv3x3(g, pack(wt, 1.0), wt.shape[0], act=False, autoscale=True)     # gradients are ~1e-6: see hav_absmax
                 need_x = False
         r = torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [need_x, need_w, False])
         return (gx if gx is not None else r[0]), r[1]
