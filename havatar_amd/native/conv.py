@@ -35,10 +35,13 @@ def pack(weight, wmul=1.0):
     return blob
 
 
-def conv3x3(x, packed, Cout, s=None, d=None, noise=None, noise_weight=None, bias=None, slope=0.2, gain=2 ** 0.5, act=True, autoscale=False):
+def conv3x3(x, packed, Cout, s=None, d=None, noise=None, noise_weight=None, bias=None, slope=0.2, gain=2 ** 0.5, act=True, autoscale=None):
     """y = act(d * conv3x3(s * x, W) + noise_weight * noise + bias) * gain; see include/havatar.h for the exact order.
-    autoscale: inputs far from 1 (gradients) are brought into fp16's comfortable range by an exact power-of-two scale found on the
-    device (hav_absmax) and undone in the epilogue."""
+    autoscale (default on; HAVATAR_CONV_AUTOSCALE=0 turns the default off): the input is brought into fp16's comfortable range by an
+    exact power-of-two scale found on the device (hav_absmax: one pass over x) and undone in the epilogue -- gradients (1e-6) keep
+    their low parts, activations of any size cannot overflow the fp16 split.  ~1 % of a frame."""
+    if autoscale is None:
+        autoscale = os.environ.get("HAVATAR_CONV_AUTOSCALE", "1") != "0"
     x = x.contiguous()
     B, Cin, H, W = x.shape
     y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device)
