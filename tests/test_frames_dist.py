@@ -109,7 +109,7 @@ def _trainer_renderer(S=6):
     return render_one, S
 
 
-@pytest.mark.parametrize("n_frames", [3, 4])
+@pytest.mark.parametrize("n_frames", [3])
 def test_real_trainer_frames_through_the_overlapped_gather_two_ranks_gloo(n_frames):
     """cfg3 as the product runs it, at toy size on CPU: 2 processes, each renders its round-robin share of the batch with the real
     Trainer and the round-r all_gather overlaps round r+1; every rank ends up with the whole batch, equal to a single-process
@@ -141,7 +141,7 @@ def test_shard_frames_partition():
         assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
 
 
-@pytest.mark.parametrize("workload", ["cfg2", "cfg3"])
+@pytest.mark.parametrize("workload", ["cfg3"])          # (cfg2's N > 1 branch is the same code minus the gather)
 def test_bench_multi_rank_branch_runs_under_gloo(workload):
     """bench.py's N > 1 branch (process group, barrier-bracketed timing, MAX over ranks, rank 0 prints one JSON line; for cfg3 the
     round-by-round overlapped all_gather) executed for real: 2 processes under torch.distributed.run, CPU tensors, gloo."""
