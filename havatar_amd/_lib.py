@@ -77,6 +77,10 @@ def lib():
     L.hav_style_demod.restype = i32
     L.hav_styled_epilogue.argtypes = [vp, vp, vp, vp, vp, vp, f32, f32, i32, i32, i64, i32, vp]
     L.hav_styled_epilogue.restype = i32
+    L.hav_demod_fwd.argtypes = [vp, vp, vp, vp, f32, f32, i32, i32, i32, i32, vp]
+    L.hav_demod_fwd.restype = i32
+    L.hav_demod_bwd.argtypes = [vp] * 8 + [f32, i32, i32, i32, i32, vp]
+    L.hav_demod_bwd.restype = i32
     L.hav_triplane_gather_fwd.argtypes = [vp, vp, vp, i64, i64, i32, i32, i32, i32, vp]
     L.hav_triplane_gather_fwd.restype = i32
     L.hav_triplane_gather_bwd.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, i32, vp]

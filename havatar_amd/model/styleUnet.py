@@ -176,16 +176,20 @@ class ModulatedConv2d(nn.Module, _InferenceCache):
         matmul + eps + rsqrt; otherwise the ATen sequence."""
         mod = self.modulation
         # sum_{i,ky,kx} (w[o,i] s[b,i])^2 = sum_i s[b,i]^2 * sum_k w[o,i,k]^2
-        wsq = self._cached("wsq", self.weight, lambda: (self.scale * self.weight[0]).pow(2).sum((2, 3)).t().contiguous()) \
-            if self.demodulate else None
+        wsq_fn = lambda: (self._cached("wsq", self.weight, lambda: (self.scale * self.weight[0]).pow(2).sum((2, 3)).t().contiguous())
+                          if self.demodulate else None)
         if self._hip_inference(style) and mod.activation is None:
             from ..native import fused
             mw = mod._cached("w", mod.weight, lambda: mod.weight * mod.scale)
             mb = mod._cached("b", mod.bias, lambda: mod.bias * mod.lr_mul) if mod.bias is not None else None
-            return fused.style_demod(style.contiguous(), mw, mb, wsq, self.eps)
+            return fused.style_demod(style.contiguous(), mw, mb, wsq_fn(), self.eps)
         s = mod(style)
-        d = torch.rsqrt(torch.matmul(s * s, wsq) + self.eps) if self.demodulate else None
-        return s, d
+        if not self.demodulate:
+            return s, None
+        if s.is_cuda and s.dtype == torch.float32 and torch.is_grad_enabled() and os.environ.get("HAVATAR_HIP_TRAIN", "1") != "0":
+            from ..native.train_ops import demod            # training on HIP tensors: one autograd node (hav_demod_fwd / _bwd)
+            return s, demod(s, self.weight[0], self.scale, self.eps)
+        return s, torch.rsqrt(torch.matmul(s * s, wsq_fn()) + self.eps)
 
     def forward_raw(self, input, style):
         """(conv(x * s) BEFORE demodulation, d): callers that fuse the demodulation into their epilogue use this."""

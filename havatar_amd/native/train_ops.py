@@ -142,3 +142,39 @@ class Upsample3d2x(Function):
 
 def upsample3d_2x(x):
     return Upsample3d2x.apply(x)
+
+
+class Demod(Function):
+    """d [B,Cout] = rsqrt(sum_i s[b,i]^2 * scale^2 sum_k W[o,i,k]^2 + eps): the demodulation factors of a ModulatedConv2d
+    (reference model/styleUnet.py:214-227, factored form) as one autograd node -- two launches each way (hav_demod_fwd / _bwd)
+    instead of ~8 + ~14 ATen launches, three of which stream the whole weight tensor."""
+
+    @staticmethod
+    def forward(ctx, s, W, scale, eps):
+        _need_hip("Demod", s, W)
+        s, W = s.contiguous(), W.contiguous()
+        B, Cin = s.shape
+        Cout, KK = W.shape[0], W.shape[2] * W.shape[3]
+        d = torch.empty(B, Cout, device=s.device, dtype=torch.float32)
+        q = torch.empty(Cin, Cout, device=s.device, dtype=torch.float32)
+        with torch.cuda.device(s.device):
+            _lib.check(_lib.lib().hav_demod_fwd(_p(d), _p(q), _p(s), _p(W), float(scale), float(eps), B, Cin, Cout, KK, _stream()), "hav_demod_fwd")
+        ctx.save_for_backward(s, W, d, q)
+        ctx.scale = float(scale)
+        return d
+
+    @staticmethod
+    def backward(ctx, gd):
+        s, W, d, q = ctx.saved_tensors
+        B, Cin = s.shape
+        Cout, KK = W.shape[0], W.shape[2] * W.shape[3]
+        gs, gW, gq = torch.empty_like(s), torch.empty_like(W), torch.empty_like(q)
+        with torch.cuda.device(s.device):
+            _lib.check(_lib.lib().hav_demod_bwd(_p(gs), _p(gW), _p(gq), _p(gd.contiguous()), _p(s), _p(d), _p(q), _p(W), ctx.scale, B, Cin, Cout,
+                                                KK, _stream()), "hav_demod_bwd")
+        return gs, gW, None, None
+
+
+def demod(s, W, scale, eps=1e-8):
+    """s [B,Cin] (differentiable), W [Cout,Cin,k,k] raw parameter -> d [B,Cout]."""
+    return Demod.apply(s, W, scale, eps)

@@ -85,6 +85,14 @@ int hav_styled_epilogue(float* out, const float* x /*[B,C,HW]*/, const float* d 
                         const float* noise_weight /*device scalar or NULL*/, const float* bias /*[C] or NULL*/, float slope,
                         float gain, int B, int C, int64_t HW, int noise_batched, void* stream);
 
+/* Demodulation factors of a modulated convolution under autograd (training path):
+ *   q[i,o] = scale^2 sum_k W[o,i,k]^2 (written to `q`, [Cin,Cout], kept for the backward);  d[b,o] = rsqrt(sum_i s[b,i]^2 q[i,o] + eps)
+ * (model/styleUnet.py:214-227, factored form) and its backward: gs [B,Cin] = d loss / d s through d only (the caller adds the direct
+ * term), gW [Cout,Cin,KK] = d loss / d W through d only; gq_scratch [Cin,Cout].  W is the raw parameter [Cout,Cin,k,k] (KK = k*k). */
+int hav_demod_fwd(float* d, float* q, const float* s, const float* W, float scale, float eps, int B, int Cin, int Cout, int KK, void* stream);
+int hav_demod_bwd(float* gs, float* gW, float* gq_scratch, const float* gd, const float* s, const float* d, const float* q, const float* W,
+                  float scale, int B, int Cin, int Cout, int KK, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Tri-plane gather with gradients (training path) -- sample_from_triplane_new + its autograd (utils/util.py:359-406:
  * two F.grid_sample(bilinear, zeros, align_corners=True) + stack): plane 0 at (q.x,q.y), plane 1 at (q.z,q.y),

@@ -451,3 +451,26 @@ def test_conv3x3_autograd_node_matches_fp64_autograd():
     for got, r64, r32 in ((xd.grad, x64.grad, x32.grad), (wd.grad, w64.grad, w32.grad)):
         floor = (r32.double() - r64).abs().max().item()
         assert (got.double().cpu() - r64).abs().max().item() <= 3.0 * floor + 2e-6 * r64.abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Cin,Cout,k", [(1, 16, 24, 3), (2, 512, 512, 3), (2, 256, 12, 1)])
+def test_demod_autograd_node_matches_the_aten_statement(B, Cin, Cout, k):
+    """hav_demod_fwd / _bwd (native/train_ops.py::demod) vs the ATen statement of ModulatedConv2d's demodulation factors and its
+    autograd, in fp64 (reference model/styleUnet.py:214-227, factored form)."""
+    from havatar_amd.native.train_ops import demod
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(Cin + Cout)
+    s = 1.0 + 0.5 * torch.randn(B, Cin, generator=g)
+    W = torch.randn(Cout, Cin, k, k, generator=g)
+    scale = 1.0 / (Cin * k * k) ** 0.5
+    gd = torch.randn(B, Cout, generator=g)
+    sd, Wd = s.to(dev).requires_grad_(True), W.to(dev).requires_grad_(True)
+    d = demod(sd, Wd, scale, 1e-8)
+    d.backward(gd.to(dev))
+    s64, W64 = s.double().requires_grad_(True), W.double().requires_grad_(True)
+    wsq = (scale * W64).pow(2).sum((2, 3)).t()
+    ref = torch.rsqrt(torch.matmul(s64 * s64, wsq) + 1e-8)
+    ref.backward(gd.double())
+    for name, got, r in (("d", d, ref), ("gs", sd.grad, s64.grad), ("gW", Wd.grad, W64.grad)):
+        assert (got.double().cpu() - r.detach()).abs().max().item() <= 2e-5 * r.detach().abs().max().item() + 1e-12, name

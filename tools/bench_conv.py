@@ -7,18 +7,29 @@ from havatar_amd.native import conv
 dev = torch.device("cuda:0")
 torch.backends.cudnn.benchmark = True
 def timed(fn, n=10):
+    """GPU time per call without host launch gaps: n calls captured in a hipGraph (as the frame runs them), replayed 7 times."""
     for _ in range(3): fn()
     torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n): fn()
     ts = []
-    for _ in range(n):
+    for _ in range(7):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); fn(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
+        a.record(); g.replay(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b) / n)
     return sorted(ts)[len(ts) // 2]
 for Cin, Cout, H in ((512, 512, 32), (1024, 512, 32), (512, 512, 64), (1024, 512, 64), (256, 256, 128), (512, 256, 128)):
     x = torch.randn(1, Cin, H, H, device=dev); w = torch.randn(Cout, Cin, 3, 3, device=dev) / (Cin * 9) ** 0.5
     b = torch.randn(Cout, device=dev)
     pk = conv.pack(w)
     t_ours = timed(lambda: conv.conv3x3(x, pk, Cout, bias=b))
+    t_raw = timed(lambda: conv.conv3x3(x, pk, Cout, bias=b, autoscale=False))
     t_mi = timed(lambda: torch.nn.functional.conv2d(x, w, padding=1))
     fl = 2 * 9 * Cin * Cout * H * H
-    print("%4d -> %4d @ %3d^2: split-fp16 %7.1f us (%5.0f TF/s eff)   MIOpen fp32 %7.1f us (%5.0f TF/s eff)" % (Cin, Cout, H, t_ours * 1e3, fl / t_ours / 1e9, t_mi * 1e3, fl / t_mi / 1e9))
+    print("%4d -> %4d @ %3d^2: split-fp16 %7.1f us (%5.0f TF/s eff; %6.1f us without the auto-scale pass)   MIOpen fp32 %7.1f us (%5.0f TF/s eff)" % (
+        Cin, Cout, H, t_ours * 1e3, fl / t_ours / 1e9, t_raw * 1e3, t_mi * 1e3, fl / t_mi / 1e9))
