@@ -105,11 +105,14 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(ConvArgs a)
     const float* sb = a.s ? a.s + (int64_t)b * Cin : nullptr;
     float in_sc = 1.0f, out_sc = 1.0f / CV_WSHIFT;
     if (a.in_amax) {
-        const float am = __uint_as_float(*a.in_amax);
-        if (am > 0.f && am < 3.0e38f) {
-            const int e = 9 - ilogbf(am);
-            in_sc = ldexpf(1.0f, e);
-            out_sc = ldexpf(1.0f / CV_WSHIFT, -e);
+        // power of two that brings max |x| into [512, 1024): exponent arithmetic on the bit patterns (clamped so that both factors stay
+        // normal floats); zero, subnormal, infinite or NaN maxima leave the scale at 1
+        const int be = (int)((*a.in_amax >> 23) & 0xFFu);          // biased exponent of max |x|
+        if (be >= 1 && be <= 254) {
+            int e = 9 - (be - 127);
+            e = e > 100 ? 100 : (e < -100 ? -100 : e);
+            in_sc = __uint_as_float((unsigned int)(127 + e) << 23);
+            out_sc = __uint_as_float((unsigned int)(127 - e - 8) << 23);          // 2^-e / 2^8
         }
     }
 
@@ -127,21 +130,25 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(ConvArgs a)
         t_lds[q] = task < CV_TASKS ? p * CV_REC + cp : -1;
         t_cp[q] = 2 * cp;
     }
-    float sv[CV_TPT][2];
-    auto fetch = [&](int cc, float (&v)[CV_TPT][2]) {
+    // fetch() only ISSUES the global loads of a chunk (raw values; the modulation factors ride along); every use of them -- scaling,
+    // splitting, the LDS writes -- happens in stash(), after the chunk's MFMAs.  A multiply inside fetch() would put the load latency
+    // (s_waitcnt vmcnt(0)) in front of the matrix work of every chunk: measured 90 -> 183 us for 512 -> 512 @ 64^2.
+    float sv[CV_TPT][2], ssc[CV_TPT][2];
+    auto fetch = [&](int cc, float (&v)[CV_TPT][2], float (&sc)[CV_TPT][2]) {
         const float* src = xb + (int64_t)(16 * cc) * H * W;
 #pragma unroll
         for (int q = 0; q < CV_TPT; ++q) {
-            v[q][0] = t_ok[q] ? src[t_off[q]] * in_sc : 0.f;
-            v[q][1] = t_ok[q] ? src[t_off[q] + H * W] * in_sc : 0.f;
-            if (sb && t_ok[q]) { v[q][0] *= sb[16 * cc + t_cp[q]]; v[q][1] *= sb[16 * cc + t_cp[q] + 1]; }
+            v[q][0] = t_ok[q] ? src[t_off[q]] : 0.f;
+            v[q][1] = t_ok[q] ? src[t_off[q] + H * W] : 0.f;
+            sc[q][0] = sb ? sb[16 * cc + t_cp[q]] : 1.0f;
+            sc[q][1] = sb ? sb[16 * cc + t_cp[q] + 1] : 1.0f;
         }
     };
-    auto stash = [&](int buf, const float (&v)[CV_TPT][2]) {
+    auto stash = [&](int buf, const float (&v)[CV_TPT][2], const float (&sc)[CV_TPT][2]) {
 #pragma unroll
         for (int q = 0; q < CV_TPT; ++q) {
             if (t_lds[q] < 0) continue;
-            const fl2_t f = {v[q][0], v[q][1]};
+            const fl2_t f = {v[q][0] * (sc[q][0] * in_sc), v[q][1] * (sc[q][1] * in_sc)};
             const h2_t hi = __builtin_convertvector(f, h2_t);
             const h2_t lo = __builtin_convertvector(f - __builtin_convertvector(hi, fl2_t), h2_t);
             lds[buf][t_lds[q]] = __builtin_bit_cast(uint32_t, hi);
@@ -152,8 +159,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(ConvArgs a)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
 
-    fetch(c_lo, sv);
-    stash(0, sv);
+    fetch(c_lo, sv, ssc);
+    stash(0, sv, ssc);
     __syncthreads();
     for (int ci = 0; ci < NC; ++ci) {
         const int cc = c_lo + ci, buf = ci & 1;
@@ -162,7 +169,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(ConvArgs a)
         uint4 A[9][2];
 #pragma unroll
         for (int t = 0; t < 9; ++t) { A[t][0] = ab[(int64_t)t * MT * 128]; A[t][1] = ab[(int64_t)t * MT * 128 + 64]; }
-        if (ci + 1 < NC) fetch(cc + 1, sv);
+        if (ci + 1 < NC) fetch(cc + 1, sv, ssc);
         const uint32_t* L = lds[buf];
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -182,7 +189,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(ConvArgs a)
         // the matrix instructions keep reading their operand registers for a while after issue: wait them out before
         // the conversion code below may recycle registers
         asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]));
-        if (ci + 1 < NC) stash(buf ^ 1, sv);
+        if (ci + 1 < NC) stash(buf ^ 1, sv, ssc);
         __syncthreads();
     }
     if (a.partial) {            // K-split: raw sums out, the epilogue runs in conv3x3_finish_kernel after the slices are added up

@@ -18,10 +18,22 @@ def timed(fn, n=10):
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         for _ in range(n): fn()
+    for _ in range(20):          # ~30 ms of the same work first: the clocks take a while to settle after an idle period
+        g.replay()
+    torch.cuda.synchronize()
     ts = []
-    for _ in range(7):
+    for _ in range(9):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(); g.replay(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b) / n)
+    return sorted(ts)[len(ts) // 2]
+def timed_eager(fn, n=10):
+    """one call at a time, the GPU idle in between (events around each call)"""
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(n):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
     return sorted(ts)[len(ts) // 2]
 for Cin, Cout, H in ((512, 512, 32), (1024, 512, 32), (512, 512, 64), (1024, 512, 64), (256, 256, 128), (512, 256, 128)):
     x = torch.randn(1, Cin, H, H, device=dev); w = torch.randn(Cout, Cin, 3, 3, device=dev) / (Cin * 9) ** 0.5
@@ -29,7 +41,14 @@ for Cin, Cout, H in ((512, 512, 32), (1024, 512, 32), (512, 512, 64), (1024, 512
     pk = conv.pack(w)
     t_ours = timed(lambda: conv.conv3x3(x, pk, Cout, bias=b))
     t_raw = timed(lambda: conv.conv3x3(x, pk, Cout, bias=b, autoscale=False))
+    sm = torch.rand(1, Cin, device=dev) + 0.5
+    dm = torch.rand(1, Cout, device=dev) + 0.5
+    nz = torch.randn(1, 1, H, H, device=dev); nwt = torch.tensor([0.1], device=dev)
+    t_mod = timed(lambda: conv.conv3x3(x, pk, Cout, s=sm, d=dm, noise=nz, noise_weight=nwt, bias=b))
     t_mi = timed(lambda: torch.nn.functional.conv2d(x, w, padding=1))
+    t_iso = timed_eager(lambda: conv.conv3x3(x, pk, Cout, bias=b, autoscale=False))
+    t_mi_iso = timed_eager(lambda: torch.nn.functional.conv2d(x, w, padding=1))
     fl = 2 * 9 * Cin * Cout * H * H
     print("%4d -> %4d @ %3d^2: split-fp16 %7.1f us (%5.0f TF/s eff; %6.1f us without the auto-scale pass)   MIOpen fp32 %7.1f us (%5.0f TF/s eff)" % (
         Cin, Cout, H, t_ours * 1e3, fl / t_ours / 1e9, t_raw * 1e3, t_mi * 1e3, fl / t_mi / 1e9))
+    print("        one call at a time (GPU idle in between): split-fp16 %.1f us, MIOpen %.1f us;  as a StyledConv (modulation, demodulation, noise, bias, act fused): %.1f us" % (t_iso * 1e3, t_mi_iso * 1e3, t_mod * 1e3))
