@@ -88,6 +88,7 @@ struct ConvArgs {
     int B, Cin, Cout, H, W;
 };
 
+template <bool HAS_S>      // modulated (s given) or plain: compile-time, so that neither variant carries the other's loads / multiplies
 __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(ConvArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds[2][CV_PIX * CV_REC];
@@ -102,7 +103,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(ConvArgs a)
     // K-split (small maps: too few output tiles to fill the GPU): this workgroup covers the channel chunks [c_lo, c_hi)
     const int c_lo = (NCT * ks) / a.ksplit, c_hi = (NCT * (ks + 1)) / a.ksplit, NC = c_hi - c_lo;
     const float* xb = a.x + (int64_t)b * Cin * H * W;
-    const float* sb = a.s ? a.s + (int64_t)b * Cin : nullptr;
+    const float* sb = HAS_S ? a.s + (int64_t)b * Cin : nullptr;
     float in_sc = 1.0f, out_sc = 1.0f / CV_WSHIFT;
     if (a.in_amax) {
         // power of two that brings max |x| into [512, 1024): exponent arithmetic on the bit patterns (clamped so that both factors stay
@@ -140,15 +141,14 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(ConvArgs a)
         for (int q = 0; q < CV_TPT; ++q) {
             v[q][0] = t_ok[q] ? src[t_off[q]] : 0.f;
             v[q][1] = t_ok[q] ? src[t_off[q] + H * W] : 0.f;
-            sc[q][0] = sb ? sb[16 * cc + t_cp[q]] : 1.0f;
-            sc[q][1] = sb ? sb[16 * cc + t_cp[q] + 1] : 1.0f;
+            if (HAS_S) { sc[q][0] = sb[16 * cc + t_cp[q]]; sc[q][1] = sb[16 * cc + t_cp[q] + 1]; }
         }
     };
     auto stash = [&](int buf, const float (&v)[CV_TPT][2], const float (&sc)[CV_TPT][2]) {
 #pragma unroll
         for (int q = 0; q < CV_TPT; ++q) {
             if (t_lds[q] < 0) continue;
-            const fl2_t f = {v[q][0] * (sc[q][0] * in_sc), v[q][1] * (sc[q][1] * in_sc)};
+            const fl2_t f = {HAS_S ? v[q][0] * (sc[q][0] * in_sc) : v[q][0] * in_sc, HAS_S ? v[q][1] * (sc[q][1] * in_sc) : v[q][1] * in_sc};
             const h2_t hi = __builtin_convertvector(f, h2_t);
             const h2_t lo = __builtin_convertvector(f - __builtin_convertvector(hi, fl2_t), h2_t);
             lds[buf][t_lds[q]] = __builtin_bit_cast(uint32_t, hi);
@@ -309,8 +309,9 @@ extern "C" int hav_conv3x3_split(float* y, const float* x, const void* packed, c
     a.y = y; a.x = x; a.blob = (const uint4*)packed; a.s = s; a.d = d; a.noise = noise; a.noise_weight = noise_weight; a.bias = bias;
     a.slope = slope; a.gain = gain; a.act = act; a.noise_batched = noise_batched;
     a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
-    hipLaunchKernelGGL(conv3x3_split_kernel, dim3((unsigned)((W / CV_COLS) * (H / CV_ROWS)), (unsigned)(Cout / 64), (unsigned)(B * a.ksplit)),
-                       dim3(256), 0, (hipStream_t)stream, a);
+    const dim3 grid((unsigned)((W / CV_COLS) * (H / CV_ROWS)), (unsigned)(Cout / 64), (unsigned)(B * a.ksplit));
+    if (s) hipLaunchKernelGGL(conv3x3_split_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(conv3x3_split_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
     HAV_LAUNCH_CHECK();
     if (a.partial) {
         const int64_t total = (int64_t)B * Cout * H * W;
