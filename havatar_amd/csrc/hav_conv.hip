@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(ConvArgs a)
         t_ok[q] = task < CV_TASKS && gy >= 0 && gy < H && gx >= 0 && gx < W;
         t_off[q] = (2 * cp) * H * W + gy * W + gx;
         t_lds[q] = task < CV_TASKS ? p * CV_REC + cp : -1;
-        t_cp[q] = 2 * cp;
+        t_cp[q] = task < CV_TASKS ? 2 * cp : 0;          // idle slots of the last round must not index past s[Cin]
     }
     // fetch() only ISSUES the global loads of a chunk (raw values; the modulation factors ride along); every use of them -- scaling,
     // splitting, the LDS writes -- happens in stash(), after the chunk's MFMAs.  A multiply inside fetch() would put the load latency
