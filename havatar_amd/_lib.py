@@ -75,6 +75,10 @@ def lib():
     L.hav_upfirdn2d_out_size.restype = i32
     L.hav_style_demod.argtypes = [vp, vp, vp, vp, vp, vp, f32, i32, i32, i32, i32, vp]
     L.hav_style_demod.restype = i32
+    L.hav_style_demod_blocks.argtypes = [i32, i32]
+    L.hav_style_demod_blocks.restype = i32
+    L.hav_style_demod_batched.argtypes = [vp, i32, i32, i32, vp, f32, i32, i32, i32, vp]
+    L.hav_style_demod_batched.restype = i32
     L.hav_styled_epilogue.argtypes = [vp, vp, vp, vp, vp, vp, f32, f32, i32, i32, i64, i32, vp]
     L.hav_styled_epilogue.restype = i32
     L.hav_demod_fwd.argtypes = [vp, vp, vp, vp, f32, f32, i32, i32, i32, i32, vp]

@@ -158,15 +158,12 @@ extern "C" int hav_fused_bias_act(void* out, const void* x, const void* b, const
 // instead of Cin/4), reduced through LDS.  Workgroup x = 0 also writes s.
 #define SD_OT 16
 #define SD_SL 64
-__global__ void __launch_bounds__(SD_OT * SD_SL) style_demod_kernel(float* __restrict__ s_out, float* __restrict__ d_out,
-                                                                    const float* __restrict__ style, const float* __restrict__ mod_w,
-                                                                    const float* __restrict__ mod_b, const float* __restrict__ wsq,
-                                                                    float eps, int D, int Cin, int Cout)
+__device__ __forceinline__ void style_demod_body(float* __restrict__ s_out, float* __restrict__ d_out, const float* __restrict__ st,
+                                                 const float* __restrict__ mod_w, const float* __restrict__ mod_b,
+                                                 const float* __restrict__ wsq, float eps, int D, int Cin, int Cout, int bx, float* s_sq)
 {
-    extern __shared__ float s_sq[];                 // [Cin] s^2, then [SD_SL][SD_OT] partial sums
     float* s_part = s_sq + Cin;
-    const int b = blockIdx.y, tid = threadIdx.x;
-    const float* st = style + (size_t)b * D;
+    const int tid = threadIdx.x;
     // s[i] = <style, mod_w[i,:]> + mod_b[i]: a group of G = pow2 >= D lanes (<= 64) per row, so that a wave reads whole rows of mod_w
     // coalesced (a thread per row walked D floats at a stride of D: 13 us for Cin = 512, D = 32); in-group tree sum, fixed order
     {
@@ -191,7 +188,7 @@ __global__ void __launch_bounds__(SD_OT * SD_SL) style_demod_kernel(float* __res
                 for (int o = G >> 1; o >= 1; o >>= 1) t += __shfl_xor(t, o, 64);
                 if (i < Cin && gl == 0) {
                     const float v = t + (mod_b ? mod_b[i] : 0.f);
-                    if (blockIdx.x == 0) s_out[(size_t)b * Cin + i] = v;
+                    if (bx == 0) s_out[i] = v;
                     s_sq[i] = v * v;
                 }
             }
@@ -200,7 +197,7 @@ __global__ void __launch_bounds__(SD_OT * SD_SL) style_demod_kernel(float* __res
     if (!d_out) return;
     __syncthreads();
     const int oi = tid & (SD_OT - 1), sl = tid / SD_OT;
-    const int o = blockIdx.x * SD_OT + oi;
+    const int o = bx * SD_OT + oi;
     float acc = 0.f;
     if (o < Cout) {
 #pragma unroll 8
@@ -211,8 +208,36 @@ __global__ void __launch_bounds__(SD_OT * SD_SL) style_demod_kernel(float* __res
     if (tid < SD_OT && o < Cout) {
         float t = 0.f;
         for (int q = 0; q < SD_SL; ++q) t += s_part[q * SD_OT + tid];
-        d_out[(size_t)b * Cout + o] = rsqrtf(t + eps);
+        d_out[o] = rsqrtf(t + eps);
     }
+}
+
+__global__ void __launch_bounds__(SD_OT * SD_SL) style_demod_kernel(float* __restrict__ s_out, float* __restrict__ d_out,
+                                                                    const float* __restrict__ style, const float* __restrict__ mod_w,
+                                                                    const float* __restrict__ mod_b, const float* __restrict__ wsq,
+                                                                    float eps, int D, int Cin, int Cout)
+{
+    extern __shared__ float s_sq[];                 // [Cin] s^2, then [SD_SL][SD_OT] partial sums
+    const int b = blockIdx.y;
+    style_demod_body(s_out + (size_t)b * Cin, d_out ? d_out + (size_t)b * Cout : nullptr, style + (size_t)b * D, mod_w, mod_b, wsq, eps, D,
+                     Cin, Cout, blockIdx.x, s_sq);
+}
+
+// All modulated convolutions of a generator in ONE launch: their style vectors only depend on the latent, which is known before the
+// first convolution runs, and one style_demod launch is latency-bound (13-20 us for 1 MB of wsq).  The layer table lives in device
+// memory; workgroup x belongs to the layer whose [first_block, first_block + blocks) range contains it.
+__global__ void __launch_bounds__(SD_OT * SD_SL) style_demod_batched_kernel(const HavStyleDemodLayer* __restrict__ layers, int n_layers,
+                                                                            const float* __restrict__ styles, float eps, int n_styles, int D)
+{
+    extern __shared__ float s_sq[];
+    int l = 0;
+    for (int q = 1; q < n_layers; ++q)
+        if ((int)blockIdx.x >= layers[q].first_block) l = q;
+    const HavStyleDemodLayer L = layers[l];
+    const int b = blockIdx.y;
+    style_demod_body(L.s_out + (size_t)b * L.Cin, L.d_out ? L.d_out + (size_t)b * L.Cout : nullptr,
+                     styles + ((size_t)b * n_styles + L.style_index) * D, L.mod_w, L.mod_b, L.wsq, eps, D, L.Cin, L.Cout,
+                     (int)blockIdx.x - L.first_block, s_sq);
 }
 
 extern "C" int hav_style_demod(float* s_out, float* d_out, const float* style, const float* mod_w, const float* mod_b,
@@ -225,6 +250,20 @@ extern "C" int hav_style_demod(float* s_out, float* d_out, const float* style, c
     const int gx = d_out ? (Cout + SD_OT - 1) / SD_OT : 1;
     hipLaunchKernelGGL(style_demod_kernel, dim3(gx, B), dim3(SD_OT * SD_SL), lds, (hipStream_t)stream, s_out, d_out, style, mod_w, mod_b,
                        wsq, eps, D, Cin, Cout);
+    HAV_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int hav_style_demod_blocks(int Cout, int demodulate) { return demodulate ? (Cout + SD_OT - 1) / SD_OT : 1; }
+
+extern "C" int hav_style_demod_batched(const HavStyleDemodLayer* layers_dev, int n_layers, int total_blocks, int max_cin,
+                                       const float* styles, float eps, int B, int n_styles, int D, void* stream)
+{
+    if (!layers_dev || !styles || n_layers < 1 || total_blocks < 1 || B < 1 || n_styles < 1 || D < 1 || max_cin < 1) return HAV_EINVAL;
+    const size_t lds = ((size_t)max_cin + SD_OT * SD_SL) * sizeof(float);
+    if (lds > 64 * 1024) return HAV_EUNSUP;
+    hipLaunchKernelGGL(style_demod_batched_kernel, dim3(total_blocks, B), dim3(SD_OT * SD_SL), lds, (hipStream_t)stream, layers_dev,
+                       n_layers, styles, eps, n_styles, D);
     HAV_LAUNCH_CHECK();
     return 0;
 }

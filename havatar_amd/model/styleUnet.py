@@ -179,6 +179,9 @@ class ModulatedConv2d(nn.Module, _InferenceCache):
         wsq_fn = lambda: (self._cached("wsq", self.weight, lambda: (self.scale * self.weight[0]).pow(2).sum((2, 3)).t().contiguous())
                           if self.demodulate else None)
         if self._hip_inference(style) and mod.activation is None:
+            pre = self.__dict__.pop("_pre", None)          # computed up front with the generator's other layers (_prefetch_styles)
+            if pre is not None:
+                return pre
             from ..native import fused
             mw = mod._cached("w", mod.weight, lambda: mod.weight * mod.scale)
             mb = mod._cached("b", mod.bias, lambda: mod.bias * mod.lr_mul) if mod.bias is not None else None
@@ -377,6 +380,32 @@ class ToRGB(nn.Module):
         return out
 
 
+def _prefetch_styles(owner, pairs, latent):
+    """HIP inference: the (s, d) vectors of all modulated convolutions of a generator in ONE launch, before the first convolution
+    (hav_style_demod_batched) -- they depend only on the latent.  pairs: [(ModulatedConv2d, index into latent[:, i])].  Each layer
+    picks its pair up in style_vectors(); anything the batched kernel does not take falls back to the per-layer launch."""
+    if not (latent.is_cuda and latent.dtype == torch.float32 and not torch.is_grad_enabled()
+            and os.environ.get("HAVATAR_STYLE_BATCH", "1") != "0"):
+        return
+    from ..native import fused
+    entries = []
+    for mc, idx in pairs:
+        mod = mc.modulation
+        if mod.activation is not None or mc.eps != pairs[0][0].eps:
+            return
+        mw = mod._cached("w", mod.weight, lambda mod=mod: mod.weight * mod.scale)
+        mb = mod._cached("b", mod.bias, lambda mod=mod: mod.bias * mod.lr_mul) if mod.bias is not None else None
+        wsq = (mc._cached("wsq", mc.weight, lambda mc=mc: (mc.scale * mc.weight[0]).pow(2).sum((2, 3)).t().contiguous())
+               if mc.demodulate else None)
+        entries.append((mw, mb, wsq, idx))
+    B = latent.shape[0]
+    plan = owner.__dict__.get("_style_plan")
+    if plan is None or plan.key != fused.StylePlan.make_key(entries, B, latent.device):
+        plan = owner.__dict__["_style_plan"] = fused.StylePlan(entries, B, latent.device)
+    for (mc, _), sd in zip(pairs, plan.run(latent.contiguous(), pairs[0][0].eps)):
+        mc.__dict__["_pre"] = sd
+
+
 def _mix_latents(styles, n_latent, inject_index):
     if len(styles) < 2:
         return styles[0].unsqueeze(1).repeat(1, n_latent, 1) if styles[0].ndim < 3 else styles[0]
@@ -492,6 +521,12 @@ class StyleGAN_zxc(nn.Module, _CondEncoder):
         elif noise is None:
             noise = [None] * self.num_layers if randomize_noise else [getattr(self.noises, f"noise_{i}") for i in range(self.num_layers)]
 
+        pairs = [(self.conv1.conv, 0)] + ([] if self.no_skip else [(self.to_rgb1.conv, 1)])
+        for k in range(len(self.convs) // 2):
+            pairs += [(self.convs[2 * k].conv, 1 + 2 * k), (self.convs[2 * k + 1].conv, 2 + 2 * k)]
+            if not self.no_skip:
+                pairs.append((self.to_rgbs[k].conv, 3 + 2 * k))
+        _prefetch_styles(self, pairs, latent)
         cond_list = self._encode(cond_feats)
         out = self.conv1(self.input(latent), latent[:, 0], noise=noise[0])
         skip = None if self.no_skip else self.to_rgb1(out, latent[:, 1])
@@ -562,6 +597,10 @@ class SWGAN_unet(nn.Module, _CondEncoder):
             styles = [truncation_latent + truncation * (s - truncation_latent) for s in styles]
         latent = _mix_latents(styles, self.n_latent, inject_index)
 
+        pairs = []
+        for k in range(len(self.convs) // 2):
+            pairs += [(self.convs[2 * k].conv, 2 * k), (self.convs[2 * k + 1].conv, 2 * k + 1), (self.to_rgbs[k].conv, 2 * k + 2)]
+        _prefetch_styles(self, pairs, latent)
         cond_list = self._encode(condition_img)
         i, skip, out = 0, None, None
         for conv_a, conv_b, n_a, n_b, to_rgb in zip(self.convs[::2], self.convs[1::2], noise[::2], noise[1::2], self.to_rgbs):

@@ -76,6 +76,52 @@ def style_demod(style, mod_w, mod_b, wsq=None, eps=1e-8):
     return s, d
 
 
+class StylePlan:
+    """Device-resident layer table of hav_style_demod_batched plus its output buffers: every modulated convolution of a generator
+    in one launch.  entries: [(mod_w [Cin,D], mod_b [Cin] | None, wsq [Cin,Cout] | None, style_index)]; rebuilt by the caller when a
+    weight-derived tensor moves (the key)."""
+
+    def __init__(self, entries, B, device):
+        import struct
+        L = _lib.lib()
+        self.key = self.make_key(entries, B, device)
+        self.B, self.n = B, len(entries)
+        self.keep = [t for e in entries for t in e[:3] if t is not None]          # the table holds raw pointers
+        self.out, rows, first = [], [], 0
+        self.max_cin = 0
+        for mw, mb, wsq, idx in entries:
+            mw = _f32c(mw, "mod_w")
+            Cin = mw.shape[0]
+            s = torch.empty(B, Cin, device=device, dtype=torch.float32)
+            d = torch.empty(B, wsq.shape[1], device=device, dtype=torch.float32) if wsq is not None else None
+            Cout = wsq.shape[1] if wsq is not None else 0
+            ptr = lambda t: t.data_ptr() if t is not None else 0
+            rows.append(struct.pack("<5Q4i", ptr(mw), ptr(mb), ptr(wsq), ptr(s), ptr(d), Cin, Cout, int(idx), first))
+            first += L.hav_style_demod_blocks(Cout, 1 if wsq is not None else 0)
+            self.max_cin = max(self.max_cin, Cin)
+            self.out.append((s, d))
+        self.total_blocks = first
+        self.D = entries[0][0].shape[1]
+        self.table = torch.frombuffer(bytearray(b"".join(rows)), dtype=torch.uint8).to(device)
+
+    @staticmethod
+    def make_key(entries, B, device):
+        return (B, str(device)) + tuple((t.data_ptr() if t is not None else 0) for e in entries for t in e[:3]) + tuple(e[3] for e in entries)
+
+    def run(self, styles, eps=1e-8):
+        """styles [B, n_styles, D] -> [(s, d | None)] per layer (buffers owned by the plan, overwritten by the next run)."""
+        styles = _f32c(styles, "styles")
+        B, n_styles, D = styles.shape
+        if B != self.B or D != self.D:
+            raise RuntimeError("StylePlan.run: built for B=%d, D=%d" % (self.B, self.D))
+        with torch.cuda.device(styles.device):
+            rc = _lib.lib().hav_style_demod_batched(C.c_void_p(self.table.data_ptr()), self.n, self.total_blocks, self.max_cin,
+                                                    C.c_void_p(styles.data_ptr()), float(eps), B, n_styles, D,
+                                                    C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _lib.check(rc, "hav_style_demod_batched")
+        return self.out
+
+
 def styled_epilogue(x, demod, noise, noise_weight, bias, negative_slope=0.2, scale=2 ** 0.5):
     """leaky_relu((x * demod[b,c] + noise_weight * noise) + bias[c]) * scale in one pass (hav_styled_epilogue)."""
     x = _f32c(x, "x")

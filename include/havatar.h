@@ -81,6 +81,23 @@ int hav_upfirdn2d_out_size(int in_h, int in_w, int kh, int kw, int up_x, int up_
 int hav_style_demod(float* s_out /*[B,Cin]*/, float* d_out /*[B,Cout] or NULL*/, const float* style /*[B,D]*/,
                     const float* mod_w /*[Cin,D]*/, const float* mod_b /*[Cin] or NULL*/, const float* wsq /*[Cin,Cout] or NULL*/,
                     float eps, int B, int D, int Cin, int Cout, void* stream);
+/* The same for every modulated convolution of a generator in ONE launch (their style vectors depend only on the latent, which is
+ * known before the first convolution runs): `layers_dev` is a device-resident table, layer l reads styles[b, style_index, :] and
+ * owns workgroups [first_block, first_block + hav_style_demod_blocks(Cout, d_out != NULL)); total_blocks = the sum; max_cin = the
+ * largest Cin of the table (sizes the LDS). */
+typedef struct HavStyleDemodLayer {
+    const float* mod_w;   /* [Cin, D] */
+    const float* mod_b;   /* [Cin] or NULL */
+    const float* wsq;     /* [Cin, Cout] or NULL (no demodulation) */
+    float* s_out;         /* [B, Cin] */
+    float* d_out;         /* [B, Cout] or NULL */
+    int32_t Cin, Cout;
+    int32_t style_index;
+    int32_t first_block;
+} HavStyleDemodLayer;
+int hav_style_demod_blocks(int Cout, int demodulate);
+int hav_style_demod_batched(const HavStyleDemodLayer* layers_dev, int n_layers, int total_blocks, int max_cin,
+                            const float* styles /*[B,n_styles,D]*/, float eps, int B, int n_styles, int D, void* stream);
 int hav_styled_epilogue(float* out, const float* x /*[B,C,HW]*/, const float* d /*[B,C] or NULL*/, const float* noise,
                         const float* noise_weight /*device scalar or NULL*/, const float* bias /*[C] or NULL*/, float slope,
                         float gain, int B, int C, int64_t HW, int noise_batched, void* stream);

@@ -242,6 +242,29 @@ def test_style_demod_matches_equal_linear_and_rsqrt():
         assert d2 is None and (s2.double() - (s_ref - 1.0)).abs().max().item() <= 2e-6 * s_ref.abs().max().item()
 
 
+def test_style_demod_batched_equals_the_per_layer_launches():
+    """hav_style_demod_batched (one launch for all modulated convolutions of a generator) == hav_style_demod per layer, bit for bit:
+    mixed Cin / Cout, a layer without demodulation, a layer without bias, B = 2, per-layer latent rows."""
+    from havatar_amd.native import fused
+    g = torch.Generator(device=DEV).manual_seed(5)
+    B, D, n_styles = 2, 32, 6
+    styles = torch.randn(B, n_styles, D, device=DEV, generator=g)
+    entries = []
+    for Cin, Cout, bias, demod, idx in ((512, 512, True, True, 0), (1024, 512, True, True, 3), (256, 12, True, False, 5),
+                                        (64, 24, False, True, 1), (7, 3, True, True, 2)):
+        mw = torch.randn(Cin, D, device=DEV, generator=g) / D ** 0.5
+        mb = torch.ones(Cin, device=DEV) if bias else None
+        wsq = torch.rand(Cin, Cout, device=DEV, generator=g) / Cin if demod else None
+        entries.append((mw, mb, wsq, idx))
+    plan = fused.StylePlan(entries, B, styles.device)
+    out = plan.run(styles, 1e-8)
+    for (mw, mb, wsq, idx), (s, d) in zip(entries, out):
+        s1, d1 = fused.style_demod(styles[:, idx].contiguous(), mw, mb, wsq, 1e-8)
+        assert torch.equal(s, s1)
+        assert (d is None and d1 is None) or torch.equal(d, d1)
+    assert plan.key == fused.StylePlan.make_key(entries, B, styles.device)
+
+
 def test_triplane_gather_forward_and_gradients_match_grid_sample():
     """hav_triplane_gather_{fwd,bwd} vs utils/util.py::sample_from_triplane_new under ATen autograd: values, d/dplanes, d/dq,
     including out-of-range taps (zeros padding) and a ragged query count."""
