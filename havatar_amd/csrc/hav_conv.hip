@@ -108,7 +108,14 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(ConvArgs a)
     if (a.in_amax) {
         // power of two that brings max |x| into [512, 1024): exponent arithmetic on the bit patterns (clamped so that both factors stay
         // normal floats); zero, subnormal, infinite or NaN maxima leave the scale at 1
-        const int be = (int)((*a.in_amax >> 23) & 0xFFu);          // biased exponent of max |x|
+        static_assert(HAV_ABSMAX_WORDS == 256, "four partial maxima per lane");
+        const uint4 w4 = reinterpret_cast<const uint4*>(a.in_amax)[lane];          // every wave folds the 256 partial maxima itself
+        unsigned int mb = w4.x > w4.y ? w4.x : w4.y;
+        mb = w4.z > mb ? w4.z : mb;
+        mb = w4.w > mb ? w4.w : mb;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { const unsigned int t = (unsigned int)__shfl_xor((int)mb, o, 64); mb = t > mb ? t : mb; }
+        const int be = (int)((mb >> 23) & 0xFFu);          // biased exponent of max |x|
         if (be >= 1 && be <= 254) {
             int e = 9 - (be - 127);
             e = e > 100 ? 100 : (e < -100 ? -100 : e);
@@ -223,14 +230,26 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(ConvArgs a)
     }
 }
 
-// max |x| over a tensor as the bit pattern of a non-negative float (atomicMax on the bits is a float max; NaNs are skipped)
+// max |x| over a tensor as HAV_ABSMAX_WORDS partial maxima (bit patterns of non-negative floats; NaNs are skipped by fmaxf): block k
+// owns the k-th slice and stores its maximum -- no atomics, nothing to zero beforehand, so the whole range control is ONE launch; the
+// consumer (conv3x3_split_kernel) folds the words with one load per thread and a wave reduction.
 __global__ void __launch_bounds__(256) absmax_kernel(unsigned int* __restrict__ out, const float* __restrict__ x, int64_t n)
 {
     __shared__ float red[4];
     float m = 0.f;
     const int64_t n4 = n >> 2;
     const float4* x4 = reinterpret_cast<const float4*>(x);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t per = (n4 + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = per * blockIdx.x, hi = (lo + per < n4) ? lo + per : n4;
+    int64_t i = lo + threadIdx.x;
+    for (; i + 768 < hi; i += 1024) {          // four independent 16-byte loads in flight per thread
+        const float4 v0 = x4[i], v1 = x4[i + 256], v2 = x4[i + 512], v3 = x4[i + 768];
+        m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v0.w))),
+                           fmaxf(fmaxf(fabsf(v1.x), fabsf(v1.y)), fmaxf(fabsf(v1.z), fabsf(v1.w)))));
+        m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(v2.x), fabsf(v2.y)), fmaxf(fabsf(v2.z), fabsf(v2.w))),
+                           fmaxf(fmaxf(fabsf(v3.x), fabsf(v3.y)), fmaxf(fabsf(v3.z), fabsf(v3.w)))));
+    }
+    for (; i < hi; i += 256) {
         const float4 v = x4[i];
         m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
     }
@@ -239,25 +258,14 @@ __global__ void __launch_bounds__(256) absmax_kernel(unsigned int* __restrict__ 
     for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-        // one atomic per workgroup, and only if it would raise the maximum (hundreds of atomics on one word are the kernel's whole cost)
-        const unsigned int bits = __float_as_uint(m);
-        if (bits > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, bits);
-    }
+    if (threadIdx.x == 0) out[blockIdx.x] = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
 }
 
 extern "C" int hav_absmax(void* out_bits, const float* x, int64_t n, void* stream)
 {
     if (!out_bits || !x || n < 0) return HAV_EINVAL;
-    hipError_t e = hipMemsetAsync(out_bits, 0, 4, (hipStream_t)stream);
-    if (e != hipSuccess) return (int)e;
-    if (n == 0) return 0;
     if (((uintptr_t)x & 15) != 0) return HAV_EUNSUP;          // float4 loads (every tensor this library is handed is 16-byte aligned)
-    int64_t blocks = (n / 4 + 255) / 256;
-    if (blocks > (int64_t)hav_num_cus() * 2) blocks = (int64_t)hav_num_cus() * 2;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (unsigned int*)out_bits, x, n);
+    hipLaunchKernelGGL(absmax_kernel, dim3(HAV_ABSMAX_WORDS), dim3(256), 0, (hipStream_t)stream, (unsigned int*)out_bits, x, n);
     HAV_LAUNCH_CHECK();
     return 0;
 }

@@ -61,7 +61,7 @@ def conv3x3(x, packed, Cout, s=None, d=None, noise=None, noise_weight=None, bias
     amax = None
     with torch.cuda.device(x.device):
         if autoscale:
-            amax = torch.empty(1, dtype=torch.int32, device=x.device)
+            amax = torch.empty(256, dtype=torch.int32, device=x.device)          # HAV_ABSMAX_WORDS partial maxima
             _lib.check(L.hav_absmax(_p(amax), _p(x), x.numel(), st), "hav_absmax")
         rc = L.hav_conv3x3_split(_p(y), _p(x), _p(packed), _p(s), _p(d), _p(noise), _p(noise_weight), _p(bias), float(slope),
                                  float(gain), int(bool(act)), nb, B, Cin, Cout, H, W, _p(scratch), _p(amax), st)

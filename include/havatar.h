@@ -180,10 +180,12 @@ int64_t hav_conv3x3_scratch_bytes(int B, int Cin, int Cout, int H, int W);
 int hav_conv3x3_split(float* y, const float* x, const void* packed, const float* s, const float* d, const float* noise,
                       const float* noise_weight, const float* bias, float slope, float gain, int act, int noise_batched, int B,
                       int Cin, int Cout, int H, int W, void* scratch, const void* in_amax, void* stream);
-/* Range control for inputs far from 1 (gradients): hav_absmax leaves the bit pattern of max |x| in a 4-byte device word; passed as
- * `in_amax` (NULL: off) the convolution scales its input by the power of two that brings that maximum to [512, 1024) before the
- * fp16 split and scales the result back -- exact, no host round trip.  Without it inputs below 2^-3 gradually lose the low part of the
- * split to fp16 subnormals (absolute operand error 2^-25) and inputs below 6e-8 vanish. */
+/* Range control for inputs far from 1 (gradients): hav_absmax leaves HAV_ABSMAX_WORDS partial maxima of |x| (bit patterns of
+ * non-negative floats, one per slice of x; no atomics, nothing to initialise) in a caller buffer of HAV_ABSMAX_WORDS * 4 bytes,
+ * 16-byte aligned; passed as `in_amax` (NULL: off) the convolution folds them and scales its input by the power of two that brings
+ * the maximum to [512, 1024) before the fp16 split and scales the result back -- exact, no host round trip.  Without it inputs below
+ * 2^-3 gradually lose the low part of the split to fp16 subnormals (absolute operand error 2^-25) and inputs below 6e-8 vanish. */
+#define HAV_ABSMAX_WORDS 256
 int hav_absmax(void* out_bits, const float* x, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------

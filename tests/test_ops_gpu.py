@@ -445,6 +445,28 @@ def test_conv3x3_split_matches_fp64_convolution(B, Cin, Cout, H, W, full):
 
 
 @pytest.mark.gpu
+def test_absmax_partial_maxima_fold_to_the_tensor_maximum():
+    """hav_absmax: HAV_ABSMAX_WORDS partial maxima whose fold is max |x| exactly -- ragged sizes (n % 4 != 0, fewer elements than
+    slices), a NaN (skipped, as fmaxf does), an empty tensor; no word is left unwritten (the buffer starts as garbage)."""
+    import ctypes as C
+    from havatar_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator(device=DEV).manual_seed(9)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for n in (0, 1, 3, 257, 4 * 256 * 256 + 2, 512 * 64 * 64):
+        x = torch.randn(max(n, 4), device=DEV, generator=g)[:n] * 3e-6 if n else torch.empty(0, device=DEV)
+        if n > 100:
+            x[n // 2] = float("nan")
+            x[n - 1] = -7.5e-6
+        words = torch.full((256,), 0x7FFFFFFF, dtype=torch.int32, device=DEV)
+        base = torch.zeros(max(n, 4), device=DEV)          # 16-byte aligned storage
+        base[:n] = x
+        assert L.hav_absmax(C.c_void_p(words.data_ptr()), C.c_void_p(base.data_ptr()), n, st) == 0
+        got = words.view(torch.float32).max().item()
+        want = torch.nan_to_num(base[:n], nan=0.0).abs().max().item() if n else 0.0
+        assert got == want, (n, got, want)
+
+
 def test_conv3x3_split_refuses_unsupported_shapes():
     from havatar_amd.native import conv
     dev = torch.device("cuda:0")
