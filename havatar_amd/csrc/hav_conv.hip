@@ -330,3 +330,251 @@ extern "C" int hav_conv3x3_split(float* y, const float* x, const void* packed, c
     }
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// The up-sampling StyledConv (model/styleUnet.py:236-243: conv_transpose2d(x * s, W^T, stride 2) -> Blur(4x4, pad (1,1)) -> demodulate ->
+// noise -> bias -> leaky-ReLU) in two launches:
+//   1. hav_gemm_split:   col[b, 9 o + t, p] = sum_i W[i, o, t] * (s[b,i] * x[b, i, p])        -- a [9 Cout x Cin] x [Cin x HW] product on the
+//      split-fp16 matrix path (three products per k step, fp32 accumulate, as above).  That IS the transposed convolution before its
+//      scatter: MIOpen runs the same product in fp32 (85 TFLOP/s), then Col2Im, and ATen / our upfirdn2d the blur and the epilogue.
+//   2. hav_upconv_finish: the stride-2 scatter (col2im), the 4x4 FIR and the block's epilogue in one pass: a workgroup builds a tile of
+//      the (2H+1) x (2W+1) transposed-convolution output in LDS -- every element gathers its <= 4 contributing taps, no atomics --
+//      and filters it from there.
+//
+// GEMM tiling: workgroup = 4 waves = 128 (M) x 128 (N); wave (wm, wn) owns 64 x 64 = 2 x 2 MFMA tiles (64 accumulator VGPRs): per
+// 16-wide k step a wave reads 4 A fragments (L2, pre-packed) and 4 B fragments (LDS) for 12 MFMAs.  K advances in chunks of 32; the
+// chunk's [32 x 128] slab of x is modulated, split and written to LDS as 80-byte (pixel, 16-k group) records, double-buffered, with
+// the next chunk's global loads in flight across the MFMAs (consumed only after them, cf. conv3x3_split_kernel).
+#define GM_KC 32
+#define GM_NT 128
+#define GM_TPT ((GM_NT * (GM_KC / 2)) / 256)          // (pixel, channel pair) staging tasks per thread and chunk
+
+extern "C" int64_t hav_gemm_packed_bytes(int M, int K) { return (int64_t)(K / 16) * (((M + 127) / 128) * 4) * 2 * 64 * 16; }
+
+// fragment (k step kk, M tile m, part): lane (i, h) holds W[32m + i][16kk + 8h + e] * wmul * 2^8, e = 0..7 (rows >= M: zero)
+__global__ void __launch_bounds__(256) gemm_pack_kernel(uint4* __restrict__ blob, const float* __restrict__ w, int M, int K, float wmul,
+                                                        int64_t total)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63), i = lane & 31, h = lane >> 5;
+    int64_t q = idx >> 6;
+    const int part = (int)(q & 1); q >>= 1;
+    const int MT = ((M + 127) / 128) * 4;
+    const int m = (int)(q % MT);
+    const int kk = (int)(q / MT);
+    const int row = 32 * m + i;
+    uint32_t o[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        float v[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) v[u] = row < M ? w[(int64_t)row * K + 16 * kk + 8 * h + 2 * d + u] * (wmul * CV_WSHIFT) : 0.f;
+        const fl2_t f = {v[0], v[1]};
+        const h2_t hi = __builtin_convertvector(f, h2_t);
+        const h2_t lo = __builtin_convertvector(f - __builtin_convertvector(hi, fl2_t), h2_t);
+        o[d] = __builtin_bit_cast(uint32_t, part ? lo : hi);
+    }
+    blob[idx] = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+extern "C" int hav_gemm_pack(void* blob, const float* w, int M, int K, float wmul, void* stream)
+{
+    if (!blob || !w || M < 1 || K < 16) return HAV_EINVAL;
+    if (K % GM_KC) return HAV_EUNSUP;
+    const int64_t total = hav_gemm_packed_bytes(M, K) / 16;
+    hipLaunchKernelGGL(gemm_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (uint4*)blob, w, M, K, wmul,
+                       total);
+    HAV_LAUNCH_CHECK();
+    return 0;
+}
+
+struct GemmArgs {
+    float* y; const float* x; const uint4* blob; const float* s;
+    int B, M, K, N;
+};
+
+template <bool HAS_S>
+__global__ void __launch_bounds__(256, 2) gemm_split_kernel(GemmArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2][2 * GM_NT * CV_REC];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int n0 = blockIdx.x * GM_NT;
+    const int b = blockIdx.z;
+    const int K = a.K, N = a.N, NC = K / GM_KC;
+    const int MT = ((a.M + 127) / 128) * 4;
+    const int mt0 = blockIdx.y * 4 + wm * 2;          // this wave's two 32-row M tiles
+    const float* xb = a.x + (int64_t)b * K * N + n0;
+    const float* sb = HAS_S ? a.s + (int64_t)b * K : nullptr;
+
+    // staging task q of this thread: pixel p = tid & 127, channel pair cp = (tid >> 7) + 2 q  (0..15)
+    const int t_p = tid & (GM_NT - 1), t_c0 = tid >> 7;
+    float sv[GM_TPT][2], ssc[GM_TPT][2];
+    auto fetch = [&](int cc, float (&v)[GM_TPT][2], float (&sc)[GM_TPT][2]) {
+        const float* src = xb + (int64_t)(GM_KC * cc) * N + t_p;
+#pragma unroll
+        for (int q = 0; q < GM_TPT; ++q) {
+            const int k = 2 * (t_c0 + 2 * q);
+            v[q][0] = src[(int64_t)k * N];
+            v[q][1] = src[(int64_t)(k + 1) * N];
+            if (HAS_S) { sc[q][0] = sb[GM_KC * cc + k]; sc[q][1] = sb[GM_KC * cc + k + 1]; }
+        }
+    };
+    auto stash = [&](int buf, const float (&v)[GM_TPT][2], const float (&sc)[GM_TPT][2]) {
+#pragma unroll
+        for (int q = 0; q < GM_TPT; ++q) {
+            const int cp = t_c0 + 2 * q, g = cp >> 3, ci = cp & 7;
+            const fl2_t f = {HAS_S ? v[q][0] * sc[q][0] : v[q][0], HAS_S ? v[q][1] * sc[q][1] : v[q][1]};
+            const h2_t hi = __builtin_convertvector(f, h2_t);
+            const h2_t lo = __builtin_convertvector(f - __builtin_convertvector(hi, fl2_t), h2_t);
+            const int at = (g * GM_NT + t_p) * CV_REC + ci;
+            lds[buf][at] = __builtin_bit_cast(uint32_t, hi);
+            lds[buf][at + 8] = __builtin_bit_cast(uint32_t, lo);
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][0][r] = 0.f; acc[0][1][r] = 0.f; acc[1][0][r] = 0.f; acc[1][1][r] = 0.f; }
+
+    fetch(0, sv, ssc);
+    stash(0, sv, ssc);
+    __syncthreads();
+    for (int cc = 0; cc < NC; ++cc) {
+        const int buf = cc & 1;
+        const uint4* ab = a.blob + ((int64_t)(2 * cc) * MT + mt0) * 128 + lane;
+        uint4 A[2][2][2];          // [k step][M tile][part]
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                A[g][mi][0] = ab[((int64_t)g * MT + mi) * 128];
+                A[g][mi][1] = ab[((int64_t)g * MT + mi) * 128 + 64];
+            }
+        if (cc + 1 < NC) fetch(cc + 1, sv, ssc);
+        const uint32_t* L = lds[buf];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            f16x8_t xh[2], xl[2];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int p = 64 * wn + 32 * ni + j;
+                xh[ni] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(L + (g * GM_NT + p) * CV_REC + 4 * h));
+                xl[ni] = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(L + (g * GM_NT + p) * CV_REC + 8 + 4 * h));
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const f16x8_t ah = __builtin_bit_cast(f16x8_t, A[g][mi][0]), al = __builtin_bit_cast(f16x8_t, A[g][mi][1]);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh[ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl[ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh[ni], acc[mi][ni], 0, 0, 0);
+                }
+            }
+        }
+        // the matrix instructions keep reading their operand registers after issue: wait them out before stash() may
+        // recycle registers
+        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+        if (cc + 1 < NC) stash(buf ^ 1, sv, ssc);
+        __syncthreads();
+    }
+    float* yb = a.y + (int64_t)b * a.M * N + n0;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * (mt0 + mi) + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row < a.M) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) yb[(int64_t)row * N + 64 * wn + 32 * ni + j] = acc[mi][ni][r] * (1.0f / CV_WSHIFT);
+            }
+        }
+}
+
+extern "C" int hav_gemm_split(float* y, const float* x, const void* packed, const float* s, int B, int M, int K, int N, void* stream)
+{
+    if (!y || !x || !packed || B < 1 || M < 1 || K < GM_KC || N < GM_NT) return HAV_EINVAL;
+    if ((K % GM_KC) || (N % GM_NT)) return HAV_EUNSUP;
+    GemmArgs a;
+    a.y = y; a.x = x; a.blob = (const uint4*)packed; a.s = s; a.B = B; a.M = M; a.K = K; a.N = N;
+    const dim3 grid((unsigned)(N / GM_NT), (unsigned)((M + 127) / 128), (unsigned)B);
+    if (s) hipLaunchKernelGGL(gemm_split_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(gemm_split_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    HAV_LAUNCH_CHECK();
+    return 0;
+}
+
+// col2im (stride 2, 3x3, no padding) + 4x4 FIR with padding (1,1) + demodulation / noise / bias / leaky-ReLU, one pass.
+//   z[P,Q]  = sum over taps (ky,kx) with P-ky, Q-kx even and inside the input:  col[o*9 + 3ky+kx][(P-ky)/2, (Q-kx)/2]     (2H+1 x 2W+1)
+//   y[Y,X]  = sum_{t,u} fir[3-t][3-u] * zpad[Y+t, X+u],  zpad = z with a one-pixel zero border                           (2H x 2W)
+// Workgroup = one (b, o) plane x UF_TR output rows: the z rows Y0-1 .. Y0+UF_TR+1 go to LDS first.
+#define UF_TR 16
+struct UpFinishArgs {
+    float* y; const float* col; const float* fir; const float* d; const float* noise; const float* noise_weight; const float* bias;
+    float slope, gain;
+    int act, noise_batched, B, Cout, H, W;
+};
+__global__ void __launch_bounds__(256) upconv_finish_kernel(UpFinishArgs a)
+{
+    extern __shared__ float zt[];          // [UF_TR + 3][ZW], ZW = 2W + 4 (z columns -1 .. 2W+2; column q of z at index q + 1)
+    const int H = a.H, W = a.W, OH = 2 * H, OW = 2 * W, ZW = OW + 4;
+    const int o = blockIdx.y, b = blockIdx.z, Y0 = blockIdx.x * UF_TR;
+    const float* cb = a.col + ((int64_t)b * a.Cout + o) * 9 * H * W;
+    for (int e = threadIdx.x; e < (UF_TR + 3) * ZW; e += 256) {
+        const int zr = e / ZW, zc = e - zr * ZW;
+        const int P = Y0 - 1 + zr, Q = zc - 1;
+        float v = 0.f;
+        if (P >= 0 && P <= OH && Q >= 0 && Q <= OW) {
+            // taps with the right parity: P even -> ky in {0, 2}, odd -> ky = 1 (same for Q)
+            const int ky0 = P & 1, kx0 = Q & 1;
+            for (int ky = ky0; ky < 3; ky += 2) {
+                const int i = (P - ky) >> 1;
+                if (i < 0 || i >= H) continue;
+                for (int kx = kx0; kx < 3; kx += 2) {
+                    const int jj = (Q - kx) >> 1;
+                    if (jj < 0 || jj >= W) continue;
+                    v += cb[(int64_t)(3 * ky + kx) * H * W + (int64_t)i * W + jj];
+                }
+            }
+        }
+        zt[e] = v;
+    }
+    __syncthreads();
+    float f[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) f[q] = a.fir[15 - q];          // flipped: upfirdn2d is a true convolution
+    const float nw = (a.noise && a.noise_weight) ? *a.noise_weight : 0.f;
+    const float dd = a.d ? a.d[(int64_t)b * a.Cout + o] : 1.f, bb = a.bias ? a.bias[o] : 0.f;
+    float* yb = a.y + ((int64_t)b * a.Cout + o) * OH * OW;
+    for (int e = threadIdx.x; e < UF_TR * OW; e += 256) {
+        const int r = e / OW, X = e - r * OW, Y = Y0 + r;
+        if (Y >= OH) break;
+        float v = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v = fmaf(f[4 * t + u], zt[(r + t) * ZW + X + u], v);
+        if (a.d) v = v * dd;
+        if (a.noise) v = v + nw * a.noise[(a.noise_batched ? (int64_t)b * OH * OW : 0) + (int64_t)Y * OW + X];
+        if (a.bias) v = v + bb;
+        if (a.act) v = (v > 0.f ? v : v * a.slope) * a.gain;
+        yb[(int64_t)Y * OW + X] = v;
+    }
+}
+
+extern "C" int hav_upconv_finish(float* y, const float* col, const float* fir4x4, const float* d, const float* noise, const float* noise_weight,
+                                 const float* bias, float slope, float gain, int act, int noise_batched, int B, int Cout, int H, int W,
+                                 void* stream)
+{
+    if (!y || !col || !fir4x4 || B < 1 || Cout < 1 || H < 1 || W < 1) return HAV_EINVAL;
+    const size_t lds = (size_t)(UF_TR + 3) * (2 * W + 4) * sizeof(float);
+    if (lds > 64 * 1024) return HAV_EUNSUP;
+    UpFinishArgs a;
+    a.y = y; a.col = col; a.fir = fir4x4; a.d = d; a.noise = noise; a.noise_weight = noise_weight; a.bias = bias;
+    a.slope = slope; a.gain = gain; a.act = act; a.noise_batched = noise_batched; a.B = B; a.Cout = Cout; a.H = H; a.W = W;
+    hipLaunchKernelGGL(upconv_finish_kernel, dim3((unsigned)((2 * H + UF_TR - 1) / UF_TR), (unsigned)Cout, (unsigned)B), dim3(256), lds,
+                       (hipStream_t)stream, a);
+    HAV_LAUNCH_CHECK();
+    return 0;
+}

@@ -171,6 +171,14 @@ class ModulatedConv2d(nn.Module, _InferenceCache):
     def packed3x3(self):
         return self._cached("w3x3", self.weight, lambda: _conv.pack(self.weight[0], self.scale))
 
+    def fused_upconv_ok(self, input):
+        """the up-sampling 3x3 (conv_transpose2d stride 2 -> 4x4 blur with padding (1,1)) in a shape hav_gemm_split + hav_upconv_finish take."""
+        return (self.kernel_size == 3 and self.upsample and _fused_conv_enabled() and os.environ.get("HAVATAR_FUSED_UPCONV", "1") != "0"
+                and tuple(self.blur.kernel.shape) == (4, 4) and tuple(self.blur.pad) == (1, 1) and _conv.upconv_eligible(input, self.weight[0]))
+
+    def packed_upconv(self):
+        return self._cached("wup", self.weight, lambda: _conv.pack_upconv(self.weight[0], self.scale))
+
     def style_vectors(self, style):
         """(s [B,Cin], d [B,Cout] | None).  HIP inference: one launch (hav_style_demod) instead of EqualLinear + bias + square +
         matmul + eps + rsqrt; otherwise the ATen sequence."""
@@ -347,6 +355,16 @@ class StyledConv(nn.Module):
                 noise = input.new_empty(b, 1, h, w).normal_()
             return _conv.conv3x3(input, self.conv.packed3x3(), self.conv.out_channel, s=s, d=d, noise=noise, noise_weight=self.noise.weight,
                                  bias=self.activate.bias, slope=self.activate.negative_slope, gain=self.activate.scale, act=True)
+        if self.conv._hip_inference(input) and self.conv.fused_upconv_ok(input):
+            # HIP inference, up-sampling 3x3: the transposed convolution as a split-fp16 matrix product, then scatter + blur + the
+            # block's epilogue in one pass (hav_gemm_split + hav_upconv_finish) instead of MIOpen GEMM + Col2Im + upfirdn2d + epilogue
+            s, d = self.conv.style_vectors(style)
+            if noise is None:
+                b, _, h, w = input.shape
+                noise = input.new_empty(b, 1, 2 * h, 2 * w).normal_()
+            return _conv.upconv3x3(input, self.conv.packed_upconv(), self.conv.out_channel, self.conv.blur.kernel, s=s, d=d, noise=noise,
+                                   noise_weight=self.noise.weight, bias=self.activate.bias, slope=self.activate.negative_slope,
+                                   gain=self.activate.scale, act=True)
         if self.conv._hip_inference(input):
             # HIP inference: demodulation * noise injection + bias + leaky-relu in ONE pass (hav_styled_epilogue) instead of four
             from ..native import fused

@@ -98,3 +98,55 @@ class _Conv3x3Split(torch.autograd.Function):
 def conv3x3_autograd(x, w):
     """x [B,Cin,H,W], w [Cout,Cin,3,3] (already scaled): differentiable 3x3 / stride 1 / padding 1 convolution, see _Conv3x3Split."""
     return _Conv3x3Split.apply(x.contiguous(), w.contiguous())
+
+
+def upconv_eligible(x, weight):
+    """weight [Cout,Cin,3,3] (the ModulatedConv2d parameter); x [B,Cin,H,W] float32 on a HIP device: shapes hav_gemm_split +
+    hav_upconv_finish take."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and weight.dim() == 4):
+        return False
+    Cout, Cin, kh, kw = weight.shape
+    B, Ci, H, W = x.shape
+    return kh == 3 and kw == 3 and Ci == Cin and Cin % 32 == 0 and (H * W) % 128 == 0 and (19 * (2 * W + 4) * 4) <= 64 * 1024
+
+
+def pack_upconv(weight, wmul=1.0):
+    """[Cout,Cin,3,3] -> fragments of the [9 Cout x Cin] matrix A[9 o + t, i] = wmul * W[o, i, t]: conv_transpose2d(x, W^T) before its
+    scatter is A . x."""
+    w = weight.detach()
+    Cout, Cin = w.shape[:2]
+    a = w.permute(0, 2, 3, 1).reshape(Cout * 9, Cin).contiguous()
+    L = _lib.lib()
+    blob = torch.empty(int(L.hav_gemm_packed_bytes(Cout * 9, Cin)), dtype=torch.uint8, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(L.hav_gemm_pack(_p(blob), _p(a), Cout * 9, Cin, float(wmul), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                   "hav_gemm_pack")
+    return blob
+
+
+def upconv3x3(x, packed, Cout, fir, s=None, d=None, noise=None, noise_weight=None, bias=None, slope=0.2, gain=2 ** 0.5, act=True):
+    """y [B,Cout,2H,2W] = act(d * blur(conv_transpose2d(s * x, W, stride 2)) + noise_weight * noise + bias) * gain: the up-sampling
+    StyledConv (model/styleUnet.py:236-243,565-599) as hav_gemm_split + hav_upconv_finish.  fir: the blur's [4,4] kernel (with the
+    factor^2 gain folded in, as Blur holds it)."""
+    x = x.contiguous()
+    B, Cin, H, W = x.shape
+    col = torch.empty(B, Cout * 9, H * W, dtype=torch.float32, device=x.device)
+    y = torch.empty(B, Cout, 2 * H, 2 * W, dtype=torch.float32, device=x.device)
+    nb = 0
+    if noise is not None:
+        noise = noise.contiguous()
+        if noise.numel() == B * 4 * H * W and B > 1:
+            nb = 1
+        elif noise.numel() != 4 * H * W:
+            raise RuntimeError("upconv3x3: noise must be [1,1,2H,2W] or [B,1,2H,2W]")
+    fir = fir.contiguous()
+    if tuple(fir.shape) != (4, 4) or fir.dtype != torch.float32:
+        raise RuntimeError("upconv3x3: a [4,4] float32 FIR kernel is required")
+    L = _lib.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    with torch.cuda.device(x.device):
+        _lib.check(L.hav_gemm_split(_p(col), _p(x), _p(packed), _p(s.contiguous() if s is not None else None), B, Cout * 9, Cin, H * W, st),
+                   "hav_gemm_split")
+        _lib.check(L.hav_upconv_finish(_p(y), _p(col), _p(fir), _p(d), _p(noise), _p(noise_weight), _p(bias), float(slope), float(gain),
+                                       int(bool(act)), nb, B, Cout, H, W, st), "hav_upconv_finish")
+    return y

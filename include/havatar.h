@@ -188,6 +188,21 @@ int hav_conv3x3_split(float* y, const float* x, const void* packed, const float*
 #define HAV_ABSMAX_WORDS 256
 int hav_absmax(void* out_bits, const float* x, int64_t n, void* stream);
 
+/* The up-sampling StyledConv of the StyleGAN blocks (model/styleUnet.py:236-243: conv_transpose2d(x * s, W, stride 2) -> 4x4 FIR with
+ * padding (1,1) -> demodulation -> noise -> bias -> leaky-ReLU) in two launches:
+ *   hav_gemm_split     y[b, m, n] = sum_k A[m, k] * (s[b, k] * x[b, k, n])    split-fp16 matrix path, fp32-class (K % 32 == 0, N % 128 == 0;
+ *                      A packed by hav_gemm_pack from a row-major [M, K] matrix with `wmul` folded in; s nullable)
+ *   hav_upconv_finish  col [B, Cout*9, H*W] (row 9 o + 3 ky + kx: the product above with A[9 o + t, i] = W[i, o, t]) -> y [B, Cout, 2H, 2W]:
+ *                      stride-2 scatter, FIR (`fir4x4`: the 16 taps as upfirdn2d takes them) and the epilogue
+ *                      act(d[b,o] * . + noise_weight * noise + bias[o]) * gain, every term nullable as in hav_conv3x3_split. */
+int64_t hav_gemm_packed_bytes(int M, int K);
+int hav_gemm_pack(void* packed, const float* w /*[M,K]*/, int M, int K, float wmul, void* stream);
+int hav_gemm_split(float* y /*[B,M,N]*/, const float* x /*[B,K,N]*/, const void* packed, const float* s /*[B,K] or NULL*/, int B, int M,
+                   int K, int N, void* stream);
+int hav_upconv_finish(float* y, const float* col, const float* fir4x4, const float* d, const float* noise, const float* noise_weight,
+                      const float* bias, float slope, float gain, int act, int noise_batched, int B, int Cout, int H, int W,
+                      void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Trilinear x2 up-sampling of a [N,C,D,H,W] float32 volume and its adjoint -- nn.Upsample(scale_factor=2, mode='trilinear',
  * align_corners=False), the first stage of every UpConv3DBlock of the skinning-volume decoder

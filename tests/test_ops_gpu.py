@@ -467,6 +467,48 @@ def test_absmax_partial_maxima_fold_to_the_tensor_maximum():
         assert got == want, (n, got, want)
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(1, 512, 512, 16, 16), (1, 512, 256, 64, 64), (2, 64, 64, 32, 32), (1, 128, 24, 16, 64)])
+def test_upconv3x3_matches_fp64_transposed_convolution_and_blur(B, Cin, Cout, H, W):
+    """hav_gemm_split + hav_upconv_finish vs the reference statement in fp64: conv_transpose2d(x * s, W, stride 2) -> upfirdn2d(4x4,
+    pad (1,1)) -> * d + nw * noise + bias -> leaky-ReLU * sqrt(2) (model/styleUnet.py:236-243,565-599).  Yardstick: the same chain in
+    fp32 through ATen (what it replaces); M = 9 Cout not a multiple of 128 exercises the padded rows."""
+    from havatar_amd.native import conv
+    from havatar_amd.model.styleUnet import make_kernel
+    g = torch.Generator(device=DEV).manual_seed(B * 1000 + Cin + Cout + H)
+    x = torch.randn(B, Cin, H, W, device=DEV, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, device=DEV, generator=g)
+    scale = 1.0 / (Cin * 9) ** 0.5
+    s = 1.0 + 0.3 * torch.randn(B, Cin, device=DEV, generator=g)
+    d = 0.5 + torch.rand(B, Cout, device=DEV, generator=g)
+    noise = torch.randn(1, 1, 2 * H, 2 * W, device=DEV, generator=g)
+    nw = torch.full((1,), 0.37, device=DEV)
+    bias = 0.2 * torch.randn(Cout, device=DEV, generator=g)
+    fir = (make_kernel((1, 3, 3, 1)) * 4).to(DEV)
+    assert conv.upconv_eligible(x, w)
+
+    def chain(dt):
+        xs = x.to(dt) * s.to(dt).view(B, Cin, 1, 1)
+        z = torch.nn.functional.conv_transpose2d(xs, (w.to(dt) * scale).transpose(0, 1), stride=2)
+        zp = torch.nn.functional.pad(z, (1, 1, 1, 1))
+        k = fir.to(dt).flip(0, 1).view(1, 1, 4, 4).expand(Cout, 1, 4, 4)
+        yb = torch.nn.functional.conv2d(zp, k, groups=Cout)
+        v = yb * d.to(dt).view(B, Cout, 1, 1) + nw.to(dt) * noise.to(dt) + bias.to(dt).view(1, -1, 1, 1)
+        return torch.nn.functional.leaky_relu(v, 0.2) * 2 ** 0.5
+
+    truth = chain(torch.float64)
+    y = conv.upconv3x3(x, conv.pack_upconv(w, scale), Cout, fir, s=s, d=d, noise=noise, noise_weight=nw, bias=bias)
+    assert y.shape == (B, Cout, 2 * H, 2 * W)
+    err = (y.double() - truth).abs().max().item()
+    ref = (chain(torch.float32).double() - truth).abs().max().item()
+    assert err <= max(3 * ref, 2e-6 * truth.abs().max().item()), (err, ref)
+    # plain product: no modulation, no epilogue terms
+    y0 = conv.upconv3x3(x, conv.pack_upconv(w, scale), Cout, fir, act=False)
+    z = torch.nn.functional.conv_transpose2d(x.double(), (w.double() * scale).transpose(0, 1), stride=2)
+    t0 = torch.nn.functional.conv2d(torch.nn.functional.pad(z, (1, 1, 1, 1)), fir.double().flip(0, 1).view(1, 1, 4, 4).expand(Cout, 1, 4, 4),
+                                    groups=Cout)
+    assert (y0.double() - t0).abs().max().item() <= 2e-6 * t0.abs().max().item()
+
+
 def test_conv3x3_split_refuses_unsupported_shapes():
     from havatar_amd.native import conv
     dev = torch.device("cuda:0")
