@@ -100,6 +100,9 @@ def lib():
     L.hav_mlp_blob_bytes.restype = i64
     L.hav_mlp_pack.argtypes = [vp, C.POINTER(HavMlpWeights), vp]
     L.hav_mlp_pack.restype = i32
+    for fn in (L.hav_haar_dwt, L.hav_haar_idwt):
+        fn.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
+        fn.restype = i32
     L.hav_gemm_packed_bytes.argtypes = [i32, i32]
     L.hav_gemm_packed_bytes.restype = i64
     L.hav_gemm_pack.argtypes = [vp, vp, i32, i32, f32, vp]

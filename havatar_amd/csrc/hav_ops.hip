@@ -797,6 +797,119 @@ extern "C" int hav_upfirdn2d(void* out, const void* in, const float* kernel, int
 }
 
 // ================================================================================================
+// Haar analysis / synthesis of the wavelet-domain skip path of SWGAN_unet (model/styleUnet.py:510-560 HaarTransform /
+// InverseHaarTransform: four upfirdn2d calls with the 2x2 kernels ll, lh, hl, hh + a cat, resp. four up-sampling calls + three adds)
+// as ONE pass each.  Arithmetic per output element is the unfused sequence's, operation for operation (tap order i asc, j asc with
+// the flipped kernel and fused multiply-adds for the analysis; one rounded product per band summed ((ll + lh) + hl) + hh for the
+// synthesis), so the results are bit-identical to the four-call path -- asserted in tests/test_ops_gpu.py.
+//   dwt : in [N, H, W]  -> out [B, 4, C, H/2, W/2] viewed as [B, 4C, H/2, W/2]  (N = B*C planes; band-major channel order of the cat)
+//   idwt: in [B, 4, C, H, W] -> out [N, 2H, 2W]
+// k: [4][2][2] floats (the four 2x2 kernels as upfirdn2d receives them, unflipped).
+// One thread = 4 output columns of the analysis (2 x 8 inputs) / 4 input columns of the synthesis (2 x 8 outputs): 16-byte accesses.
+__global__ void __launch_bounds__(256) haar_dwt_kernel(float* __restrict__ out, const float* __restrict__ in, const float* __restrict__ k,
+                                                       int B, int C, int H, int W)
+{
+    const int OH = H >> 1, OW = W >> 1, OW4 = OW >> 2;
+    const int64_t total = (int64_t)B * C * OH * OW4;
+    float kk[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) kk[q] = k[q];
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int x4 = (int)(idx % OW4);
+        int64_t t = idx / OW4;
+        const int oy = (int)(t % OH);
+        const int64_t n = t / OH;          // plane b*C + c
+        const int64_t b = n / C, c = n - b * C;
+        const float* r0 = in + (n * H + 2 * oy) * (int64_t)W + 8 * x4;
+        const float4 a0 = *reinterpret_cast<const float4*>(r0), a1 = *reinterpret_cast<const float4*>(r0 + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(r0 + W), b1 = *reinterpret_cast<const float4*>(r0 + W + 4);
+        const float top[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        const float bot[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int band = 0; band < 4; ++band) {
+            const float* kb = kk + 4 * band;          // taps (i, j) use the flipped kernel k[1-i][1-j]
+            float o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v = fmaf(top[2 * q], kb[3], 0.f);
+                v = fmaf(top[2 * q + 1], kb[2], v);
+                v = fmaf(bot[2 * q], kb[1], v);
+                v = fmaf(bot[2 * q + 1], kb[0], v);
+                o[q] = v;
+            }
+            float* dst = out + ((((b * 4 + band) * C + c) * OH + oy) * (int64_t)OW) + 4 * x4;
+            *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) haar_idwt_kernel(float* __restrict__ out, const float* __restrict__ in, const float* __restrict__ k,
+                                                        int B, int C, int H, int W)
+{
+    const int W4 = W >> 2;
+    const int64_t total = (int64_t)B * C * H * W4;
+    float kk[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) kk[q] = k[q];
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int x4 = (int)(idx % W4);
+        int64_t t = idx / W4;
+        const int y = (int)(t % H);
+        const int64_t n = t / H;
+        const int64_t b = n / C, c = n - b * C;
+        float v[4][4];
+#pragma unroll
+        for (int band = 0; band < 4; ++band) {
+            const float4 q4 = *reinterpret_cast<const float4*>(in + ((((b * 4 + band) * C + c) * H + y) * (int64_t)W) + 4 * x4);
+            v[band][0] = q4.x; v[band][1] = q4.y; v[band][2] = q4.z; v[band][3] = q4.w;
+        }
+#pragma unroll
+        for (int ry = 0; ry < 2; ++ry) {
+            float o[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int rx = 0; rx < 2; ++rx) {
+                    // out[2y+ry, 2x+rx] = in[y, x] * k[ry][rx] per band (the one tap that lands on a real sample), bands summed in order
+                    // (individually rounded products and sums: the compiler would contract r + v*k into an fma)
+                    float r = mul_rn(v[0][q], kk[0 + 2 * ry + rx]);
+                    r = add_rn(r, mul_rn(v[1][q], kk[4 + 2 * ry + rx]));
+                    r = add_rn(r, mul_rn(v[2][q], kk[8 + 2 * ry + rx]));
+                    r = add_rn(r, mul_rn(v[3][q], kk[12 + 2 * ry + rx]));
+                    o[2 * q + rx] = r;
+                }
+            float* dst = out + (n * 2 * H + 2 * y + ry) * (int64_t)(2 * W) + 8 * x4;
+            *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        }
+    }
+}
+
+extern "C" int hav_haar_dwt(float* out, const float* in, const float* k4x2x2, int B, int C, int H, int W, void* stream)
+{
+    if (!out || !in || !k4x2x2 || B < 1 || C < 1 || H < 2 || W < 2) return HAV_EINVAL;
+    if ((H & 1) || (W % 8) || (((uintptr_t)out | (uintptr_t)in) & 15)) return HAV_EUNSUP;
+    const int64_t total = (int64_t)B * C * (H / 2) * (W / 8);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > (int64_t)hav_num_cus() * 16) blocks = (int64_t)hav_num_cus() * 16;
+    hipLaunchKernelGGL(haar_dwt_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, in, k4x2x2, B, C, H, W);
+    HAV_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int hav_haar_idwt(float* out, const float* in, const float* k4x2x2, int B, int C, int H, int W, void* stream)
+{
+    if (!out || !in || !k4x2x2 || B < 1 || C < 1 || H < 1 || W < 1) return HAV_EINVAL;
+    if ((W % 4) || (((uintptr_t)out | (uintptr_t)in) & 15)) return HAV_EUNSUP;
+    const int64_t total = (int64_t)B * C * H * (W / 4);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > (int64_t)hav_num_cus() * 16) blocks = (int64_t)hav_num_cus() * 16;
+    hipLaunchKernelGGL(haar_idwt_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, in, k4x2x2, B, C, H, W);
+    HAV_LAUNCH_CHECK();
+    return 0;
+}
+
+// ================================================================================================
 // Demodulation of a modulated convolution under autograd (training path):
 //   q[i,o] = c^2 sum_k W[o,i,k]^2 ,   d[b,o] = rsqrt( sum_i s[b,i]^2 q[i,o] + eps )
 // (reference model/styleUnet.py:214-227 in its factored form) and its backward

@@ -278,6 +278,18 @@ class ConvLayer(nn.Sequential):
         return super().forward(input)
 
 
+def _fused_haar_enabled():
+    return os.environ.get("HAVATAR_FUSED_HAAR", "1") != "0"
+
+
+def _haar_bank(mod, ks):
+    """[4,2,2] tensor of a transform's four kernels, cached on the module (buffers do not change after construction / .to())."""
+    bank = mod.__dict__.get("_bank")
+    if bank is None or bank.device != ks[0].device:
+        bank = mod.__dict__["_bank"] = torch.stack([k.to(torch.float32) for k in ks]).contiguous()
+    return bank
+
+
 def get_haar_wavelet(in_channels):
     l = 1 / (2 ** 0.5) * torch.ones(1, 2)
     h = 1 / (2 ** 0.5) * torch.ones(1, 2)
@@ -292,6 +304,11 @@ class HaarTransform(nn.Module):
             self.register_buffer(n, k)
 
     def forward(self, input):
+        if input.is_cuda and input.dtype == torch.float32 and not torch.is_grad_enabled() and _fused_haar_enabled():
+            from ..native import fused           # HIP inference: the four band filters + cat as one pass (hav_haar_dwt), same bits
+            out = fused.haar(input, _haar_bank(self, (self.ll, self.lh, self.hl, self.hh)))
+            if out is not None:
+                return out
         return torch.cat([upfirdn2d(input, k, down=2) for k in (self.ll, self.lh, self.hl, self.hh)], 1)
 
 
@@ -303,6 +320,11 @@ class InverseHaarTransform(nn.Module):
             self.register_buffer(n, k)
 
     def forward(self, input):
+        if input.is_cuda and input.dtype == torch.float32 and not torch.is_grad_enabled() and _fused_haar_enabled():
+            from ..native import fused           # HIP inference: four up-sampling filters + three adds as one pass (hav_haar_idwt)
+            out = fused.haar(input, _haar_bank(self, (self.ll, self.lh, self.hl, self.hh)), inverse=True)
+            if out is not None:
+                return out
         parts = input.chunk(4, 1)
         ks = (self.ll, self.lh, self.hl, self.hh)
         return sum(upfirdn2d(p, k, up=2, pad=(1, 0, 1, 0)) for p, k in zip(parts, ks))

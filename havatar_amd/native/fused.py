@@ -142,3 +142,28 @@ def styled_epilogue(x, demod, noise, noise_weight, bias, negative_slope=0.2, sca
                                             C.c_void_p(torch.cuda.current_stream().cuda_stream))
     _lib.check(rc, "hav_styled_epilogue")
     return out
+
+
+def haar(x, k4, inverse=False):
+    """HaarTransform / InverseHaarTransform of model/styleUnet.py as one launch (hav_haar_dwt / hav_haar_idwt), bit-identical to the
+    four upfirdn2d calls.  k4 [4,2,2]: the kernels of the four calls.  Returns None when the shape is not taken (caller falls back)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+        return None
+    x = x.contiguous()
+    B, Cc, H, W = x.shape
+    if inverse:
+        if Cc % 4 or W % 4:
+            return None
+        out = torch.empty(B, Cc // 4, 2 * H, 2 * W, device=x.device, dtype=torch.float32)
+        fn, Cn = _lib.lib().hav_haar_idwt, Cc // 4
+    else:
+        if H % 2 or W % 8:
+            return None
+        out = torch.empty(B, Cc * 4, H // 2, W // 2, device=x.device, dtype=torch.float32)
+        fn, Cn = _lib.lib().hav_haar_dwt, Cc
+    k4 = _f32c(k4, "k4")
+    with torch.cuda.device(x.device):
+        rc = fn(C.c_void_p(out.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(k4.data_ptr()), B, Cn, H, W,
+                C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, "hav_haar")
+    return out

@@ -203,6 +203,14 @@ int hav_upconv_finish(float* y, const float* col, const float* fir4x4, const flo
                       const float* bias, float slope, float gain, int act, int noise_batched, int B, int Cout, int H, int W,
                       void* stream);
 
+/* Haar analysis / synthesis of SWGAN_unet's wavelet-domain skip path (model/styleUnet.py HaarTransform / InverseHaarTransform: four
+ * upfirdn2d calls each, + cat / + three adds) as one pass each, bit-identical to the four-call sequence.
+ *   hav_haar_dwt : in [B,C,H,W] -> out [B,4C,H/2,W/2], channel = band*C + c, bands ll, lh, hl, hh   (H even, W % 8 == 0)
+ *   hav_haar_idwt: in [B,4C,H,W] -> out [B,C,2H,2W]                                                  (W % 4 == 0)
+ * k4x2x2: the four 2x2 kernels exactly as the upfirdn2d calls receive them (the synthesis takes ll, -lh, -hl, hh). */
+int hav_haar_dwt(float* out, const float* in, const float* k4x2x2, int B, int C, int H, int W, void* stream);
+int hav_haar_idwt(float* out, const float* in, const float* k4x2x2, int B, int C, int H, int W, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Trilinear x2 up-sampling of a [N,C,D,H,W] float32 volume and its adjoint -- nn.Upsample(scale_factor=2, mode='trilinear',
  * align_corners=False), the first stage of every UpConv3DBlock of the skinning-volume decoder

@@ -242,6 +242,28 @@ def test_style_demod_matches_equal_linear_and_rsqrt():
         assert d2 is None and (s2.double() - (s_ref - 1.0)).abs().max().item() <= 2e-6 * s_ref.abs().max().item()
 
 
+def test_fused_haar_transforms_equal_the_four_call_sequences_bitwise():
+    """hav_haar_dwt / hav_haar_idwt == HaarTransform / InverseHaarTransform as four upfirdn2d calls + cat / + adds
+    (model/styleUnet.py), bit for bit; and the pair is the identity to fp32 rounding (orthonormal Haar basis)."""
+    import os
+    from havatar_amd.model.styleUnet import HaarTransform, InverseHaarTransform
+    g = torch.Generator(device=DEV).manual_seed(21)
+    dwt, iwt = HaarTransform(3).to(DEV), InverseHaarTransform(3).to(DEV)
+    for B, Cc, H, W in ((1, 3, 64, 64), (2, 3, 128, 256), (1, 5, 16, 8)):
+        x = torch.randn(B, Cc, H, W, device=DEV, generator=g)
+        y = torch.randn(B, 4 * Cc, H // 2, W // 2, device=DEV, generator=g)
+        with torch.no_grad():
+            os.environ["HAVATAR_FUSED_HAAR"] = "0"
+            try:
+                d_ref, i_ref = dwt(x), iwt(y)
+            finally:
+                os.environ.pop("HAVATAR_FUSED_HAAR")
+            d, i = dwt(x), iwt(y)
+            assert d.shape == d_ref.shape and torch.equal(d, d_ref)
+            assert i.shape == i_ref.shape and torch.equal(i, i_ref)
+            assert (iwt(dwt(x)) - x).abs().max().item() <= 1e-6 * x.abs().max().item()
+
+
 def test_style_demod_batched_equals_the_per_layer_launches():
     """hav_style_demod_batched (one launch for all modulated convolutions of a generator) == hav_style_demod per layer, bit for bit:
     mixed Cin / Cout, a layer without demodulation, a layer without bias, B = 2, per-layer latent rows."""
