@@ -88,6 +88,15 @@ struct ConvArgs {
     int B, Cin, Cout, H, W;
 };
 
+#ifdef CV_PROFILE
+// tools/conv_phase.sh: per-wave cycle sums of the main loop's phases (alternative build only)
+__device__ unsigned long long* g_cv_prof = nullptr;
+extern "C" int hav_conv_profile_buffer(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cv_prof), &p, sizeof(p)); }
+#define CV_T(v) do { v = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
+#else
+#define CV_T(v) do { } while (0)
+#endif
+
 template <bool HAS_S>      // modulated (s given) or plain: compile-time, so that neither variant carries the other's loads / multiplies
 __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(ConvArgs a)
 {
@@ -169,14 +178,17 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(ConvArgs a)
     fetch(c_lo, sv, ssc);
     stash(0, sv, ssc);
     __syncthreads();
+    unsigned long long pt0 = 0, pt1 = 0, pt2 = 0, pt3 = 0, pt4 = 0, ps[4] = {0, 0, 0, 0};
     for (int ci = 0; ci < NC; ++ci) {
         const int cc = c_lo + ci, buf = ci & 1;
+        CV_T(pt0);
         // weights of this chunk: 9 taps x (hi, lo), all in flight
         const uint4* ab = a.blob + ((int64_t)(cc * 9) * MT + mt) * 128 + lane;
         uint4 A[9][2];
 #pragma unroll
         for (int t = 0; t < 9; ++t) { A[t][0] = ab[(int64_t)t * MT * 128]; A[t][1] = ab[(int64_t)t * MT * 128 + 64]; }
         if (ci + 1 < NC) fetch(cc + 1, sv, ssc);
+        CV_T(pt1);
         const uint32_t* L = lds[buf];
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -195,10 +207,22 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(ConvArgs a)
         }
         // the matrix instructions keep reading their operand registers for a while after issue: wait them out before
         // the conversion code below may recycle registers
+        CV_T(pt2);
         asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]));
         if (ci + 1 < NC) stash(buf ^ 1, sv, ssc);
+        CV_T(pt3);
         __syncthreads();
+        CV_T(pt4);
+#ifdef CV_PROFILE
+        ps[0] += pt1 - pt0; ps[1] += pt2 - pt1; ps[2] += pt3 - pt2; ps[3] += pt4 - pt3;
+#endif
     }
+#ifdef CV_PROFILE
+    if (g_cv_prof && lane == 0) {
+        const int w = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave;
+        for (int q = 0; q < 4; ++q) g_cv_prof[(size_t)w * 4 + q] = ps[q];
+    }
+#endif
     if (a.partial) {            // K-split: raw sums out, the epilogue runs in conv3x3_finish_kernel after the slices are added up
         float* pp = a.partial + (int64_t)ks * a.B * a.Cout * H * W;
 #pragma unroll
