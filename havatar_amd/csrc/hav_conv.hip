@@ -254,6 +254,189 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(ConvArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Interleaved variant (the default where it applies: Cout % 128 == 0).  What the measurements above say: an in-order wave cannot run
+// its MFMAs beside its own memory / conversion work unless that work sits BETWEEN the MFMAs in program order, and a second wave on
+// the SIMD does not help (a wave with an MFMA waiting for the pipe keeps the other wave's vector instructions from issuing: a
+// 512-thread ping-pong variant -- one half of the workgroup loading / converting chunk c+1 while the other half runs the MFMAs of
+// chunk c -- measured exactly the sum again, 70.8 vs 73.4 us, and was dropped).  A 32x32x16 MFMA occupies the matrix pipe for 32 cycles but the issue port
+// only for ~4: the ~7 slots behind it are free for the same wave.  So this kernel
+//   * takes 128 (M) x 128 (N) tiles -- each wave owns one 32-row M tile and all four pixel rows: the 18 weight fragments of a chunk
+//     feed 108 MFMAs instead of 54, which brings the vector-memory path from 80 % to 40 % of its throughput at MFMA speed;
+//   * cuts the chunk into 36 segments of three MFMAs (one tap, one row) and hangs a fixed slice of the side work on every segment:
+//     the two ds_read_b128 of the segment two ahead (ring of three B operands), one weight-fragment load of the NEXT chunk (second
+//     register set), the input loads of the chunk AFTER next, and the convert / split / ds_write of one staging task of the next
+//     chunk (its loads were issued a whole chunk earlier).  sched_barrier(0) pins the segments; nothing waits inside the loop.
+// One wave per SIMD (the two weight sets + 64 accumulators need ~330 registers of the 512).
+#define CV_KEEP4(u) asm volatile("" : : "v"((u).x), "v"((u).y), "v"((u).z), "v"((u).w))
+template <bool HAS_S>
+__global__ void __launch_bounds__(256, 1) conv3x3_il_kernel(ConvArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2][CV_PIX * CV_REC];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 31, h = lane >> 5;
+    const int bw = a.W / CV_COLS;
+    const int px = blockIdx.x % bw, py = blockIdx.x / bw;
+    const int x0 = px * CV_COLS, y0 = py * CV_ROWS;
+    const int mt = blockIdx.y * 4 + wave;          // this wave's 32-row tile of output channels (all four rows of the pixel tile)
+    const int b = blockIdx.z / a.ksplit, ks = blockIdx.z - b * a.ksplit;
+    const int H = a.H, W = a.W, Cin = a.Cin, NCT = Cin / 16, MT = a.Cout / 32;
+    const int c_lo = (NCT * ks) / a.ksplit, c_hi = (NCT * (ks + 1)) / a.ksplit, NC = c_hi - c_lo;
+    const float* xb = a.x + (int64_t)b * Cin * H * W;
+    const float* sb = HAS_S ? a.s + (int64_t)b * Cin : nullptr;
+    float in_sc = 1.0f, out_sc = 1.0f / CV_WSHIFT;
+    if (a.in_amax) {          // see conv3x3_split_kernel
+        const uint4 w4m = reinterpret_cast<const uint4*>(a.in_amax)[lane];
+        unsigned int mb = w4m.x > w4m.y ? w4m.x : w4m.y;
+        mb = w4m.z > mb ? w4m.z : mb;
+        mb = w4m.w > mb ? w4m.w : mb;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { const unsigned int t = (unsigned int)__shfl_xor((int)mb, o, 64); mb = t > mb ? t : mb; }
+        const int be = (int)((mb >> 23) & 0xFFu);
+        if (be >= 1 && be <= 254) {
+            int e = 9 - (be - 127);
+            e = e > 100 ? 100 : (e < -100 ? -100 : e);
+            in_sc = __uint_as_float((unsigned int)(127 + e) << 23);
+            out_sc = __uint_as_float((unsigned int)(127 - e - 8) << 23);
+        }
+    }
+    // staging tasks (pixel of the patch, channel pair); padding / idle slots load a valid address and are zeroed by their factor
+    int t_off[CV_TPT], t_lds[CV_TPT], t_cp[CV_TPT];
+    float t_m[CV_TPT];
+#pragma unroll
+    for (int q = 0; q < CV_TPT; ++q) {
+        const int task = tid + 256 * q;
+        const int cp = task / CV_PIX, p = task - cp * CV_PIX;
+        const int pr = p / CV_PC, pc = p - pr * CV_PC;
+        const int gy = y0 + pr - 1, gx = x0 + pc - 1;
+        const bool ok = task < CV_TASKS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        t_off[q] = ok ? (2 * cp) * H * W + gy * W + gx : 0;
+        t_m[q] = ok ? in_sc : 0.f;
+        t_lds[q] = task < CV_TASKS ? p * CV_REC + cp : CV_PIX * CV_REC;          // idle slots of the last round: caught below
+        t_cp[q] = task < CV_TASKS ? 2 * cp : 0;
+    }
+    auto fetch1 = [&](int cc, int q, float (&v)[CV_TPT][2], float (&sc)[CV_TPT][2]) {
+        const float* src = xb + (int64_t)(16 * cc) * H * W;
+        v[q][0] = src[t_off[q]];
+        v[q][1] = src[t_off[q] + H * W];
+        if (HAS_S) { sc[q][0] = sb[16 * cc + t_cp[q]]; sc[q][1] = sb[16 * cc + t_cp[q] + 1]; }
+    };
+    auto stash1 = [&](uint32_t* L, int q, const float (&v)[CV_TPT][2], const float (&sc)[CV_TPT][2]) {
+        if (q == CV_TPT - 1 && t_lds[q] >= CV_PIX * CV_REC) return;
+        const fl2_t f = {HAS_S ? v[q][0] * (sc[q][0] * t_m[q]) : v[q][0] * t_m[q], HAS_S ? v[q][1] * (sc[q][1] * t_m[q]) : v[q][1] * t_m[q]};
+        const h2_t hi = __builtin_convertvector(f, h2_t);
+        const h2_t lo = __builtin_convertvector(f - __builtin_convertvector(hi, fl2_t), h2_t);
+        L[t_lds[q]] = __builtin_bit_cast(uint32_t, hi);
+        L[t_lds[q] + 8] = __builtin_bit_cast(uint32_t, lo);
+    };
+    auto aload = [&](int cc, int idx, uint4 (&A)[9][2]) {          // fragment idx = 2 t + part of chunk cc
+        const uint4* ab = a.blob + ((int64_t)(cc * 9) * MT + mt) * 128 + lane;
+        A[idx >> 1][idx & 1] = ab[(int64_t)(idx >> 1) * MT * 128 + 64 * (idx & 1)];
+    };
+    f32x16 acc[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rr][r] = 0.f;
+
+    uint4 A0[9][2], A1[9][2];
+    float v0[CV_TPT][2], v1[CV_TPT][2], s0[CV_TPT][2], s1[CV_TPT][2];
+    unsigned long long pt0 = 0, pt1 = 0, pt2 = 0, ps[4] = {0, 0, 0, 0};
+    // prologue: chunk c_lo's patch goes to buffer 0; its fragments to A0; chunk c_lo+1's inputs are in flight in v0
+#pragma unroll
+    for (int q = 0; q < CV_TPT; ++q) fetch1(c_lo, q, v1, s1);
+#pragma unroll
+    for (int idx = 0; idx < 18; ++idx) aload(c_lo, idx, A0);
+#pragma unroll
+    for (int q = 0; q < CV_TPT; ++q) stash1(lds[0], q, v1, s1);
+    {
+        const int c1 = NC > 1 ? c_lo + 1 : c_lo;
+#pragma unroll
+        for (int q = 0; q < CV_TPT; ++q) fetch1(c1, q, v0, s0);
+    }
+    __syncthreads();
+
+    // one chunk: MFMAs on (Ac, lds[buf]); side work: An <- fragments of chunk cn1, vn <- inputs of chunk cn2, vc -> lds[buf ^ 1]
+    auto chunk = [&](int buf, int cn1, int cn2, uint4 (&Ac)[9][2], uint4 (&An)[9][2], float (&vc)[CV_TPT][2], float (&sc_)[CV_TPT][2],
+                     float (&vn)[CV_TPT][2], float (&sn)[CV_TPT][2]) {
+        const uint32_t* L = lds[buf] + j * CV_REC + 4 * h;
+        uint32_t* Lw = lds[buf ^ 1];
+        CV_T(pt0);
+        uint4 Bq[3][2];
+        auto bload = [&](int k, uint4 (&d)[2]) {          // segment k = 4 t + rr
+            const int t = k >> 2, rr = k & 3, ky = t / 3, kx = t - 3 * ky;
+            d[0] = *reinterpret_cast<const uint4*>(L + ((rr + ky) * CV_PC + kx) * CV_REC);
+            d[1] = *reinterpret_cast<const uint4*>(L + ((rr + ky) * CV_PC + kx) * CV_REC + 8);
+        };
+        bload(0, Bq[0]);
+        bload(1, Bq[1]);
+#pragma unroll
+        for (int k = 0; k < 36; ++k) {
+            const int t = k >> 2, rr = k & 3;
+            const f16x8_t ah = __builtin_bit_cast(f16x8_t, Ac[t][0]), al = __builtin_bit_cast(f16x8_t, Ac[t][1]);
+            const f16x8_t xh = __builtin_bit_cast(f16x8_t, Bq[k % 3][0]), xl = __builtin_bit_cast(f16x8_t, Bq[k % 3][1]);
+            acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh, acc[rr], 0, 0, 0);
+            acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl, acc[rr], 0, 0, 0);
+            acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh, acc[rr], 0, 0, 0);
+            if (k + 2 < 36) bload(k + 2, Bq[(k + 2) % 3]);          // slot last read by segment k-1: its MFMAs issued >= 96 cycles ago
+            if ((k & 1) == 0) aload(cn1, k >> 1, An);               // 18 fragments of the next chunk, one per even segment
+            else if (k < 2 * CV_TPT) fetch1(cn2, k >> 1, vn, sn);   // inputs of the chunk after next, one task per odd segment
+            if (k >= 15 && (k - 15) % 3 == 0 && (k - 15) / 3 < CV_TPT) stash1(Lw, (k - 15) / 3, vc, sc_);          // k = 15, 18, .., 33
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the matrix instructions keep reading their operand registers for a while after issue: the fragment
+        // registers stay allocated until here (no temporary may land in them), and the pipe drains before the next chunk's first writes
+#pragma unroll
+        for (int t = 0; t < 9; ++t) { CV_KEEP4(Ac[t][0]); CV_KEEP4(Ac[t][1]); }
+        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+        CV_T(pt1);
+        __syncthreads();
+        CV_T(pt2);
+#ifdef CV_PROFILE
+        ps[1] += pt1 - pt0; ps[3] += pt2 - pt1;
+#endif
+    };
+    for (int ci = 0; ci < NC; ci += 2) {
+        const int cc = c_lo + ci;
+        const int n1 = ci + 1 < NC ? cc + 1 : cc, n2 = ci + 2 < NC ? cc + 2 : cc, n3 = ci + 3 < NC ? cc + 3 : cc;
+        chunk(0, n1, n2, A0, A1, v0, s0, v1, s1);
+        if (ci + 1 < NC) chunk(1, n2, n3, A1, A0, v1, s1, v0, s0);
+    }
+#ifdef CV_PROFILE
+    if (g_cv_prof && lane == 0) {
+        const int w = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave;
+        for (int q = 0; q < 4; ++q) g_cv_prof[(size_t)w * 4 + q] = ps[q];
+    }
+#endif
+
+    if (a.partial) {
+        float* pp = a.partial + (int64_t)ks * a.B * a.Cout * H * W;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
+                pp[(((int64_t)b * a.Cout + co) * H + y0 + rr) * W + x0 + j] = acc[rr][r] * out_sc;
+            }
+        return;
+    }
+    const float nw = (a.noise && a.noise_weight) ? *a.noise_weight : 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int gy = y0 + rr, gx = x0 + j;
+        const float nz = a.noise ? a.noise[(a.noise_batched ? (int64_t)b * H * W : 0) + (int64_t)gy * W + gx] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
+            float v = acc[rr][r] * out_sc;
+            if (a.d) v = v * a.d[(int64_t)b * a.Cout + co];
+            if (a.noise) v = v + nw * nz;
+            if (a.bias) v = v + a.bias[co];
+            if (a.act) v = (v > 0.f ? v : v * a.slope) * a.gain;
+            a.y[(((int64_t)b * a.Cout + co) * H + gy) * W + gx] = v;
+        }
+    }
+}
+
 // max |x| over a tensor as HAV_ABSMAX_WORDS partial maxima (bit patterns of non-negative floats; NaNs are skipped by fmaxf): block k
 // owns the k-th slice and stores its maximum -- no atomics, nothing to zero beforehand, so the whole range control is ONE launch; the
 // consumer (conv3x3_split_kernel) folds the words with one load per thread and a wave reduction.
@@ -314,11 +497,20 @@ __global__ void __launch_bounds__(256) conv3x3_finish_kernel(ConvArgs a, int64_t
 }
 
 // scratch the K-split path needs for these sizes (0: no K-split, pass NULL)
+// which kernel: the interleaved 128 x 128 one wherever Cout allows it; HAVATAR_CONV_KERNEL=0 forces the plain 64 x 128 kernel (A/B
+// runs; read once)
+static bool conv_interleaved(int Cout)
+{
+    static const int forced = [] { const char* e = getenv("HAVATAR_CONV_KERNEL"); return e ? atoi(e) : -1; }();
+    return forced != 0 && (Cout % 128) == 0;
+}
 static int conv_ksplit(int B, int Cin, int Cout, int H, int W)
 {
-    const int64_t tiles = (int64_t)B * (Cout / 64) * (H / CV_ROWS) * (W / CV_COLS);
+    const bool il = conv_interleaved(Cout);
+    const int64_t tiles = (int64_t)B * (Cout / (il ? 128 : 64)) * (H / CV_ROWS) * (W / CV_COLS);
     int ks = 1;
-    while (tiles * ks < hav_num_cus() && ks < 4 && (Cin / 16) / (ks * 2) >= 4) ks *= 2;
+    if (il) { while (tiles * ks < hav_num_cus() && ks < 8 && (Cin / 16) / (ks * 2) >= 2) ks *= 2; }
+    else { while (tiles * ks < hav_num_cus() && ks < 4 && (Cin / 16) / (ks * 2) >= 4) ks *= 2; }
     return ks;
 }
 extern "C" int64_t hav_conv3x3_scratch_bytes(int B, int Cin, int Cout, int H, int W)
@@ -341,9 +533,15 @@ extern "C" int hav_conv3x3_split(float* y, const float* x, const void* packed, c
     a.y = y; a.x = x; a.blob = (const uint4*)packed; a.s = s; a.d = d; a.noise = noise; a.noise_weight = noise_weight; a.bias = bias;
     a.slope = slope; a.gain = gain; a.act = act; a.noise_batched = noise_batched;
     a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
-    const dim3 grid((unsigned)((W / CV_COLS) * (H / CV_ROWS)), (unsigned)(Cout / 64), (unsigned)(B * a.ksplit));
-    if (s) hipLaunchKernelGGL(conv3x3_split_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(conv3x3_split_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    const bool il = conv_interleaved(Cout);
+    const dim3 grid((unsigned)((W / CV_COLS) * (H / CV_ROWS)), (unsigned)(Cout / (il ? 128 : 64)), (unsigned)(B * a.ksplit));
+    if (il) {
+        if (s) hipLaunchKernelGGL(conv3x3_il_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(conv3x3_il_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    } else {
+        if (s) hipLaunchKernelGGL(conv3x3_split_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(conv3x3_split_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    }
     HAV_LAUNCH_CHECK();
     if (a.partial) {
         const int64_t total = (int64_t)B * Cout * H * W;

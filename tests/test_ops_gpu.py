@@ -424,7 +424,8 @@ def test_upsample3d_2x_matches_nn_upsample_and_its_autograd(shape):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,Cin,Cout,H,W,full", [(1, 16, 64, 4, 32, True), (2, 48, 64, 8, 64, True), (1, 64, 128, 12, 32, False),
-                                                 (1, 512, 512, 32, 32, True), (1, 256, 256, 128, 128, False)])
+                                                 (1, 512, 512, 32, 32, True), (1, 256, 256, 128, 128, False),
+                                                 (1, 16, 128, 4, 32, True), (2, 48, 256, 64, 64, True), (1, 1024, 512, 64, 64, True)])
 def test_conv3x3_split_matches_fp64_convolution(B, Cin, Cout, H, W, full):
     """hav_conv3x3_split (split-fp16 implicit GEMM + fused modulation / demodulation / noise / bias / leaky-ReLU) against the fp64
     statement of the same StyledConv / ConvLayer arithmetic (model/styleUnet.py:165-297,326-368,565-599); the fp32 F.conv2d route's
@@ -529,6 +530,28 @@ def test_upconv3x3_matches_fp64_transposed_convolution_and_blur(B, Cin, Cout, H,
     t0 = torch.nn.functional.conv2d(torch.nn.functional.pad(z, (1, 1, 1, 1)), fir.double().flip(0, 1).view(1, 1, 4, 4).expand(Cout, 1, 4, 4),
                                     groups=Cout)
     assert (y0.double() - t0).abs().max().item() <= 2e-6 * t0.abs().max().item()
+
+
+def test_conv3x3_full_occupancy_runs_are_bitwise_identical():
+    """The interleaved kernel hangs VALU / LDS / memory work between its MFMAs; the matrix instructions keep reading their operand
+    registers after issue, and a compiler that recycles such a register shows up as run-to-run differences once every
+    SIMD is busy -- never on small maps.  20 launches of a 1024 -> 512 @ 64^2 convolution (all fused terms) and of a 256 -> 256 @ 128^2
+    one must agree bit for bit, and so must the plain 64 x 128 kernel (Cout = 64)."""
+    from havatar_amd.native import conv
+    g = torch.Generator(device=DEV).manual_seed(77)
+    for Cin, Cout, H in ((1024, 512, 64), (256, 256, 128), (256, 64, 128)):
+        x = torch.randn(1, Cin, H, H, device=DEV, generator=g)
+        w = torch.randn(Cout, Cin, 3, 3, device=DEV, generator=g)
+        s = 1.0 + 0.3 * torch.randn(1, Cin, device=DEV, generator=g)
+        d = 0.5 + torch.rand(1, Cout, device=DEV, generator=g)
+        noise = torch.randn(1, 1, H, H, device=DEV, generator=g)
+        nw = torch.full((1,), 0.37, device=DEV)
+        bias = 0.1 * torch.randn(Cout, device=DEV, generator=g)
+        pk = conv.pack(w, 1.0 / (Cin * 9) ** 0.5)
+        first = conv.conv3x3(x, pk, Cout, s=s, d=d, noise=noise, noise_weight=nw, bias=bias)
+        for _ in range(19):
+            again = conv.conv3x3(x, pk, Cout, s=s, d=d, noise=noise, noise_weight=nw, bias=bias)
+            assert torch.equal(first, again), (Cin, Cout, H, (first != again).sum().item())
 
 
 def test_conv3x3_split_refuses_unsupported_shapes():

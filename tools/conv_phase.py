@@ -12,7 +12,8 @@ from havatar_amd.native import conv  # noqa: E402
 dev = torch.device("cuda:0")
 L = _lib.lib()
 L.hav_conv_profile_buffer.argtypes = [C.c_void_p]
-names = ["issue A loads + next chunk's x loads", "9 taps: ds_read + 54 MFMA (issue)", "s_nop + convert / split / ds_write", "barrier"]
+names = ["issue A loads + next chunk's x loads", "9 taps: ds_read + MFMAs (interleaved kernel: + all side work)", "s_nop + convert / split / ds_write", "barrier"]
+L.hav_conv3x3_scratch_bytes.restype = C.c_int64
 for (Cin, Cout, H) in ((512, 512, 64), (1024, 512, 64), (256, 256, 128)):
     x = torch.randn(1, Cin, H, H, device=dev)
     w = torch.randn(Cout, Cin, 3, 3, device=dev) / (Cin * 9) ** 0.5
@@ -30,4 +31,4 @@ for (Cin, Cout, H) in ((512, 512, 64), (1024, 512, 64), (256, 256, 128)):
     tot = r.sum(1).mean().item() / nchunk
     for q in range(4):
         print("   %-44s %8.0f  (%4.1f %%)" % (names[q], r[:, q].mean().item() / nchunk, 100 * r[:, q].mean().item() / nchunk / tot))
-    print("   %-44s %8.0f   (MFMA issue floor: 54 x 32 = 1728)" % ("total", tot))
+    print("   %-44s %8.0f   (MFMA issue floor per chunk: 54 x 32 = 1728 in the 64 x 128 kernels, 108 x 32 = 3456 in the interleaved 128 x 128 kernel)" % ("total", tot))
