@@ -435,7 +435,7 @@ def main():
             "data": "synthetic",
             "config": {"batch": CFG3_NOTE % (args.frames, world, -(-args.frames // world)) if args.workload == "cfg3" else None,
                        "workload": "cfg2: Trainer.forward(render_full_img=True) for one 512x512 frame per GPU per step: tri-plane encoders "
-                                   "(P3: 2x StyleGAN_zxc, MIOpen convs + HIP upfirdn2d/fused_bias_act) -> per-frame plane projection -> fused "
+                                   "(P3: 2x StyleGAN_zxc: 3x3 / up-sampling convolutions on split-fp16 MFMA HIP kernels with the block glue fused, stride-2 and 1x1 ones on MIOpen, HIP upfirdn2d/fused_bias_act) -> per-frame plane projection -> fused "
                                    "ray march (P5-P12) over 262144 rays x (64 coarse + 48 fine) = 29.36M radiance-MLP queries -> [1,67,512,512]",
                        "phase_ms": {"encoders_P3": round(enc_ms, 3), "plane_prepare": round(prep_ms, 3), "ray_march_kernel": round(kern_ms, 3),
                                     "encoders_P3_inside_the_graph": round(1e3 * dt / args.steps / (frames_per_step / world) - kern_ms - prep_ms, 3),
