@@ -11,6 +11,8 @@ Other workloads (not what the driver runs; same JSON contract):
   --workload cfg3 [--frames 64]   BASELINE configs[2]: a batch of 64 frames dealt round-robin to the ranks (8 per GPU on 8 GPUs), finished
                                   RGB frames all-gathered round by round over RCCL WHILE the next frame renders
                                   (frames.OverlappedFrameGather); one step = one batch, total work fixed -> "scaling": "strong".
+  --workload cfg4                 BASELINE configs[3]: the stage-two HD path, one step = the cfg2 frame (512^2 NeRF volume render) + SWGAN_unet
+                                  (512 -> 1024) on its 64 feature channels -> [1,3,1024,1024]; both stages are hipGraphs.
   --workload cfg5                 BASELINE configs[4]: train_avatar.py's optimisation step, 2 frames x 4096 rays x (64 + 48) samples,
                                   forward + backward + Adam as one hipGraph launch, radiance MLP forward/backward on bf16 MFMA.
   --device cpu [--size 16]        plumbing mode for the tests: CPU tensors, gloo, no HIP library; exercises the N > 1 branch without GPUs.
@@ -198,7 +200,7 @@ def main():
     ap.add_argument("--perturb", type=int, default=1, help="stratified jitter on (reference default for inference)")
     ap.add_argument("--graph", type=int, default=1, help="replay the frame as one hipGraph (0 = eager launches)")
     ap.add_argument("--live-pmc", type=int, default=1, help="measure roofline.traffic in this run (2 rocprofv3 --pmc passes, ~1 min; N=1 only)")
-    ap.add_argument("--workload", choices=["cfg2", "cfg3", "cfg5"], default="cfg2")
+    ap.add_argument("--workload", choices=["cfg2", "cfg3", "cfg4", "cfg5"], default="cfg2")
     ap.add_argument("--frames", type=int, default=64, help="cfg3: frames per batch (one step = one batch)")
     ap.add_argument("--device", choices=["cuda", "cpu"], default="cuda")
     ap.add_argument("--size", type=int, default=512, help="frame edge in pixels (plumbing mode)")
@@ -296,6 +298,30 @@ def main():
                 gather.submit(r, None if k is None else render(batch_poses[k])[0][0, :3])
             return gather.finalize()
         frames_per_step = args.frames
+    elif args.workload == "cfg4":
+        # stage two on top of the frame (reference: avatarHD_reenactment.py:153-160): SWGAN_unet(styles=[style], condition_img=render[:, 3:])
+        from havatar_amd.model.styleUnet import SWGAN_unet
+        up = SWGAN_unet(inp_size=H, inp_ch=64, out_ch=3, out_size=2 * H, style_dim=64, n_mlp=4, channel_multiplier=2)
+        up.requires_grad_(False)
+        up = synth.fill_state_dict(up, seed=2).to(dev).eval()
+        style = torch.from_numpy(synth.normal((1, 64), 93)).to(dev)
+        if args.graph:
+            from havatar_amd.graph import GraphedForward
+            with torch.no_grad():
+                first = render(poses[0])[0]
+            up_g = GraphedForward(lambda condition_img: up(styles=[style], condition_img=condition_img),
+                                  {"condition_img": first[:, 3:].contiguous()})
+
+            def upsample(feat):
+                return up_g(condition_img=feat)
+        else:
+            def upsample(feat):
+                with torch.no_grad():
+                    return up(styles=[style], condition_img=feat)
+
+        def step(i):
+            return upsample(render(poses[i % len(poses)])[0][:, 3:])
+        frames_per_step = world
     else:
         def step(i):
             return render(poses[i % len(poses)])
@@ -310,6 +336,10 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(i)
+    sync()
+            mm = tr._hip_marcher()
+            print("dbg step", i, "%.2f ms/frame so far" % (1e3 * (time.perf_counter() - t0) / (i + 1)), "fallback", mm.fp16_fallback_happened(),
+                  "planes max %.4g" % tr.model_coarse.triPlane_embeddings.abs().max().item(), mm.last_variant, file=sys.stderr, flush=True)
     sync()
     if world > 1:
         dist.barrier()
@@ -428,8 +458,14 @@ def main():
         # which unit is actually busiest (committed counters of this variant): the label the fraction below must be read with
         names = {"ta": "ta (texture addresser = the L1 gather path of the 8 tri-plane taps)", "mfma": "mfma", "valu": "valu"}
         busiest = max((k for k in ("ta", "mfma", "valu") if busy and k in busy), key=lambda k: busy[k], default=None)
+        cfg4_ms = None
+        if args.workload == "cfg4":          # the upsampler alone (its own graph), HIP events around the replay
+            with torch.no_grad():
+                feat = render(poses[0])[0][:, 3:].contiguous()
+                cfg4_ms = timed(lambda: upsample(feat), n_ev)
         res = {
-            "metric": "rendered frames/sec @512^2, 64 samples/ray", "value": round(fps, 3), "unit": "frames/s",
+            "metric": ("stage-two HD frames/sec: 512^2 NeRF volume render (64 samples/ray) + SWGAN_unet upsampler to 1024^2" if args.workload == "cfg4"
+                       else "rendered frames/sec @512^2, 64 samples/ray"), "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "strong" if args.workload == "cfg3" else "weak", "vs_baseline": None, "dtype": DTYPE[MODE],
             "data": "synthetic",
@@ -441,6 +477,11 @@ def main():
                                     "encoders_P3_inside_the_graph": round(1e3 * dt / args.steps / (frames_per_step / world) - kern_ms - prep_ms, 3),
                                     "note": "encoders_P3 is timed eagerly on one stream; inside the frame's hipGraph the two encoders run "
                                             "on two streams without launch gaps: step - march - preparation"},
+                       "stage_two": ({"upsampler_ms": round(cfg4_ms, 3), "output": [1, 3, 2 * H, 2 * W],
+                                      "what": "BASELINE configs[3]: the step is the cfg2 frame below followed by SWGAN_unet(512 -> 1024) on render[:, 3:] "
+                                              "(avatarHD_reenactment.py:153-160): its 3x3 / up-sampling convolutions, Haar transforms, upfirdn2d and "
+                                              "fused_bias_act are kernels of this library, stride-2 / 1x1 convolutions MIOpen; phase_ms.encoders_P3_inside_the_graph "
+                                              "includes the upsampler in this workload"} if args.workload == "cfg4" else None),
                        "rays_per_frame": H * W, "num_coarse": S_C, "num_fine": S_F, "perturb": perturb, "hipgraph": bool(args.graph),
                        "parallelism": ("frames sharded, %d rank(s), one overlapped all_gather of finished frames per round" if args.workload == "cfg3"
                                        else "frames sharded, %d rank(s), no data-path collective") % world,
