@@ -337,10 +337,6 @@ def main():
     for i in range(args.steps):
         out = step(i)
     sync()
-            mm = tr._hip_marcher()
-            print("dbg step", i, "%.2f ms/frame so far" % (1e3 * (time.perf_counter() - t0) / (i + 1)), "fallback", mm.fp16_fallback_happened(),
-                  "planes max %.4g" % tr.model_coarse.triPlane_embeddings.abs().max().item(), mm.last_variant, file=sys.stderr, flush=True)
-    sync()
     if world > 1:
         dist.barrier()
     sync()
