@@ -726,6 +726,104 @@ static int ufd_launch_direct(float* out, const float* in, const float* k, const 
     return 0;
 }
 
+// x2 up-sampling FIR (up = 2, down = 1, FIR <= 4x4: `Upsample` of the ToRGB skip path, model/styleUnet.py:65-75) without LDS: a thread owns
+// an 8 x 8 output block = the 2x2-tap polyphase filters applied to a 6 x 6 input window held in registers (12 loads, 16 16-byte stores).
+// EY / EX = parity of the padding: with output rows Y0 = 8 rb the zero-stuffed coordinate of tap i of row Y0 + q is 2 a0 + EY + q + i,
+// so which taps land on real samples -- and on which row of the window -- is known at compile time.  Same tap order (i asc, j asc over
+// the real taps, FMA chain from 0) as the tiled kernel: bit-identical results.
+template <int EY, int EX>
+__global__ void __launch_bounds__(256) ufd_up2_direct_f32_kernel(float* __restrict__ out, const float* __restrict__ in, const float* __restrict__ k,
+                                                                 UfdArgs a, int strips_x, int blocks_y, int64_t total)
+{
+    int64_t lb = blockIdx.x;
+    if ((gridDim.x & 7) == 0) lb = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);          // XCD-contiguous strip list
+    const int64_t gid = lb * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int sx = (int)(gid % strips_x);
+    int64_t t = gid / strips_x;
+    const int rb = (int)(t % blocks_y);
+    const int64_t m = t / blocks_y;
+    const int ox0 = 8 * sx, oy0 = 8 * rb;
+    const int a0f = (oy0 - a.py0 - EY) / 2, b0f = (ox0 - a.px0 - EX) / 2;          // exact divisions (even numerators), negative at the top / left edge
+    float kreg[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) kreg[i * 4 + j] = (i < a.kh && j < a.kw) ? k[(a.kh - 1 - i) * a.kw + (a.kw - 1 - j)] : 0.f;
+    const float* plane = in + m * (int64_t)a.in_h * a.in_w;
+    float v[6][6];
+    const bool interior = a0f >= 0 && a0f + 6 <= a.in_h && b0f >= 0 && b0f + 6 <= a.in_w;
+    if (interior) {
+        const float* src = plane + (int64_t)a0f * a.in_w + b0f;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+            typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+            const f4u q = *reinterpret_cast<const f4u*>(src + (int64_t)r * a.in_w);
+            const f2u w = *reinterpret_cast<const f2u*>(src + (int64_t)r * a.in_w + 4);
+            v[r][0] = q.x; v[r][1] = q.y; v[r][2] = q.z; v[r][3] = q.w; v[r][4] = w.x; v[r][5] = w.y;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const int iy = a0f + r;
+            const bool rok = iy >= 0 && iy < a.in_h;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const int ix = b0f + c;
+                v[r][c] = (rok && ix >= 0 && ix < a.in_w) ? plane[(int64_t)iy * a.in_w + ix] : 0.f;
+            }
+        }
+    }
+    float* oplane = out + m * (int64_t)a.out_h * a.out_w;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        float acc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (((q + i + EY) & 1) != 0) continue;          // tap row i of output row q sits between two samples
+            const int r = (q + i + EY) >> 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    if (((c + j + EX) & 1) != 0) continue;
+                    acc[c] = fmaf(v[r][(c + j + EX) >> 1], kreg[i * 4 + j], acc[c]);
+                }
+        }
+        const int oy = oy0 + q;
+        if (oy >= a.out_h) break;
+        float* dst = oplane + (int64_t)oy * a.out_w + ox0;
+        if (ox0 + 7 < a.out_w) {
+            typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+            const f4u o0 = {acc[0], acc[1], acc[2], acc[3]}, o1 = {acc[4], acc[5], acc[6], acc[7]};
+            *reinterpret_cast<f4u*>(dst) = o0;
+            *reinterpret_cast<f4u*>(dst + 4) = o1;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) if (ox0 + c < a.out_w) dst[c] = acc[c];
+        }
+    }
+}
+static int ufd_launch_up2_direct(float* out, const float* in, const float* k, const UfdArgs& a, hipStream_t st)
+{
+    const int strips_x = (a.out_w + 7) / 8, blocks_y = (a.out_h + 7) / 8;
+    const int64_t total = a.major * strips_x * blocks_y;
+    const int64_t blocks = ((total + 255) / 256 + 7) / 8 * 8;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return HAV_EUNSUP;
+    const int ey = a.py0 & 1, ex = a.px0 & 1;
+#define UFD_UP2(EY_, EX_) hipLaunchKernelGGL((ufd_up2_direct_f32_kernel<EY_, EX_>), dim3((unsigned)blocks), dim3(256), 0, st, out, in, k, a, strips_x, blocks_y, total)
+    if (ey == 0 && ex == 0) UFD_UP2(0, 0);
+    else if (ey == 0) UFD_UP2(0, 1);
+    else if (ex == 0) UFD_UP2(1, 0);
+    else UFD_UP2(1, 1);
+#undef UFD_UP2
+    HAV_LAUNCH_CHECK();
+    return 0;
+}
+
 template <typename T>
 static int ufd_launch(void* out_, const void* in_, const float* k, const UfdArgs& a, hipStream_t st)
 {
@@ -742,6 +840,9 @@ static int ufd_launch(void* out_, const void* in_, const float* k, const UfdArgs
                 if (kh <= 4 && kw <= 4 && (kh > 3 || kw > 3)) return ufd_launch_direct<1, 4, 4, 8>((float*)out, (const float*)in, k, a, st);
                 if (kh <= 3 && kw <= 3) return ufd_launch_direct<1, 3, 3, 8>((float*)out, (const float*)in, k, a, st);
             }
+            // f32 x2 up-sampling with a FIR of up to 4x4 taps (non-negative padding): the register-window kernel
+            if (up == 2 && dn == 1 && kh <= 4 && kw <= 4 && a.px0 >= 0 && a.py0 >= 0 && a.out_w >= 64)
+                return ufd_launch_up2_direct((float*)out, (const float*)in, k, a, st);
         }
         // the six parameter classes the StyleGAN blocks use (modes 1-6) + up2/down2
         if (up == 1 && dn == 1 && kh <= 3 && kw <= 3) return ufd_launch_tiled<T, 1, 1, 3, 3>(out, in, k, a, st);

@@ -108,6 +108,9 @@ def test_upfirdn2d_matches_reference_vectors_and_grads():
     (3, 31, 33, 1, 2, 2, (2, 2), (1, 1), (1, 0, 1, 0)), (2, 129, 67, 1, 4, 4, (1, 1), (2, 2), (1, 1, 1, 1)),
     (6, 64, 66, 1, 2, 2, (1, 1), (2, 2), (0, 0, 0, 0)), (2, 16, 16, 1, 1, 1, (1, 1), (1, 1), (0, 0, 0, 0)),
     (2, 40, 40, 1, 4, 2, (1, 1), (1, 1), (3, 0, 1, 2)), (2, 40, 41, 1, 2, 4, (2, 2), (1, 1), (0, 3, 2, 1)),
+    # x2 up-sampling through the register-window kernel (f32, out_w >= 64): both padding parities, ragged sizes, a non-square FIR
+    (3, 64, 64, 1, 4, 4, (2, 2), (1, 1), (2, 1, 2, 1)), (2, 37, 50, 1, 4, 4, (2, 2), (1, 1), (1, 2, 3, 0)),
+    (1, 128, 96, 1, 3, 4, (2, 2), (1, 1), (3, 2, 0, 5)), (12, 256, 256, 1, 4, 4, (2, 2), (1, 1), (2, 1, 2, 1)),
     # generic kernel: minor > 1, anisotropic factors, large FIR, negative pads
     (2, 12, 9, 3, 5, 3, (3, 2), (2, 3), (2, 3, 1, 4)), (3, 20, 22, 1, 7, 7, (1, 1), (1, 1), (3, 3, 3, 3)),
     (2, 14, 15, 2, 4, 4, (1, 1), (1, 1), (-1, 2, -2, 3)), (1, 9, 9, 1, 3, 3, (2, 2), (2, 2), (1, 1, 1, 1)),

@@ -91,6 +91,19 @@ for name, shape, k, up, dn, pad in (("upfirdn2d blur k4 [64,513,513]", (64, 513,
     ms, K = timed(mk, by)
     rows.append((name, ms, by, K))
     torch.cuda.empty_cache()
+# the Haar analysis / synthesis of SWGAN_unet's skip path as one pass each (hav_haar_dwt / hav_haar_idwt): four bands in one launch --
+# compare with 4 x the per-band upfirdn2d rows above (+ a cat / three adds)
+bank = torch.stack([torch.tensor(q, device=dev) for q in ([[.5, .5], [.5, .5]], [[-.5, -.5], [.5, .5]], [[-.5, .5], [-.5, .5]], [[.5, -.5], [-.5, .5]])])
+for name, shape, inv in (("haar analysis, 4 bands, one pass [3,1024,1024]", (1, 3, 1024, 1024), False),
+                         ("haar synthesis, 4 bands, one pass [12,512,512]", (1, 12, 512, 512), True)):
+    n_in = 3 * 1024 * 1024
+
+    def mkh(i):
+        x = torch.randn(shape, device=dev)
+        return lambda: fused.haar(x, bank, inverse=inv)
+    ms, K = timed(mkh, 8 * n_in)
+    rows.append((name, ms, 8 * n_in, K))
+    torch.cuda.empty_cache()
 print("# every launch on its own buffers, >= 1 GiB distinct per timed sequence (K launches): DRAM bandwidth, not Infinity Cache")
 for name, ms, by, K in rows:
     print("%-40s %8.1f us  %7.1f MB  %7.0f GB/s  %5.1f %% of 8 TB/s   (K=%d)" % (name, ms * 1e3, by / 1e6, by / ms / 1e6, 100 * by / ms / 1e6 / 8000, K))
