@@ -124,7 +124,7 @@ def main(argv=None, device=None, style=None):
                                          num_workers=int(os.environ.get("HAVATAR_WORKERS", 4)), pin_memory=device.type == "cuda")
     use_graph = device.type == "cuda" and os.environ.get("HAVATAR_GRAPH", "1") != "0"
     graphed, graphed2, written = None, None, []
-    writers = ThreadPoolExecutor(max_workers=int(os.environ.get("HAVATAR_PNG_THREADS", 4)))     # PNG deflate off the critical path
+    writers = ThreadPoolExecutor(max_workers=int(os.environ.get("HAVATAR_PNG_THREADS", 12)))    # PNG deflate off the critical path (a 1024^2 frame is ~70 ms of zlib on one core)
     pending, ring, in_flight = [], [None, None], None
     t_first = t_loop = None
     with torch.no_grad():
