@@ -555,6 +555,17 @@ def test_conv3x3_full_occupancy_runs_are_bitwise_identical():
         for _ in range(19):
             again = conv.conv3x3(x, pk, Cout, s=s, d=d, noise=noise, noise_weight=nw, bias=bias)
             assert torch.equal(first, again), (Cin, Cout, H, (first != again).sum().item())
+    # the same for the up-sampling path (hav_gemm_split + hav_upconv_finish) at a size that fills the GPU: 512 -> 256, 64^2 -> 128^2
+    from havatar_amd.model.styleUnet import make_kernel
+    x = torch.randn(1, 512, 64, 64, device=DEV, generator=g)
+    w = torch.randn(256, 512, 3, 3, device=DEV, generator=g)
+    s = 1.0 + 0.3 * torch.randn(1, 512, device=DEV, generator=g)
+    d = 0.5 + torch.rand(1, 256, device=DEV, generator=g)
+    fir = (make_kernel((1, 3, 3, 1)) * 4).to(DEV)
+    pk = conv.pack_upconv(w, 1.0 / (512 * 9) ** 0.5)
+    first = conv.upconv3x3(x, pk, 256, fir, s=s, d=d)
+    for _ in range(19):
+        assert torch.equal(first, conv.upconv3x3(x, pk, 256, fir, s=s, d=d))
 
 
 def test_conv3x3_split_refuses_unsupported_shapes():
