@@ -800,3 +800,197 @@ extern "C" int hav_upconv_finish(float* y, const float* col, const float* fir4x4
     HAV_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the 3x3 / stride 1 / padding 1 convolution on the same split-fp16 matrix path (training; reference: autograd of
+// conv2d_gradfix.conv2d in model/styleUnet.py -- MIOpen's fp32 igemm_wrw + its NHWC transposes are 6.4 ms of a 31 ms step):
+//
+//   gw[o, i, ky, kx] = sum_{b, y, x} g[b, o, y, x] * xin[b, i, y + ky - 1, x + kx - 1]
+//
+// GEMM view: M = Cout, N = Cin, K = pixels -- per tap a different shift of the N operand.  Both operands are activations (nothing to
+// pre-pack): both go through LDS as fp16 hi / lo.  Workgroup = 64 (o) x 32 (i) x 9 taps; wave (mo, tg) owns one 32-row M tile and taps
+// 0-4 or 5-8 (5 / 4 accumulator tiles).  K advances one image-row segment of 16 pixels per step down a column strip (b, x0): the step
+// needs g[.., y, x0..x0+15] and input rows y-1, y, y+1; rows live in a ring of four LDS slots, each row stored THREE times, shifted by
+// kx - 1 = -1, 0, +1 pixels (an MFMA operand is 8 consecutive fp16 = one 16-byte LDS read, and a one-pixel shift is 2 bytes), so a
+// step stages one new input row (x3) and one g row.  Column strips are dealt to gridDim.z workgroups per output block (K split);
+// partial sums are laid out [z][tap][o][i] (lane = i: coalesced) and added up by conv3x3_wgrad_reduce_kernel into [o][i][3][3].
+// g is gradient-sized (1e-6): it takes the same power-of-two range control as the forward kernels (in_amax of g).
+#define WG_XI 52            // dwords per input channel in a row slot: 3 shifts x 16 (8 hi + 8 lo) + 4 pad (16 lanes -> 16 bank groups)
+#define WG_GO 20            // dwords per output channel in a g buffer: 8 hi + 8 lo + 4 pad
+struct WgradArgs {
+    float* partial; const float* g; const float* x; const unsigned int* g_amax;
+    int B, Cin, Cout, H, W, strips;
+};
+
+__global__ void __launch_bounds__(256, 2) conv3x3_wgrad_kernel(WgradArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t xs[4][32 * WG_XI];
+    __shared__ __attribute__((aligned(16))) uint32_t gs[2][64 * WG_GO];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 31, h = lane >> 5;
+    const int mo = wave & 1, tg = wave >> 1;
+    const int i0 = blockIdx.x * 32, o0 = blockIdx.y * 64;
+    const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
+    const int sw = W / 16;          // strips per image
+    float g_sc = 1.0f, out_sc = 1.0f;
+    if (a.g_amax) {
+        const uint4 w4m = reinterpret_cast<const uint4*>(a.g_amax)[lane];
+        unsigned int mb = w4m.x > w4m.y ? w4m.x : w4m.y;
+        mb = w4m.z > mb ? w4m.z : mb;
+        mb = w4m.w > mb ? w4m.w : mb;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { const unsigned int t = (unsigned int)__shfl_xor((int)mb, o, 64); mb = t > mb ? t : mb; }
+        const int be = (int)((mb >> 23) & 0xFFu);
+        if (be >= 1 && be <= 254) {
+            int e = 9 - (be - 127);
+            e = e > 100 ? 100 : (e < -100 ? -100 : e);
+            g_sc = __uint_as_float((unsigned int)(127 + e) << 23);
+            out_sc = __uint_as_float((unsigned int)(127 - e) << 23);
+        }
+    }
+    // staging roles.  g: thread = (o = tid >> 2, 4 pixels q4 = tid & 3): one float4.  x: thread = (i = tid >> 3, pixel pair p8 = tid & 7)
+    const int g_o = tid >> 2, g_q = tid & 3;
+    const int x_i = tid >> 3, x_p = tid & 7;
+    f32x16 acc[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    auto split2 = [](float v0, float v1, uint32_t& hi, uint32_t& lo) {
+        const fl2_t f = {v0, v1};
+        const h2_t hh = __builtin_convertvector(f, h2_t);
+        const h2_t ll = __builtin_convertvector(f - __builtin_convertvector(hh, fl2_t), h2_t);
+        hi = __builtin_bit_cast(uint32_t, hh); lo = __builtin_bit_cast(uint32_t, ll);
+    };
+    // input row `row` of strip (b, x0) -> ring slot (row + 1) & 3, three shifted copies; rows outside the image are zeros.  fetch_*
+    // only issue the loads; stash_* (conversion, LDS writes) run after the step's MFMAs so that the loads fly under them
+    struct XR { float a0, a1, el, er; };
+    auto fetch_x = [&](int b, int x0, int row) {
+        XR r = {0.f, 0.f, 0.f, 0.f};
+        if (row >= 0 && row < H) {
+            const float* src = a.x + (((int64_t)b * Cin + i0 + x_i) * H + row) * W + x0;
+            const float2 v = *reinterpret_cast<const float2*>(src + 2 * x_p);
+            r.a0 = v.x; r.a1 = v.y;
+            if (x_p == 0 && x0 > 0) r.el = src[-1];
+            if (x_p == 7 && x0 + 16 < W) r.er = src[16];
+        }
+        return r;
+    };
+    auto stash_x = [&](int row, const XR& r) {
+        uint32_t* dst = xs[(row + 1) & 3] + x_i * WG_XI;
+        // neighbours inside the 8-thread group of this channel (lanes are consecutive): previous pair's second / next pair's first
+        float pa1 = __shfl_up(r.a1, 1, 64), na0 = __shfl_down(r.a0, 1, 64);
+        if (x_p == 0) pa1 = r.el;
+        if (x_p == 7) na0 = r.er;
+        uint32_t hi, lo;
+        split2(pa1, r.a0, hi, lo);  dst[0 * 16 + x_p] = hi; dst[0 * 16 + 8 + x_p] = lo;          // kx = 0: element j = x[x0 + j - 1]
+        split2(r.a0, r.a1, hi, lo); dst[1 * 16 + x_p] = hi; dst[1 * 16 + 8 + x_p] = lo;          // kx = 1
+        split2(r.a1, na0, hi, lo);  dst[2 * 16 + x_p] = hi; dst[2 * 16 + 8 + x_p] = lo;          // kx = 2: element j = x[x0 + j + 1]
+    };
+    auto fetch_g = [&](int b, int x0, int row) {
+        return *reinterpret_cast<const float4*>(a.g + (((int64_t)b * Cout + o0 + g_o) * H + row) * W + x0 + 4 * g_q);
+    };
+    auto stash_g = [&](int buf, const float4& v) {
+        uint32_t* dst = gs[buf] + g_o * WG_GO + 2 * g_q;
+        uint32_t h0, l0, h1, l1;
+        split2(v.x * g_sc, v.y * g_sc, h0, l0);
+        split2(v.z * g_sc, v.w * g_sc, h1, l1);
+        dst[0] = h0; dst[1] = h1; dst[8] = l0; dst[9] = l1;
+    };
+
+    for (int s = blockIdx.z; s < a.strips; s += gridDim.z) {
+        const int b = s / sw, x0 = (s - b * sw) * 16;
+        __syncthreads();          // the previous strip's last step is done with the ring
+        stash_x(-1, fetch_x(b, x0, -1));
+        stash_x(0, fetch_x(b, x0, 0));
+        stash_x(1, fetch_x(b, x0, 1));
+        stash_g(0, fetch_g(b, x0, 0));
+        __syncthreads();
+        for (int y = 0; y < H; ++y) {
+            // next step's operands: input row y + 2 (its slot held row y - 2) and g row y + 1 (other buffer): loads now, LDS after the MFMAs
+            const bool more = y + 1 < H;
+            XR nx = {0.f, 0.f, 0.f, 0.f};
+            float4 ng = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (more) { nx = fetch_x(b, x0, y + 2); ng = fetch_g(b, x0, y + 1); }
+            const uint32_t* G = gs[y & 1] + (32 * mo + j) * WG_GO + 4 * h;
+            const f16x8_t gh = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(G));
+            const f16x8_t gl = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(G + 8));
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const int t = tg * 5 + q;          // tap (wave-uniform); tg = 1 has four (t = 5..8)
+                if (t < 9) {
+                    const int ky = t / 3, kx = t - 3 * ky;
+                    const uint32_t* X = xs[(y + ky) & 3] + j * WG_XI + kx * 16 + 4 * h;          // row y + ky - 1 -> slot (y + ky) & 3
+                    const f16x8_t xh = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(X));
+                    const f16x8_t xl = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(X + 8));
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl, xh, acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xl, acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xh, acc[q], 0, 0, 0);
+                }
+            }
+            asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]));
+            if (more) { stash_x(y + 2, nx); stash_g((y + 1) & 1, ng); }
+            __syncthreads();
+        }
+    }
+    // D[m = o][n = i]: lane j = i, registers = o rows.  partial[z][t][o][i]
+    float* pp = a.partial + (int64_t)blockIdx.z * 9 * Cout * Cin;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const int t = tg * 5 + q;
+        if (t < 9) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = o0 + 32 * mo + (r & 3) + 8 * (r >> 2) + 4 * h;
+                pp[((int64_t)t * Cout + o) * Cin + i0 + j] = acc[q][r] * out_sc;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) conv3x3_wgrad_reduce_kernel(float* __restrict__ gw, const float* __restrict__ partial, int ks, int Cout, int Cin)
+{
+    const int64_t n = (int64_t)Cout * Cin;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        float v[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            float s = 0.f;
+            for (int k = 0; k < ks; ++k) s += partial[((int64_t)k * 9 + t) * n + e];
+            v[t] = s;
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) gw[e * 9 + t] = v[t];
+    }
+}
+
+static int wgrad_ksplit(int B, int Cin, int Cout, int H, int W)
+{
+    const int blocks = (Cin / 32) * (Cout / 64), strips = B * (W / 16);
+    int ks = 1;
+    while (blocks * ks < 2 * hav_num_cus() && ks * 2 <= strips) ks *= 2;
+    return ks;
+}
+extern "C" int64_t hav_conv3x3_wgrad_scratch_bytes(int B, int Cin, int Cout, int H, int W)
+{
+    if (B < 1 || Cin < 32 || Cout < 64 || H < 1 || W < 16 || (Cin % 32) || (Cout % 64) || (W % 16)) return 0;
+    return (int64_t)wgrad_ksplit(B, Cin, Cout, H, W) * 9 * Cout * Cin * 4;
+}
+extern "C" int hav_conv3x3_wgrad(float* gw, const float* g, const float* x, void* scratch, const void* g_amax, int B, int Cin, int Cout, int H,
+                                 int W, void* stream)
+{
+    if (!gw || !g || !x || !scratch || B < 1 || H < 1) return HAV_EINVAL;
+    if (Cin < 32 || Cout < 64 || W < 16 || (Cin % 32) || (Cout % 64) || (W % 16)) return HAV_EUNSUP;
+    WgradArgs a;
+    a.partial = (float*)scratch; a.g = g; a.x = x; a.g_amax = (const unsigned int*)g_amax;
+    a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.strips = B * (W / 16);
+    const int ks = wgrad_ksplit(B, Cin, Cout, H, W);
+    hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3((unsigned)(Cin / 32), (unsigned)(Cout / 64), (unsigned)ks), dim3(256), 0, (hipStream_t)stream, a);
+    HAV_LAUNCH_CHECK();
+    const int64_t n = (int64_t)Cout * Cin;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > (int64_t)hav_num_cus() * 8) blocks = (int64_t)hav_num_cus() * 8;
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gw, (const float*)scratch, ks, Cout, Cin);
+    HAV_LAUNCH_CHECK();
+    return 0;
+}

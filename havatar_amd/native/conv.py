@@ -69,6 +69,29 @@ def conv3x3(x, packed, Cout, s=None, d=None, noise=None, noise_weight=None, bias
     return y
 
 
+def wgrad_eligible(g, x):
+    if not (g.is_cuda and g.dtype == torch.float32 and x.dtype == torch.float32 and g.dim() == 4 and x.dim() == 4):
+        return False
+    B, Cout, H, W = g.shape
+    return x.shape[0] == B and tuple(x.shape[2:]) == (H, W) and x.shape[1] % 32 == 0 and Cout % 64 == 0 and W % 16 == 0
+
+
+def wgrad3x3(g, x):
+    """gw [Cout,Cin,3,3] = d/dW of conv2d(x, W, stride 1, padding 1) given g = dL/dy (hav_conv3x3_wgrad: split-fp16 MFMA, fp32-class)."""
+    g, x = g.contiguous(), x.contiguous()
+    B, Cout, H, W = g.shape
+    Cin = x.shape[1]
+    L = _lib.lib()
+    gw = torch.empty(Cout, Cin, 3, 3, dtype=torch.float32, device=g.device)
+    scratch = torch.empty(int(L.hav_conv3x3_wgrad_scratch_bytes(B, Cin, Cout, H, W)), dtype=torch.uint8, device=g.device)
+    amax = torch.empty(256, dtype=torch.int32, device=g.device)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    with torch.cuda.device(g.device):
+        _lib.check(L.hav_absmax(_p(amax), _p(g), g.numel(), st), "hav_absmax")
+        _lib.check(L.hav_conv3x3_wgrad(_p(gw), _p(g), _p(x), _p(scratch), _p(amax), B, Cin, Cout, H, W, st), "hav_conv3x3_wgrad")
+    return gw
+
+
 class _Conv3x3Split(torch.autograd.Function):
     """conv2d(x, w, stride 1, padding 1) for training: the forward runs on hav_conv3x3_split (split-fp16 MFMA, fp32-class results,
     ~2x MIOpen's fp32 Winograd on the encoder shapes), and so does the data gradient, which is the same kind of convolution with
@@ -91,8 +114,14 @@ class _Conv3x3Split(torch.autograd.Function):
             if eligible(g, wt):
                 gx = conv3x3(g, pack(wt, 1.0), wt.shape[0], act=False, autoscale=True)     # gradients are ~1e-6: see hav_absmax
                 need_x = False
+        gw = None
+        if need_w and os.environ.get("HAVATAR_CONV_WGRAD", "1") != "0" and wgrad_eligible(g, x):
+            gw = wgrad3x3(g, x)          # the weight gradient on the split-fp16 path too (MIOpen: fp32 igemm_wrw + NHWC transposes)
+            need_w = False
+        if not (need_x or need_w):
+            return gx, gw
         r = torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [need_x, need_w, False])
-        return (gx if gx is not None else r[0]), r[1]
+        return (gx if gx is not None else r[0]), (gw if gw is not None else r[1])
 
 
 def conv3x3_autograd(x, w):

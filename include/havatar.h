@@ -188,6 +188,12 @@ int hav_conv3x3_split(float* y, const float* x, const void* packed, const float*
 #define HAV_ABSMAX_WORDS 256
 int hav_absmax(void* out_bits, const float* x, int64_t n, void* stream);
 
+/* Weight gradient of the same convolution (training): gw[o,i,ky,kx] = sum_{b,y,x} g[b,o,y,x] * x[b,i,y+ky-1,x+kx-1] on the split-fp16
+ * matrix path (Cin % 32 == 0, Cout % 64 == 0, W % 16 == 0).  scratch: hav_conv3x3_wgrad_scratch_bytes() bytes (K-split partial sums);
+ * g_amax: HAV_ABSMAX_WORDS words from hav_absmax(g) or NULL (range control of the gradient-sized operand). */
+int64_t hav_conv3x3_wgrad_scratch_bytes(int B, int Cin, int Cout, int H, int W);
+int hav_conv3x3_wgrad(float* gw /*[Cout,Cin,3,3]*/, const float* g /*[B,Cout,H,W]*/, const float* x /*[B,Cin,H,W]*/, void* scratch,
+                      const void* g_amax, int B, int Cin, int Cout, int H, int W, void* stream);
 /* The up-sampling StyledConv of the StyleGAN blocks (model/styleUnet.py:236-243: conv_transpose2d(x * s, W, stride 2) -> 4x4 FIR with
  * padding (1,1) -> demodulation -> noise -> bias -> leaky-ReLU) in two launches:
  *   hav_gemm_split     y[b, m, n] = sum_k A[m, k] * (s[b, k] * x[b, k, n])    split-fp16 matrix path, fp32-class (K % 32 == 0, N % 128 == 0;

@@ -600,6 +600,30 @@ def test_conv3x3_autograd_node_matches_fp64_autograd():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(1, 32, 64, 5, 16), (2, 64, 128, 32, 32), (2, 512, 512, 64, 64), (1, 96, 64, 17, 48)])
+def test_conv3x3_wgrad_matches_fp64_autograd(B, Cin, Cout, H, W):
+    """hav_conv3x3_wgrad (weight gradient on the split-fp16 matrix path, K-split + reduction) against fp64 autograd of F.conv2d, with the
+    fp32 ATen route's own error as the yardstick; gradient-sized g (3e-7) exercises the range control; odd heights, a single strip,
+    several strips per workgroup."""
+    from havatar_amd.native import conv
+    g_ = torch.Generator().manual_seed(B + Cin + Cout + H)
+    x = torch.randn(B, Cin, H, W, generator=g_)
+    go = torch.randn(B, Cout, H, W, generator=g_) * 3e-7
+    w = torch.randn(Cout, Cin, 3, 3, generator=g_) / (Cin * 9) ** 0.5
+    assert conv.wgrad_eligible(go.cuda(), x.cuda())
+    got = conv.wgrad3x3(go.cuda(), x.cuda()).double().cpu()
+    w64 = w.double().requires_grad_(True)
+    torch.nn.functional.conv2d(x.double(), w64, padding=1).backward(go.double())
+    w32 = w.clone().requires_grad_(True)
+    torch.nn.functional.conv2d(x, w32, padding=1).backward(go)
+    floor = (w32.grad.double() - w64.grad).abs().max().item()
+    assert (got - w64.grad).abs().max().item() <= 3.0 * floor + 2e-6 * w64.grad.abs().max().item()
+    # run-to-run identical (fixed reduction order, no atomics)
+    again = conv.wgrad3x3(go.cuda(), x.cuda()).double().cpu()
+    assert torch.equal(got, again)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,Cin,Cout,k", [(1, 16, 24, 3), (2, 512, 512, 3), (2, 256, 12, 1)])
 def test_demod_autograd_node_matches_the_aten_statement(B, Cin, Cout, k):
     """hav_demod_fwd / _bwd (native/train_ops.py::demod) vs the ATen statement of ModulatedConv2d's demodulation factors and its
