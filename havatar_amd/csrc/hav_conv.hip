@@ -964,11 +964,14 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_reduce_kernel(float* __rest
     }
 }
 
+#ifndef WGRAD_FILL
+#define WGRAD_FILL 2
+#endif
 static int wgrad_ksplit(int B, int Cin, int Cout, int H, int W)
 {
     const int blocks = (Cin / 32) * (Cout / 64), strips = B * (W / 16);
     int ks = 1;
-    while (blocks * ks < 2 * hav_num_cus() && ks * 2 <= strips) ks *= 2;
+    while (blocks * ks < WGRAD_FILL * hav_num_cus() && ks * 2 <= strips) ks *= 2;
     return ks;
 }
 extern "C" int64_t hav_conv3x3_wgrad_scratch_bytes(int B, int Cin, int Cout, int H, int W)
