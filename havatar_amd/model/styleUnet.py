@@ -113,7 +113,7 @@ class EqualConv2d(nn.Module, _InferenceCache):
         w = self._cached("w", self.weight, lambda: self.weight * self.scale)
         if (torch.is_grad_enabled() and _fused_conv_enabled() and input.shape[-1] * input.shape[-2] >= 1024
                 and _conv.eligible(input, w, self.stride, self.padding)):
-            # training on HIP tensors: forward on the split-fp16 MFMA kernel, backward through MIOpen (native/conv.py)
+            # training on HIP tensors: forward and both gradients on the split-fp16 MFMA kernels (native/conv.py)
             out = _conv.conv3x3_autograd(input, w)
             return out if self.bias is None else out + self.bias.view(1, -1, 1, 1)
         return conv2d_gradfix.conv2d(input, w, bias=self.bias, stride=self.stride, padding=self.padding)
@@ -215,7 +215,7 @@ class ModulatedConv2d(nn.Module, _InferenceCache):
             out = conv2d_gradfix.conv2d(self.blur(x), w, padding=0, stride=2)
         elif (torch.is_grad_enabled() and self.kernel_size == 3 and _fused_conv_enabled() and x.shape[-1] * x.shape[-2] >= 1024
               and _conv.eligible(x, w)):
-            out = _conv.conv3x3_autograd(x, w)          # training: split-fp16 MFMA forward, MIOpen backward (native/conv.py)
+            out = _conv.conv3x3_autograd(x, w)          # training: forward, data and weight gradient on the split-fp16 MFMA kernels (native/conv.py)
         else:
             out = conv2d_gradfix.conv2d(x, w, padding=self.padding)
         return out, d

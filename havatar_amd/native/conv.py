@@ -95,7 +95,8 @@ def wgrad3x3(g, x):
 class _Conv3x3Split(torch.autograd.Function):
     """conv2d(x, w, stride 1, padding 1) for training: the forward runs on hav_conv3x3_split (split-fp16 MFMA, fp32-class results,
     ~2x MIOpen's fp32 Winograd on the encoder shapes), and so does the data gradient, which is the same kind of convolution with
-    the transposed, flipped filters; the weight gradient is ATen's convolution_backward (MIOpen) on the saved fp32 operands."""
+    the transposed, flipped filters; the weight gradient runs on hav_conv3x3_wgrad (wgrad3x3 below; ATen's convolution_backward only
+    for shapes that kernel does not take, HAVATAR_CONV_WGRAD=0 forces it)."""
 
     @staticmethod
     def forward(ctx, x, w):
