@@ -39,7 +39,7 @@ for f in sorted(glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.
     for r in rows:
         acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, cs in acc.items():
-        if "march" not in k and "fba" not in k and "ufd" not in k and "plane_project" not in k:
+        if not any(t in k for t in ("march", "fba", "ufd", "plane_project", "conv3x3", "gemm_split", "upconv", "haar", "style_demod", "absmax")):
             continue
         print("  %s" % k[:80])
         for c, vals in sorted(cs.items()):
