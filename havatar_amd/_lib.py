@@ -62,6 +62,10 @@ def lib():
         raise HavatarLibraryError(
             f"{path} is missing: build it with `python -m havatar_amd.build` "
             "(or __graft_entry__.build()). There is no fallback path.")
+    # PyTorch-ROCm ships its own libamdhip64; the library must bind to THAT runtime (device memory and streams come from torch).
+    # Loaded before torch, it would pull in /opt/rocm's copy first and the process would hold two HIP runtimes: every call from
+    # here then fails with hipErrorNoDevice (100) -- seen when __graft_entry__.build() ran before the first `import torch`.
+    import torch  # noqa: F401
     L = C.CDLL(path)
     L.hav_abi_version.restype = C.c_int
     if L.hav_abi_version() != ABI_VERSION:
