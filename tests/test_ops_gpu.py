@@ -493,7 +493,8 @@ def test_absmax_partial_maxima_fold_to_the_tensor_maximum():
         assert got == want, (n, got, want)
 
 
-@pytest.mark.parametrize("B,Cin,Cout,H,W", [(1, 512, 512, 16, 16), (1, 512, 256, 64, 64), (2, 64, 64, 32, 32), (1, 128, 24, 16, 64)])
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(1, 512, 512, 16, 16), (1, 512, 256, 64, 64), (2, 64, 64, 32, 32), (1, 128, 24, 16, 64),
+                                            (1, 32, 16, 64, 6), (2, 32, 8, 64, 2)])
 def test_upconv3x3_matches_fp64_transposed_convolution_and_blur(B, Cin, Cout, H, W):
     """hav_gemm_split + hav_upconv_finish vs the reference statement in fp64: conv_transpose2d(x * s, W, stride 2) -> upfirdn2d(4x4,
     pad (1,1)) -> * d + nw * noise + bias -> leaky-ReLU * sqrt(2) (model/styleUnet.py:236-243,565-599).  Yardstick: the same chain in
