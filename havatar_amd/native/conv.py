@@ -1,6 +1,10 @@
-"""3x3 stride-1 convolution of the StyleGAN blocks on the fp16 matrix cores with split operands and the block's glue fused in
-(libhavatar_hip.so: hav_conv3x3_*; include/havatar.h).  Inference only (no autograd); HIP float32 tensors; no fallback in here --
-`eligible()` tells the caller whether the shape is supported, otherwise it keeps its MIOpen route."""
+"""The convolutions of the StyleGAN blocks (reference model/styleUnet.py:165-297,326-368,565-599) on the fp16 matrix cores with split
+operands (libhavatar_hip.so: hav_conv3x3_*, hav_gemm_*, hav_upconv_finish; include/havatar.h):
+  conv3x3 / pack            3x3 stride 1 with the block's glue fused in (inference)
+  upconv3x3 / pack_upconv   the up-sampling StyledConv: transposed convolution as a matrix product + scatter / blur / epilogue
+  conv3x3_autograd          forward, data gradient (same kernel) and weight gradient (wgrad3x3 = hav_conv3x3_wgrad) for training
+HIP float32 tensors only; no fallback in here -- the `*eligible()` predicates tell the caller whether a shape is supported, otherwise
+it keeps its MIOpen route."""
 import ctypes as C
 import os
 
