@@ -1,4 +1,13 @@
-// hav_conv.hip -- 3x3 stride-1 convolution of the StyleGAN blocks as an implicit GEMM on the fp16 matrix cores with split
+// hav_conv.hip -- the convolutions of the StyleGAN blocks on the fp16 matrix cores with split operands (fp32-class results):
+//   conv3x3_split_kernel / conv3x3_il_kernel   3x3 stride 1 as an implicit GEMM, the block's modulation / demodulation / noise / bias /
+//                                              leaky-ReLU fused in (plain 64 x 128 tiles; interleaved 128 x 128 tiles for Cout % 128 == 0)
+//   gemm_split_kernel + upconv_finish_kernel   the up-sampling StyledConv: transposed convolution as a matrix product, then stride-2
+//                                              scatter + 4x4 FIR + epilogue in one pass
+//   conv3x3_wgrad_kernel (+ reduce)            weight gradient of the 3x3 convolution (training)
+//   absmax_kernel                              range control for gradient-sized inputs
+// The first section describes the 3x3 forward kernel; the others carry their own headers further down.
+//
+// 3x3 stride-1 convolution of the StyleGAN blocks as an implicit GEMM on the fp16 matrix cores with split
 // operands (fp32-class results), with the modulation, demodulation, noise, bias and leaky-ReLU of the block fused in.
 // SURVEY 8(f) next-4; reference: ModulatedConv2d / StyledConv / ConvLayer of model/styleUnet.py:165-297,326-368,565-599 in their
 // scale-input / shared-weight / scale-output form (the reference's own non-fused algebra, :200-227):
