@@ -293,11 +293,24 @@ __global__ void __launch_bounds__(256) plane_project_kernel(float* __restrict__ 
     // index and mostly need the same piece of neighbouring texels: they now hit one 64-byte segment instead of four lines 512 bytes
     // apart (the texture path serves a quad per cycle only when it stays inside one line).  W % 4 == 0.
     float* out = dst + (size_t)pb * HW * 128;
-    for (int i = tid; i < 64 * 128; i += 256) {
-        const int t = i >> 7, hu = i & 127;
-        const int tt = t0 + t;                       // y * W + x with W % 4 == 0: tt >> 2 = group, tt & 3 = x & 3
-        const int tg = p ? HAV_TG1 : HAV_TG;
-        if (tt < HW) out[(size_t)(tt >> tg) * (128 << tg) + (hu >> 2) * (4 << tg) + (tt & ((1 << tg) - 1)) * 4 + (hu & 3)] = sO[t * 129 + hu];
+    const int tg = p ? HAV_TG1 : HAV_TG;
+    if (t0 + 64 <= HW && (64 >> tg) << tg == 64) {
+        // the workgroup's 64 texels are 64 >> tg whole groups = ONE contiguous block of 64 x 128 floats in the prepared layout: walk it
+        // in address order, 16 bytes per thread (a wave writes 1 KB contiguous; indexed by (texel, unit) the same stores were 16-byte
+        // fragments at a 64-byte stride: four times the store transactions)
+        float4* blk = reinterpret_cast<float4*>(out + (size_t)(t0 >> tg) * (128 << tg));
+        for (int q = tid; q < 64 * 32; q += 256) {          // float4 index inside the block
+            const int g = q / (32 << tg), rem = q - g * (32 << tg);          // group, float4 inside the group: [piece 0..31][texel 0..(1<<tg)-1]
+            const int piece = rem >> tg, tx4 = rem & ((1 << tg) - 1);
+            const float* so = sO + ((g << tg) + tx4) * 129 + 4 * piece;
+            blk[q] = make_float4(so[0], so[1], so[2], so[3]);
+        }
+    } else {
+        for (int i = tid; i < 64 * 128; i += 256) {
+            const int t = i >> 7, hu = i & 127;
+            const int tt = t0 + t;                       // y * W + x with W % 4 == 0: tt >> 2 = group, tt & 3 = x & 3
+            if (tt < HW) out[(size_t)(tt >> tg) * (128 << tg) + (hu >> 2) * (4 << tg) + (tt & ((1 << tg) - 1)) * 4 + (hu & 3)] = sO[t * 129 + hu];
+        }
     }
     if (tid < 128) {                // fp16 range guard: this tile's max |P[hu]| (texels past the end hold exact zeros)
         float m = 0.f;
