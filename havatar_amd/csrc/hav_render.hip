@@ -674,14 +674,8 @@ __device__ __forceinline__ void mfma_split3(f32x16 (&acc)[4], const uint4* frag 
     uint4 A[2][3];
     uint4 bh, bm, bl;
     bf16x8_t pa, pb;                  // operands of the previous group's last MFMA
-    // this lane's fragment column as ONE opaque base: every read below is base + immediate.  Left transparent, the compiler hoists
-    // one loop-invariant address register PER FRAGMENT out of the sample loop (the LDS image is larger than the 64-KB immediate
-    // range), spills them and reloads an address from scratch in front of every ds_read
-#ifndef HAV_NO_FRAG_OPAQUE
-    frag += lane;
-    asm volatile("" : "+v"(frag));
-    lane = 0;
-#endif
+    // (Do NOT launder `frag` through an empty asm to stop address hoisting: the pointer then loses its LDS address space and every
+    // fragment read becomes a FLAT load -- +0.8 ms per frame, measured.)
 #pragma unroll
     for (int q = 0; q < 3; ++q) A[0][q] = frag[q * 64 + lane];
 #pragma unroll
@@ -727,52 +721,90 @@ __device__ __forceinline__ void split2h(float v0, float v1, uint32_t& ph, uint32
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     const f2 v = {v0, v1};
     const h2 hi = __builtin_convertvector(v, h2);
+    ph = __builtin_bit_cast(uint32_t, hi);
+#ifndef HAV_NO_FMA_MIX
+    // lo = fp16(v - (float)hi), the subtraction exact in fp32: the mixed-precision FMAs read the fp16 half directly and write the rounded
+    // fp16 result into one half of the destination -- 3 instructions per operand pair instead of 5 (two cvt_f32_f16, pk_add, cvt_pk)
+    uint32_t lo;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(ph), "v"(v0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(ph), "v"(v1));
+    pl = lo;
+#else
     const f2 r = v - __builtin_convertvector(hi, f2);           // exact
     const h2 lo = __builtin_convertvector(r, h2);
-    ph = __builtin_bit_cast(uint32_t, hi);
     pl = __builtin_bit_cast(uint32_t, lo);
+#endif
 }
 // HARD: the keep-alives above pin VALUES, not physical registers: when the allocator has to spill or split the live range of an
 // operand between its MFMA and the KEEP (seen in the one instantiation that runs with 64 more live accumulators than the others:
 // the feature projection of a parked tile inside the kernels that also composite the coarse outputs, ~0.4 % of the rays of a
 // full frame wrong in columns 16-31, run to run), the register the MFMA is still reading is free again.  HARD waits the matrix
 // instruction out (32 cycles) before the vector code of the next k-chunk may touch anything.
+#ifndef HAV_BLOCK_FENCE
+#define HAV_BLOCK_FENCE 1
+#endif
+#ifndef HAV_BKEEP
+#define HAV_BKEEP 0
+#endif
+#ifndef HAV_HARD_NOPS
+#define HAV_HARD_NOPS "s_nop 15\n\ts_nop 15"
+#endif
 template <int NCH, int NM, bool HARD = true, typename GetV>
 __device__ __forceinline__ void mfma_split2h(f32x16 (&acc)[NM], const uint4* frag /* [NCH][NM row tiles][2 parts][64 lanes] */, int lane, GetV getv)
 {
-    uint4 A[2][2];
-    uint4 bh, bl;
-    f16x8_t pa, pb;
-#ifndef HAV_NO_FRAG_OPAQUE
+#ifndef HAV_FRAG_DIST
+#define HAV_FRAG_DIST 1     // groups of MFMAs a fragment read runs ahead of its use (1: 64-96 cycles; 2 and 3 measured the same: the loops do not wait on the LDS)
 #endif
+    constexpr int FD = HAV_FRAG_DIST, NBUF = FD + 1, NG = NCH * NM;
+    uint4 A[NBUF][2];
+    uint4 bh, bl;
+    uint4 obh = {0u, 0u, 0u, 0u}, obl = {0u, 0u, 0u, 0u};      // the previous chunk's B operands (HAV_BKEEP)
+    f16x8_t pa, pb;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) A[0][q] = frag[q * 64 + lane];
+    for (int d = 0; d < FD; ++d)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (d < NG) A[d][q] = frag[(d * 2 + q) * 64 + lane];
 #pragma unroll
     for (int g = 0; g < NCH * NM; ++g) {
         const int m = g % NM, ch = g / NM;
         if (m == 0) {
             float v[8];
             getv(ch, v);
+#if HAV_BKEEP
+            if (ch > 0) { obh = bh; obl = bl; }
+#endif
             split2h(v[0], v[1], bh.x, bl.x); split2h(v[2], v[3], bh.y, bl.y);
             split2h(v[4], v[5], bh.z, bl.z); split2h(v[6], v[7], bh.w, bl.w);
+#if HAV_BKEEP
+            // the registers that held the previous chunk's B operands stay allocated until this chunk's are complete: the new values
+            // (and the temporaries of their conversion) cannot land in a register an MFMA of the previous chunk may still be reading
+            if (ch > 0) {
+                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                u32x4 nh = {bh.x, bh.y, bh.z, bh.w}, nl = {bl.x, bl.y, bl.z, bl.w};
+                const u32x4 oh = {obh.x, obh.y, obh.z, obh.w}, ol = {obl.x, obl.y, obl.z, obl.w};
+                asm volatile("" : "+v"(nh), "+v"(nl) : "v"(oh), "v"(ol));
+                bh = make_uint4(nh.x, nh.y, nh.z, nh.w); bl = make_uint4(nl.x, nl.y, nl.z, nl.w);
+            }
+#endif
         }
         const f16x8_t xh = __builtin_bit_cast(f16x8_t, bh), xl = __builtin_bit_cast(f16x8_t, bl);
-        const f16x8_t ah = __builtin_bit_cast(f16x8_t, A[g & 1][0]), al = __builtin_bit_cast(f16x8_t, A[g & 1][1]);
+        const f16x8_t ah = __builtin_bit_cast(f16x8_t, A[g % NBUF][0]), al = __builtin_bit_cast(f16x8_t, A[g % NBUF][1]);
         acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh, acc[m], 0, 0, 0);
         if (g > 0) { KEEP(acc[m], pa); KEEP(acc[m], pb); }
-        if (g + 1 < NCH * NM) {
+        if (g + FD < NG) {           // into the buffer whose last reader (group g - 1) is long done
 #pragma unroll
-            for (int q = 0; q < 2; ++q) A[(g + 1) & 1][q] = frag[((g + 1) * 2 + q) * 64 + lane];
+            for (int q = 0; q < 2; ++q) A[(g + FD) % NBUF][q] = frag[((g + FD) * 2 + q) * 64 + lane];
         }
         acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl, acc[m], 0, 0, 0);
         KEEP(acc[m], al);
         acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh, acc[m], 0, 0, 0);
         KEEP(acc[m], xl);
         pa = ah; pb = xh;
-        if (HARD && m == NM - 1 && g + 1 < NCH * NM) asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[m]) : "v"(pa), "v"(pb));
+        if (HARD && m == NM - 1 && g + 1 < NCH * NM) asm volatile(HAV_HARD_NOPS : "+v"(acc[m]) : "v"(pa), "v"(pb));
         __builtin_amdgcn_sched_barrier(0);
     }
-    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[NM - 1]) : "v"(pa), "v"(pb));
+    asm volatile(HAV_HARD_NOPS : "+v"(acc[NM - 1]) : "v"(pa), "v"(pb));
 }
 #undef KEEP
 
@@ -1515,6 +1547,17 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
 #endif
         RAY_FENCE();
         float* slot = CACHE ? a.ws + ((a.ablate & 1024) ? 0 : a.ws_slot * ((long long)blockIdx.x * MARCH_WAVES + wave)) : nullptr;   // 1024: timing experiment, all waves share one L2-resident slot
+        // coarse weights w[0..S_c) of the block's rays for the inverse CDF: with a workspace, one coalesced 128-byte row per sample
+        // in this wave's own slot; without, the ray's (not yet written) rgb_fine row.  Either way they are read back with L1-bypassing
+        // loads: rgb_fine rows of neighbouring rays share cache lines ACROSS waves, and an L1 line fetched by the neighbour before
+        // this wave's stores is never refreshed (the rare 16-rays-of-a-block differences of tools/stress_diag.py).
+        float* wrow = CACHE ? slot + (size_t)a.S_fp * ENTF : nullptr;
+#if HAV_BLOCK_FENCE
+        if (CACHE) {        // the slot is re-used block after block: everything the previous block did to it has landed, and no L1 line of it survives
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+#endif
         auto park = [&](int e, const f32x16 (&v)[4], float r0, float r1, float r2, float r3) {       // entry e of this block's slot
             float4* H2 = reinterpret_cast<float4*>(slot + (size_t)e * ENTF);
             if (FEATPARK) {
@@ -1656,7 +1699,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                 for (int u = 0; u < FQ; ++u) {
                     zq[u] = 0.f; eq[u] = 0;
                     if (produced < S) { zq[u] = next_entry(eq[u]); ++produced; }
-                    rq[u] = RAWp[(size_t)eq[u] * (ENTF / 4) + j];
+                    rq[u] = nt_load4(&RAWp[(size_t)eq[u] * (ENTF / 4) + j]);
                 }
                 float dist = 0.f;
                 for (int s0 = 0; s0 < S; s0 += FQ) {
@@ -1670,7 +1713,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                             // refill this slot with merged sample sidx + FQ (if any) before using its neighbour's depth
                             if (produced < S) {
                                 zq[u] = next_entry(eq[u]); ++produced;
-                                rq[u] = RAWp[(size_t)eq[u] * (ENTF / 4) + j];
+                                rq[u] = nt_load4(&RAWp[(size_t)eq[u] * (ENTF / 4) + j]);
                             }
                             if (sidx + 1 < S) dist = zq[(u + 1) % FQ] - zc;          // dists[-1] repeats dists[-2] (:36-37)
                             float sg = raw.w;
@@ -1706,7 +1749,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                 constexpr int NROW = FEATPARK ? 8 : 16;
                 for (int e = 0; e < S; ++e) {
                     const float4* H2 = reinterpret_cast<const float4*>(slot + (size_t)e * ENTF);
-                    const float wgt = slot[(size_t)e * ENTF + H2F + 128 + j];
+                    const float wgt = __builtin_nontemporal_load(&slot[(size_t)e * ENTF + H2F + 128 + j]);
 #pragma unroll
                     for (int q = 0; q < NROW; ++q) {
                         const float4 v = nt_load4(&H2[q * 64 + lane]);
@@ -1754,7 +1797,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                 dep = fmaf(wgt, z, dep);
                 accw += wgt;
                 wmax = fmaxf(wmax, wgt);
-                if (pass == 0 && S_fp > 0 && h == 0 && rayok) wpark[s] = wgt;
+                if (pass == 0 && S_fp > 0 && h == 0) { if (CACHE) wrow[s * 32 + j] = wgt; else if (rayok) wpark[s] = wgt; }
                 if (CACHE && pass == 0 && S_fp > 0 && !(s & 1)) park(s >> 1, acc2, hd0, hd1, hd2, hd3);
                 if (pass == 1 && a.dbg_zfine && h == 0 && rayok) a.dbg_zfine[gr * S_fp + s] = z;
                 // advance: dists[-1] repeats dists[-2] (:36-37)
@@ -1778,7 +1821,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
             if (pass == 0 && S_fp > 0) {
                 const int nw = S_c - 2, nb = S_c - 1;
                 float sum = 0.f;
-                for (int i = 0; i < nw; ++i) sum += (wpark[1 + i] + 1e-5f);
+                for (int i = 0; i < nw; ++i) sum += (__builtin_nontemporal_load(CACHE ? &wrow[(1 + i) * 32 + j] : &wpark[1 + i]) + 1e-5f);
                 float run = 0.f, cdf_lo = 0.f;
                 int k = 0;
                 auto u_of = [&](int kk) -> float {
@@ -1795,7 +1838,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                 float zi = z_coarse<RM>(a, gr, rkey, 0, near, far), zi1 = z_coarse<RM>(a, gr, rkey, 1, near, far);
                 float zi2 = z_coarse<RM>(a, gr, rkey, 2, near, far);
                 for (int i = 0; i < nw; ++i) {
-                    run += (wpark[1 + i] + 1e-5f) / sum;
+                    run += (__builtin_nontemporal_load(CACHE ? &wrow[(1 + i) * 32 + j] : &wpark[1 + i]) + 1e-5f) / sum;
                     const float cdf_hi = run;
                     const float bl = 0.5f * (zi1 + zi), ba = 0.5f * (zi2 + zi1);
                     float dnm = cdf_hi - cdf_lo;
@@ -1876,7 +1919,8 @@ static int mlp_prec(const HavRenderParams* p) { return p->mlp_mode == HAV_MLP_F3
 static long long fine_cache_slot_floats(const HavRenderParams* p)
 {
     const long long S_fp = (p->S_c + 1) / 2 + p->S_f;
-    return S_fp * ((mlp_prec(p) == 2 ? WS_H2_FLOATS / 2 : WS_H2_FLOATS) + 128 + 32);      // features (fp16 mode) or hidden units
+    return S_fp * ((mlp_prec(p) == 2 ? WS_H2_FLOATS / 2 : WS_H2_FLOATS) + 128 + 32)       // features (fp16 mode) or hidden units
+           + (long long)((p->S_c + 3) & ~3) * 32;                                                // + the coarse weights of the block, [S_c][32]
 }
 // Would a workspace be used at all?  Measured on MI355X: with stratified jitter on (the production setting)
 // skipping the repeated samples is worth 10-15 % of the kernel; with deterministic depths the coarse tiles are so coherent (all 32

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Which launches of the production kernel differ from the first one, in which output, at how many rays and by how much
+(diagnostic companion of tools/stress_production.py; HAVATAR_LIB selects the library build)."""
+import os, sys
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+from havatar_amd import synth
+from havatar_amd.render import RayMarcher
+dev = torch.device("cuda:0"); H = W = int(os.environ.get("SIZE", 512)); N = int(os.environ.get("LAUNCHES", 400))
+sc = synth.scene(8, 8, "primary")
+t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
+rays = t(synth.camera_rays(H, W))[None]; bg = torch.ones(1, H * W, 3, device=dev)
+rm = RayMarcher(sc["nerf_scale"], sc["nerf_trans"], sc["skin_scale"], sc["skin_trans"])
+rm.set_mlp(*[t(sc["mlp"][k]) for k in ("W1", "b1", "W2", "b2", "Wa", "ba", "Wf", "bf", "Wc", "bc")])
+rm.set_triplane(t(sc["planes"]))
+args = (rays, bg, t(sc["inv_T"]), t(sc["vol"]), 64, 16)
+names = ("rgb_c", "d_c", "a_c", "wmax", "rgb_f", "d_f", "a_f")
+for perturb in (True, False):
+    def go():
+        if rm.rng_counter is not None: rm.rng_counter.zero_()
+        return rm.render(*args, perturb=perturb, coarse_outputs=False)
+    ref = [o.clone() if o is not None else None for o in go()]
+    nbad = 0
+    for i in range(N):
+        out = go(); torch.cuda.synchronize()
+        for nm, a, b in zip(names, ref, out):
+            if a is None or torch.equal(a, b): continue
+            d = (a - b).abs().reshape(a.shape[1], -1).amax(1)
+            idx = torch.nonzero(d > 0).flatten()
+            nbad += 1
+            print("  launch %d %s: %d rays differ, max %.3e, rays %s (blocks %s lanes %s)" % (i, nm, idx.numel(), float(d.max()), idx[:8].tolist(),
+                  sorted(set((idx // 32).tolist()))[:6], sorted(set((idx % 32).tolist()))[:16]))
+    print(rm.variant(64, 16, perturb=perturb, coarse_outputs=False), ":", nbad, "differing outputs in", N, "launches")
