@@ -202,6 +202,9 @@ def main():
     ap.add_argument("--live-pmc", type=int, default=1, help="measure roofline.traffic in this run (2 rocprofv3 --pmc passes, ~1 min; N=1 only)")
     ap.add_argument("--workload", choices=["cfg2", "cfg3", "cfg4", "cfg5"], default="cfg2")
     ap.add_argument("--frames", type=int, default=64, help="cfg3: frames per batch (one step = one batch)")
+    ap.add_argument("--force-collective", type=int, default=0,
+                    help="cfg3 at N=1: create a 1-rank RCCL group and send every finished frame through the side-stream all_gather "
+                         "(the exchange step's HIP branch on one GPU)")
     ap.add_argument("--device", choices=["cuda", "cpu"], default="cuda")
     ap.add_argument("--size", type=int, default=512, help="frame edge in pixels (plumbing mode)")
     args = ap.parse_args()
@@ -240,8 +243,11 @@ def main():
     else:
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or (args.force_collective and args.workload == "cfg3"):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if cpu:
             dist.init_process_group("gloo")
         else:
@@ -289,7 +295,7 @@ def main():
         # one step = one batch of --frames frames: this rank renders frames rank, rank + N, ...; the finished RGB frame of round r is
         # all-gathered (RCCL over xGMI) while round r + 1 renders; every rank ends the step holding the whole batch
         from havatar_amd.frames import OverlappedFrameGather
-        gather = OverlappedFrameGather(args.frames, (3, H, W), device=dev)
+        gather = OverlappedFrameGather(args.frames, (3, H, W), device=dev, force_collective=bool(args.force_collective))
         batch_poses = {k: t(synth.frame_pose(k % 64))[None] for k in range(rank, args.frames, world)}
 
         def step(i):
@@ -356,7 +362,7 @@ def main():
                               "data": "synthetic", "config": {"workload": args.workload + " (CPU plumbing mode: PyTorch statement of the path, gloo)",
                                                                "frames_per_step": frames_per_step, "size": H,
                                                                "gathered": list(out.shape) if args.workload == "cfg3" else None}}))
-        if world > 1:
+        if dist.is_initialized():
             dist.destroy_process_group()
         return
 
@@ -481,6 +487,8 @@ def main():
                        "rays_per_frame": H * W, "num_coarse": S_C, "num_fine": S_F, "perturb": perturb, "hipgraph": bool(args.graph),
                        "parallelism": ("frames sharded, %d rank(s), one overlapped all_gather of finished frames per round" if args.workload == "cfg3"
                                        else "frames sharded, %d rank(s), no data-path collective") % world,
+                       "exchange": (("RCCL all_gather_into_tensor from a side stream, %d-rank group%s" % (world, " (forced at N = 1)" if world == 1 else ""))
+                                    if (args.workload == "cfg3" and gather.collective) else None),
                        "kernel": kname},
             "roofline": {"bound": "mfma", "busiest_unit": names.get(busiest), "unit_busy": busy,
                          "achieved": round(FLOP_PER_FRAME / (kern_ms * 1e-3) / 1e12, 3), "peak": peak / 1e12,
@@ -531,7 +539,7 @@ def main():
                                    "one_core": {"value": round(1.0 / est1, 6), "unit": "frames/s", "cores": 1,
                                                 "sample": "%d image row(s) (%d rays), 1 thread, %.1f s measured, scaled to a full frame" % (rows1, rows1 * W, took1)}}
         print(json.dumps(res))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -54,11 +54,14 @@ class OverlappedFrameGather:
     snapshot), and nothing on the host waits until `finalize()`.  3.1 MB per rank and round for a 512x512 RGB fp32 frame: on the xGMI
     full mesh every GPU pushes its frame down all 7 links at once (direct all-gather), ~20 us against >= 9 ms of rendering.
     On CPU tensors (gloo, the tests) the same calls run with `async_op=True` in gloo's worker thread.
-    With world_size 1 (or no process group) it only collects the frames."""
+    With world_size 1 (or no process group) it only collects the frames -- unless `force_collective` is set and a process group
+    exists: then a 1-rank group goes through the very same snapshot / side-stream / all_gather_into_tensor / stream-wait sequence
+    (how the HIP + RCCL branch is exercised on a single GPU: tests/test_frames_gpu.py, bench.py --workload cfg3 --force-collective 1)."""
 
-    def __init__(self, n_frames, frame_shape, dtype=torch.float32, device="cpu", group=None):
+    def __init__(self, n_frames, frame_shape, dtype=torch.float32, device="cpu", group=None, force_collective=False):
         self.group = group
         on = dist.is_available() and dist.is_initialized()
+        self.collective = on and (force_collective or dist.get_world_size(group) > 1)
         self.world = dist.get_world_size(group) if on else 1
         self.rank = dist.get_rank(group) if on else 0
         self.n_frames = n_frames
@@ -84,7 +87,7 @@ class OverlappedFrameGather:
             st.zero_()
         else:
             st.copy_(frame.reshape(st.shape), non_blocking=True)
-        if self.world == 1:
+        if not self.collective:
             self.out[r].copy_(st, non_blocking=True)
             return
         if self.side is not None:
