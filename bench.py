@@ -34,7 +34,8 @@ FLOP_PER_FRAME = FLOP_PER_QUERY * Q_PER_RAY * H * W     # 2.7848e12
 BYTES_PER_FRAME = 600 * H * W + 8388608 + 2097152 + 190992   # compulsory HBM bytes
 PEAK_FP32_MFMA = 157.3e12                               # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA = 2500e12                                # MI355X_MICROARCH.md: bf16 MFMA, dense
-DTYPE = {"half": "f32 (2 x fp16 split-operand MFMA, fp32 accumulate; fp32-sgemm-class results)",
+DTYPE = {"half": "f32 emulated as 2 x fp16 split-operand MFMA with fp32 accumulate: 22-bit operands (hi + lo fp16, lo.lo dropped), fp16 exponent range "
+                 "guarded on the device (bf16_split_mode = the >= 24-bit-operand mode, exact_f32_mode = true fp32 MFMA, both timed in this line)",
          "split": "f32 (3 x bf16 split-operand MFMA, fp32 accumulate; fp32-sgemm-class results)", "f32": "f32"}
 # matrix-core work the kernel actually executes per 32-sample tile: 11 k-chunks x 4 row tiles x 6 products of
 # v_mfma_f32_32x32x16_bf16 (32768 FLOP each), or 352 v_mfma_f32_32x32x2_f32 (4096 FLOP each) in the exact-fp32 mode
@@ -444,6 +445,19 @@ def main():
             f32_ms = timed(lambda: mf.render(rays, bg, poses[0], vol, S_C, S_F, perturb=perturb, coarse_outputs=False), 3)
         f32_variant = mf.last_variant
 
+    # the >= 24-bit-operand mode (3 x bf16 per operand, six exact products: HAV_MLP_SPLIT_BF16) beside the headline as well
+    bf16_ms = None
+    if rank == 0 and MODE == "half":
+        from havatar_amd import _lib
+        from havatar_amd.render import RayMarcher
+        mb = RayMarcher(m.nerf_scale, m.nerf_trans, m.skin_scale, m.skin_trans)
+        mb.mlp_mode = _lib.HAV_MLP_SPLIT_BF16
+        with torch.no_grad():
+            mb.set_mlp(*[t_.detach() for t_ in tr.model_coarse.mlp_tensors()])
+            mb.set_triplane(tr.model_coarse.triPlane_embeddings.detach())
+            bf16_ms = timed(lambda: mb.render(rays, bg, poses[0], vol, S_C, S_F, perturb=perturb, coarse_outputs=False), 5)
+        bf16_variant = mb.last_variant
+
     if rank == 0:
         kname = rm.variant(S_C, S_F, perturb=perturb, coarse_outputs=False)
         traffic = (live_pmc_traffic() if (args.live_pmc and world == 1) else None) or pmc_traffic(kname)
@@ -460,6 +474,17 @@ def main():
         # which unit is actually busiest (committed counters of this variant): the label the fraction below must be read with
         names = {"ta": "ta (texture addresser = the L1 gather path of the 8 tri-plane taps)", "mfma": "mfma", "valu": "valu"}
         busiest = max((k for k in ("ta", "mfma", "valu") if busy and k in busy), key=lambda k: busy[k], default=None)
+        # the unit that limits the kernel gets its own roofline: bytes the 8 tri-plane taps move into VGPRs per launch (128 x 16 B per lane
+        # and evaluated tile: the byte count is fixed by the algebra of DESIGN.md 3.3) against the texture path's 64 B/clk/CU
+        tap_bytes = 128 * 16 * 64 * tiles
+        kk, _, _src = committed_pmc(kname)
+        clk = (kk["GRBM_GUI_ACTIVE"] / 8.0 / (kern_ms * 1e-3)) if (kk and "GRBM_GUI_ACTIVE" in kk) else None       # effective shader clock
+        clk_used = clk if (clk and 1.0e9 < clk < 2.6e9) else 2.4e9
+        ta_peak = 64.0 * 256 * clk_used
+        ta_roof = {"what": "tri-plane tap bytes delivered to VGPRs per launch / (64 B/clk/CU x 256 CUs x clock)", "bytes_per_launch": tap_bytes,
+                   "achieved_TBps": round(tap_bytes / (kern_ms * 1e-3) / 1e12, 2), "peak_TBps": round(ta_peak / 1e12, 2),
+                   "clock_GHz": round(clk_used / 1e9, 3), "clock_source": ("GRBM_GUI_ACTIVE of the committed profile / this run's kernel time" if clk_used == clk else "2.4 GHz maximum clock (no usable profile)"),
+                   "frac": round(tap_bytes / (kern_ms * 1e-3) / ta_peak, 4), "busy": (busy or {}).get("ta")}
         cfg4_ms = None
         if args.workload == "cfg4":          # the upsampler alone (its own graph), HIP events around the replay
             with torch.no_grad():
@@ -490,7 +515,7 @@ def main():
                        "exchange": (("RCCL all_gather_into_tensor from a side stream, %d-rank group%s" % (world, " (forced at N = 1)" if world == 1 else ""))
                                     if (args.workload == "cfg3" and gather.collective) else None),
                        "kernel": kname},
-            "roofline": {"bound": "mfma", "busiest_unit": names.get(busiest), "unit_busy": busy,
+            "roofline": {"bound": "mfma", "limited_by": busiest, "busiest_unit": names.get(busiest), "unit_busy": busy, "ta": ta_roof,
                          "achieved": round(FLOP_PER_FRAME / (kern_ms * 1e-3) / 1e12, 3), "peak": peak / 1e12,
                          "unit": "TFLOP/s", "frac": round(FLOP_PER_FRAME / (kern_ms * 1e-3) / peak, 4),
                          "traffic": traffic["bytes"] if traffic else None, "traffic_detail": traffic,
@@ -500,9 +525,9 @@ def main():
                                  "achieved = ALGORITHMIC fp32 FLOP of the reference network (94848/query x 112 x 262144) / kernel time; peak = the "
                                  "dense peak of the matrix pipe the kernel runs on (16-bit MFMA 2.5 PFLOP/s in the split modes, where one fp32 "
                                  "product costs 3 (fp16) or 6 (bf16) 16-bit products; fp32 MFMA 157.3 TFLOP/s in exact mode).  The matrix cores "
-                                 "are NOT what limits the kernel: unit_busy (rocprofv3 counters of the committed profile) names the busiest "
-                                 "unit -- the texture addresser serving the tri-plane gather -- and mfma_executed_* counts what the matrix "
-                                 "cores really execute (SQ_INSTS_MFMA).  Against the fp32 MFMA peak the algorithmic number is "
+                                 "are NOT what limits the kernel: limited_by / unit_busy (rocprofv3 counters of the committed profile) name the busiest "
+                                 "unit -- the texture addresser serving the tri-plane gather, priced in roofline.ta -- and mfma_executed_* counts what "
+                                 "the matrix cores really execute (SQ_INSTS_MFMA).  Against the fp32 MFMA peak the algorithmic number is "
                                  "frac_of_fp32_mfma_peak (> 1: 52% of the reference's matrix work is removed by linearity, DESIGN.md 3.3, the "
                                  "fine pass re-uses the even coarse samples, 3.7, and the rest runs on the 16-bit pipe)",
                          "field_evaluations_per_ray": {"reference": Q_PER_RAY, "executed": q_exec},
@@ -519,6 +544,13 @@ def main():
                                      "roofline_frac_of_fp32_mfma_peak": round(FLOP_PER_FRAME / (f32_ms * 1e-3) / PEAK_FP32_MFMA, 4),
                                      "note": "HAVATAR_MLP=f32: v_mfma_f32_32x32x2_f32 (an fmaf chain per dot product) instead of the emulated-fp32 "
                                              "split; same frame; estimate = this run's step time with the march kernel time swapped"}
+        if bf16_ms is not None:
+            step_ms = 1e3 * dt / args.steps / (frames_per_step / world)
+            res["bf16_split_mode"] = {"kernel": bf16_variant, "kernel_ms": round(bf16_ms, 3),
+                                      "frames_per_s_est": round(1e3 / (step_ms - kern_ms + bf16_ms), 2),
+                                      "note": "HAVATAR_MLP=split: every operand = hi + mid + lo bf16 exactly (>= 24 significant bits), the six partial "
+                                              "products >= 2^-16 of the leading one; same frame; estimate = this run's step time with the march "
+                                              "kernel time swapped"}
         if not args.no_cpu_baseline:
             threads = os.cpu_count() or 1
             rows = args.cpu_rows or 4
@@ -533,6 +565,9 @@ def main():
                 rows1 = int(max(2, min(H, rows1 * 10.0 / max(took1, 1e-3))))
                 est1, took1 = cpu_baseline(sc, rows1, 1)
             res["cpu_baseline"] = {"value": round(1.0 / est, 5), "unit": "frames/s", "cores": threads, "kind": "port",
+                                   "scope": "the ray march only (P5-P12); the GPU step above also runs both tri-plane encoders (P3: 327 GFLOP of fp32 "
+                                            "convolutions per frame, 0.9 s on 8 host cores with PyTorch CPU: BASELINE.md section 2), so the whole-frame CPU "
+                                            "rate is lower than this figure",
                                    "cpu_model": cpu_model(),
                                    "sample": "%d of %d image rows (%d rays) of the same frame, oracle/hav_oracle.c with OpenMP, "
                                              "%.1f s measured, scaled to a full frame" % (rows, H, rows * W, took),

@@ -14,10 +14,31 @@ LIB = os.path.join(LIBDIR, "libhavatar_hip.so")
 SOURCES = ["hav_ops.hip", "hav_render.hip", "hav_train.hip", "hav_mlp_train.hip", "hav_conv.hip"]
 HEADERS = ["hav_common.h", os.path.join("..", "..", "include", "havatar.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
+BUILD_INFO = os.path.join(LIBDIR, "BUILD_INFO.json")
+# The split-operand MFMA sequences of hav_render.hip / hav_conv.hip lean on instruction placement the compiler does not model
+# (operand keep-alives, hand-placed wait states).  They were validated -- parity suite, full-occupancy determinism
+# stress (tools/stress_production.py, tools/stress_diag.py) -- with exactly this compiler; another one needs that validation again.
+TESTED_HIPCC = ("HIP version: 7.2.26015-fc0010cf6a",
+                "AMD clang version 22.0.0git (https://github.com/RadeonOpenCompute/llvm-project roc-7.2.0 26014 7b800a19466229b8479a78de19143dc33c3ab9b5)")
+
+
+def hipcc_version(hipcc):
+    out = subprocess.run([hipcc, "--version"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, check=False).stdout.decode(errors="replace")
+    return tuple(ln.strip() for ln in out.splitlines()[:2])
+
+
+def check_compiler(hipcc):
+    """Refuse (loudly) to build the hazard-sensitive kernels with an unvalidated compiler unless HAVATAR_ALLOW_UNTESTED_HIPCC=1."""
+    ver = hipcc_version(hipcc)
+    if ver != TESTED_HIPCC and os.environ.get("HAVATAR_ALLOW_UNTESTED_HIPCC", "0") != "1":
+        raise RuntimeError("hipcc differs from the compiler the MFMA hazard work-arounds of hav_render.hip were validated with:\n  found  %s\n  tested %s\n"
+                           "Re-run tools/stress_production.py and the -m gpu determinism tests on a GPU with the new build, then set "
+                           "HAVATAR_ALLOW_UNTESTED_HIPCC=1 (and update TESTED_HIPCC in havatar_amd/build.py)." % (ver, TESTED_HIPCC))
+    return ver
 
 
 def _stale():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(BUILD_INFO):
         return True
     t = os.path.getmtime(LIB)
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
@@ -31,6 +52,7 @@ def build(force=False, verbose=False):
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
     os.makedirs(LIBDIR, exist_ok=True)
+    ver = check_compiler(hipcc)
     objs = []
     procs = []
     for src in SOURCES:
@@ -46,6 +68,9 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode(errors="replace")))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     subprocess.check_call(cmd)
+    import json
+    with open(BUILD_INFO, "w") as f:          # travels with the .so: _lib.lib() reports it, tests/test_abi.py checks it
+        json.dump({"hipcc": list(ver), "tested": ver == TESTED_HIPCC, "flags": FLAGS, "sources": SOURCES}, f, indent=1)
     return LIB
 
 

@@ -593,7 +593,38 @@ struct LaneCtx {
     const float4* sB;                           // LDS copy of b1 | b2 (block kernel; the pair kernel reads them through the buffer path)
     __amdgpu_buffer_rsrc_t wrs;
     int lane, h, hoff;
+    int* lock;                                  // LDS word shared by the two waves of this wave's SIMD (mfma_lock); nullptr: no turn-taking
 };
+#ifndef HAV_MFMA_LOCK
+#define HAV_MFMA_LOCK 0
+#endif
+// Optional turn-taking of the two waves of a SIMD around every matrix-core sequence (an LDS spin lock per SIMD, index = the hardware
+// SIMD id of HW_REG_HW_ID; waves w and w + 4 of a 512-thread workgroup share one: tools/ubench/simd_map.hip).  Built to test whether the
+// rare run-to-run differences of DESIGN.md 3.5 come from the two waves' MFMAs interleaving in the shared pipe: on one MI355X 6000
+// launches per production variant came out bit-identical with it against 14 differing launches without -- on two other boxes the
+// differences persisted with the lock.  1-2 % of kernel time; off by default (-DHAV_MFMA_LOCK=1 builds it in).
+__device__ __forceinline__ void mfma_lock(const LaneCtx& L)
+{
+#if HAV_MFMA_LOCK
+    if (!L.lock) return;                        // (the ray-pair kernel: fp32 MFMA only, one sequence at a time per SIMD by construction)
+    int got;
+    do {
+        got = 1;
+        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) got = atomicCAS(L.lock, 0, 1);
+        got = __builtin_amdgcn_readfirstlane(got);
+        if (got) __builtin_amdgcn_s_sleep(2);
+    } while (got);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#endif
+}
+__device__ __forceinline__ void mfma_unlock(const LaneCtx& L)
+{
+#if HAV_MFMA_LOCK
+    if (!L.lock) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) atomicExch(L.lock, 0);
+#endif
+}
 
 #define LDB4(off_floats) __builtin_amdgcn_raw_buffer_load_b128(L.wrs, h * 16, (off_floats) * 4, 0)
 
@@ -740,11 +771,18 @@ __device__ __forceinline__ void split2h(float v0, float v1, uint32_t& ph, uint32
 // the feature projection of a parked tile inside the kernels that also composite the coarse outputs, ~0.4 % of the rays of a
 // full frame wrong in columns 16-31, run to run), the register the MFMA is still reading is free again.  HARD waits the matrix
 // instruction out (32 cycles) before the vector code of the next k-chunk may touch anything.
-#ifndef HAV_BLOCK_FENCE
-#define HAV_BLOCK_FENCE 1
+#ifndef HAV_SELF_NT
+#define HAV_SELF_NT 1       // reads of what the kernel wrote itself (parked head values, weights) bypass the L1
 #endif
-#ifndef HAV_BKEEP
-#define HAV_BKEEP 0
+#if HAV_SELF_NT
+#define HAV_SELF_LOAD(p) __builtin_nontemporal_load(p)
+#define HAV_SELF_LOAD4(p) nt_load4(p)
+#else
+#define HAV_SELF_LOAD(p) (*(p))
+#define HAV_SELF_LOAD4(p) (*(p))
+#endif
+#ifndef HAV_BLOCK_FENCE
+#define HAV_BLOCK_FENCE 0     // 1: drain + L1 invalidate at every block start (measured: -2.5 % speed, no robust effect on the rare event of DESIGN.md 3.5)
 #endif
 #ifndef HAV_HARD_NOPS
 #define HAV_HARD_NOPS "s_nop 15\n\ts_nop 15"
@@ -758,7 +796,6 @@ __device__ __forceinline__ void mfma_split2h(f32x16 (&acc)[NM], const uint4* fra
     constexpr int FD = HAV_FRAG_DIST, NBUF = FD + 1, NG = NCH * NM;
     uint4 A[NBUF][2];
     uint4 bh, bl;
-    uint4 obh = {0u, 0u, 0u, 0u}, obl = {0u, 0u, 0u, 0u};      // the previous chunk's B operands (HAV_BKEEP)
     f16x8_t pa, pb;
 #pragma unroll
     for (int d = 0; d < FD; ++d)
@@ -771,22 +808,8 @@ __device__ __forceinline__ void mfma_split2h(f32x16 (&acc)[NM], const uint4* fra
         if (m == 0) {
             float v[8];
             getv(ch, v);
-#if HAV_BKEEP
-            if (ch > 0) { obh = bh; obl = bl; }
-#endif
             split2h(v[0], v[1], bh.x, bl.x); split2h(v[2], v[3], bh.y, bl.y);
             split2h(v[4], v[5], bh.z, bl.z); split2h(v[6], v[7], bh.w, bl.w);
-#if HAV_BKEEP
-            // the registers that held the previous chunk's B operands stay allocated until this chunk's are complete: the new values
-            // (and the temporaries of their conversion) cannot land in a register an MFMA of the previous chunk may still be reading
-            if (ch > 0) {
-                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-                u32x4 nh = {bh.x, bh.y, bh.z, bh.w}, nl = {bl.x, bl.y, bl.z, bl.w};
-                const u32x4 oh = {obh.x, obh.y, obh.z, obh.w}, ol = {obl.x, obl.y, obl.z, obl.w};
-                asm volatile("" : "+v"(nh), "+v"(nl) : "v"(oh), "v"(ol));
-                bh = make_uint4(nh.x, nh.y, nh.z, nh.w); bl = make_uint4(nl.x, nl.y, nl.z, nl.w);
-            }
-#endif
         }
         const f16x8_t xh = __builtin_bit_cast(f16x8_t, bh), xl = __builtin_bit_cast(f16x8_t, bl);
         const f16x8_t ah = __builtin_bit_cast(f16x8_t, A[g % NBUF][0]), al = __builtin_bit_cast(f16x8_t, A[g % NBUF][1]);
@@ -987,6 +1010,7 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
         }
         __builtin_amdgcn_sched_barrier(0);
         TICK(3);
+        mfma_lock(L);
 
         if (PREC == 2) {
             mfma_split2h<3, 4>(acc1, L.sA1, lane, [&](int c, float (&v)[8]) {
@@ -1059,6 +1083,7 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
             }
         }
         relu_tiles<LEAN>(acc2);
+        mfma_unlock(L);
         TICK(5);
 
         __builtin_amdgcn_sched_barrier(0);
@@ -1175,7 +1200,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
     const int j = lane & 31, h = lane >> 5, col = lane & 15, rowt = (lane >> 4) & 1;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.blob), 0, BLOB_FLOATS * 4, 0x00020000);
     LaneCtx L;
-    L.sW1 = sW1; L.sW2 = sW2; L.sW4 = sW4; L.wrs = wrs; L.lane = lane; L.h = h; L.hoff = h * 16;
+    L.sW1 = sW1; L.sW2 = sW2; L.sW4 = sW4; L.wrs = wrs; L.lane = lane; L.h = h; L.hoff = h * 16; L.lock = nullptr;
 
     const int S_c = a.p.S_c, S_fp = a.S_fp;
     const long long NR = a.NR;
@@ -1507,6 +1532,17 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
     L.sB = reinterpret_cast<const float4*>(smem + WLDS);
     L.wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.blob), 0, BLOB_FLOATS * 4, 0x00020000);
     L.lane = lane; L.h = h; L.hoff = h * 16;
+    {   // one lock word per SIMD behind the per-wave scratch, indexed by the SIMD this wave really runs on (HW_REG_HW_ID bits 5:4)
+        int* locks = reinterpret_cast<int*>(smem + WLDS + 256 + MARCH_WAVES * a.scr_floats);
+#ifdef HAV_LOCK_BY_WAVE
+        const unsigned simd = wave & 3;
+#else
+        const unsigned simd = __builtin_amdgcn_readfirstlane((__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) >> 4) & 3u);
+#endif
+        L.lock = locks + simd;
+        if (tid < 4) locks[tid] = 0;
+        __syncthreads();
+    }
 
     const int S_c = a.p.S_c, S_f = a.p.S_f, S_fp = a.S_fp, S_half = (S_c + 1) >> 1;
     const int R = a.p.R;
@@ -1566,10 +1602,12 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) ft[m][r] = 0.f;
+                mfma_lock(L);
                 mfma_split2h<8, 2>(ft, L.sAF, lane, [&](int ch, float (&x)[8]) {
 #pragma unroll
                     for (int el = 0; el < 8; ++el) x[el] = v[ch >> 1][8 * (ch & 1) + el];
                 });
+                mfma_unlock(L);
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -1699,7 +1737,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                 for (int u = 0; u < FQ; ++u) {
                     zq[u] = 0.f; eq[u] = 0;
                     if (produced < S) { zq[u] = next_entry(eq[u]); ++produced; }
-                    rq[u] = nt_load4(&RAWp[(size_t)eq[u] * (ENTF / 4) + j]);
+                    rq[u] = HAV_SELF_LOAD4(&RAWp[(size_t)eq[u] * (ENTF / 4) + j]);
                 }
                 float dist = 0.f;
                 for (int s0 = 0; s0 < S; s0 += FQ) {
@@ -1713,7 +1751,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                             // refill this slot with merged sample sidx + FQ (if any) before using its neighbour's depth
                             if (produced < S) {
                                 zq[u] = next_entry(eq[u]); ++produced;
-                                rq[u] = nt_load4(&RAWp[(size_t)eq[u] * (ENTF / 4) + j]);
+                                rq[u] = HAV_SELF_LOAD4(&RAWp[(size_t)eq[u] * (ENTF / 4) + j]);
                             }
                             if (sidx + 1 < S) dist = zq[(u + 1) % FQ] - zc;          // dists[-1] repeats dists[-2] (:36-37)
                             float sg = raw.w;
@@ -1731,7 +1769,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                             dep = fmaf(wgt, zc, dep);
                             accw += wgt;
                             wmax = fmaxf(wmax, wgt);
-                            slot[(size_t)ec * ENTF + H2F + 128 + j] = wgt;       // both half-waves write the same value
+                            if (h == 0) slot[(size_t)ec * ENTF + H2F + 128 + j] = wgt;      // one writer per address
                             if (a.dbg_zfine && h == 0 && rayok) a.dbg_zfine[gr * S_fp + sidx] = zc;
                         }
                     }
@@ -1749,7 +1787,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                 constexpr int NROW = FEATPARK ? 8 : 16;
                 for (int e = 0; e < S; ++e) {
                     const float4* H2 = reinterpret_cast<const float4*>(slot + (size_t)e * ENTF);
-                    const float wgt = __builtin_nontemporal_load(&slot[(size_t)e * ENTF + H2F + 128 + j]);
+                    const float wgt = HAV_SELF_LOAD(&slot[(size_t)e * ENTF + H2F + 128 + j]);
 #pragma unroll
                     for (int q = 0; q < NROW; ++q) {
                         const float4 v = nt_load4(&H2[q * 64 + lane]);
@@ -1821,7 +1859,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
             if (pass == 0 && S_fp > 0) {
                 const int nw = S_c - 2, nb = S_c - 1;
                 float sum = 0.f;
-                for (int i = 0; i < nw; ++i) sum += (__builtin_nontemporal_load(CACHE ? &wrow[(1 + i) * 32 + j] : &wpark[1 + i]) + 1e-5f);
+                for (int i = 0; i < nw; ++i) sum += (HAV_SELF_LOAD(CACHE ? &wrow[(1 + i) * 32 + j] : &wpark[1 + i]) + 1e-5f);
                 float run = 0.f, cdf_lo = 0.f;
                 int k = 0;
                 auto u_of = [&](int kk) -> float {
@@ -1838,7 +1876,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                 float zi = z_coarse<RM>(a, gr, rkey, 0, near, far), zi1 = z_coarse<RM>(a, gr, rkey, 1, near, far);
                 float zi2 = z_coarse<RM>(a, gr, rkey, 2, near, far);
                 for (int i = 0; i < nw; ++i) {
-                    run += (__builtin_nontemporal_load(CACHE ? &wrow[(1 + i) * 32 + j] : &wpark[1 + i]) + 1e-5f) / sum;
+                    run += (HAV_SELF_LOAD(CACHE ? &wrow[(1 + i) * 32 + j] : &wpark[1 + i]) + 1e-5f) / sum;
                     const float cdf_hi = run;
                     const float bl = 0.5f * (zi1 + zi), ba = 0.5f * (zi2 + zi1);
                     float dnm = cdf_hi - cdf_lo;
@@ -2071,7 +2109,7 @@ extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, cons
     if (v.blk) {
         a.scr_floats = ((p->S_f > 0 ? p->S_f : 1) * 32 + 3) & ~3;
         auto lds_of = [&](int prec) {
-            return ((size_t)(prec == 2 ? LDSH_FLOATS : (prec == 1 ? LDS3_FLOATS : LDS_FLOATS)) + 256 + (size_t)MARCH_WAVES * a.scr_floats) * sizeof(float);
+            return ((size_t)(prec == 2 ? LDSH_FLOATS : (prec == 1 ? LDS3_FLOATS : LDS_FLOATS)) + 256 + (size_t)MARCH_WAVES * a.scr_floats + 4) * sizeof(float);
         };
         if (lds_of(v.prec) > 160 * 1024 || (v.guard && lds_of(1) > 160 * 1024)) return HAV_EUNSUP;
         const int gridb = march_grid_blocks(p);

@@ -70,6 +70,22 @@ def main():
     out["swgan_cks"] = np.array([img.double().sum().item(), img.double().abs().sum().item(), img.double().abs().max().item()])
     path = os.path.join(REPO, "tests", "golden", "modules.npz")
     np.savez_compressed(path, **out)
+    # P15 at BASELINE configs[3] size: 512 -> 1024 (its own file, so that modules.npz keeps regenerating byte for byte)
+    g4 = SWGAN_unet(inp_size=512, inp_ch=64, out_ch=3, out_size=1024, style_dim=64, n_mlp=4, channel_multiplier=2)
+    g4.requires_grad_(False)
+    synth.fill_state_dict(g4, seed=2)
+    cond4 = torch.from_numpy(synth.normal((1, 64, 512, 512), 92, 0.5))
+    style4 = torch.from_numpy(synth.normal((1, 64), 93))
+    with torch.no_grad():
+        img4 = g4(styles=[style4], condition_img=cond4, randomize_noise=False)
+    out4 = {"swgan_keys": np.array(sorted(g4.state_dict().keys())),
+            "swgan_slice": img4[:, :, ::32, ::32].numpy(),                      # the whole frame at stride 32
+            "swgan_patch": img4[:, :, 496:528, 496:528].numpy(),                # a dense 32 x 32 patch across the image centre
+            "swgan_edge": img4[:, :, :8, -8:].numpy(),                          # a corner (padding paths of the FIR / convolutions)
+            "swgan_cks": np.array([img4.double().sum().item(), img4.double().abs().sum().item(), img4.double().abs().max().item()])}
+    path4 = os.path.join(REPO, "tests", "golden", "modules_cfg4.npz")
+    np.savez_compressed(path4, **out4)
+    print("modules_cfg4.npz", os.path.getsize(path4) // 1024, "KiB", "swgan 512->1024 |max| %.3f" % out4["swgan_cks"][2])
     print("modules.npz", os.path.getsize(path) // 1024, "KiB", "planes |max| %.3f" % out["planes_cks"][2], "swgan |max| %.3f" % out["swgan_cks"][2],
           "acc_fine", out["fwd_acc_fine"].min(), out["fwd_acc_fine"].max())
 

@@ -99,3 +99,29 @@ def test_cpu_tensors_are_refused_by_native_modules():
         fused.fused_bias_act(x, x.new_empty(0), x.new_empty(0), 3, 0, 0.2, 1.0)
     with pytest.raises(RuntimeError):
         upfirdn2d.upfirdn2d(x.reshape(2, 4, 4, 1), torch.ones(2, 2), 1, 1, 1, 1, 0, 0, 0, 0)
+
+
+def test_build_info_records_the_validated_compiler():
+    """havatar_amd/build.py writes the hipcc identity next to the library and refuses an unvalidated compiler (the
+    split-MFMA sequences rely on instruction placement the compiler does not model)."""
+    import json
+    from havatar_amd import build as hb
+    hb.build()
+    assert os.path.exists(hb.BUILD_INFO), "python -m havatar_amd.build writes lib/BUILD_INFO.json"
+    info = json.load(open(hb.BUILD_INFO))
+    assert tuple(info["hipcc"]) == hb.TESTED_HIPCC and info["tested"] is True
+    # an unknown compiler is refused unless explicitly allowed
+    import pytest as _pt
+    fake = os.path.join(os.path.dirname(hb.BUILD_INFO), "_fake_hipcc.sh")
+    with open(fake, "w") as f:
+        f.write("#!/bin/sh\necho 'HIP version: 9.9.0'\necho 'AMD clang version 99'\n")
+    os.chmod(fake, 0o755)
+    try:
+        os.environ.pop("HAVATAR_ALLOW_UNTESTED_HIPCC", None)
+        with _pt.raises(RuntimeError, match="differs from the compiler"):
+            hb.check_compiler(fake)
+        os.environ["HAVATAR_ALLOW_UNTESTED_HIPCC"] = "1"
+        assert hb.check_compiler(fake)[0] == "HIP version: 9.9.0"
+    finally:
+        os.environ.pop("HAVATAR_ALLOW_UNTESTED_HIPCC", None)
+        os.remove(fake)

@@ -177,6 +177,33 @@ def test_swgan_unet_hip_matches_reference(gold):
 
 
 @pytest.mark.gpu
+def test_swgan_unet_cfg4_size_hip_matches_reference(golden_dir):
+    """BASELINE configs[3] size against the REFERENCE: SWGAN_unet 512 -> 1024 (model/styleUnet.py:1323-1410) run by
+    oracle/gen_golden_modules.py on the CPU with key-derived weights; the HIP inference route (split-fp16 convolution kernels, fused
+    block glue, Haar / upfirdn2d / fused_bias_act kernels) must reproduce its output: the whole frame at stride 32, a dense 32 x 32
+    patch across the image centre, a corner, and the frame's checksums."""
+    import os
+    from havatar_amd.model.styleUnet import SWGAN_unet
+    gold4 = np.load(os.path.join(golden_dir, "modules_cfg4.npz"))
+    g = SWGAN_unet(inp_size=512, inp_ch=64, out_ch=3, out_size=1024, style_dim=64, n_mlp=4, channel_multiplier=2)
+    g.requires_grad_(False)
+    synth.fill_state_dict(g, seed=2)
+    assert sorted(g.state_dict().keys()) == list(gold4["swgan_keys"])
+    g = g.cuda().eval()
+    cond = torch.from_numpy(synth.normal((1, 64, 512, 512), 92, 0.5)).cuda()
+    style = torch.from_numpy(synth.normal((1, 64), 93)).cuda()
+    with torch.no_grad():
+        img = g(styles=[style], condition_img=cond, randomize_noise=False)
+    scale = float(gold4["swgan_cks"][2])
+    tol = 2e-3 * scale                                           # the bar of the 128 -> 512 vector (22-bit-operand convolutions, ~20 layers deep)
+    assert linf(img[:, :, ::32, ::32].cpu().numpy(), gold4["swgan_slice"]) <= tol
+    assert linf(img[:, :, 496:528, 496:528].cpu().numpy(), gold4["swgan_patch"]) <= tol
+    assert linf(img[:, :, :8, -8:].cpu().numpy(), gold4["swgan_edge"]) <= tol
+    cks = np.array([img.double().sum().item(), img.double().abs().sum().item(), img.double().abs().max().item()])
+    assert abs(cks[1] - gold4["swgan_cks"][1]) <= 1e-4 * gold4["swgan_cks"][1] and abs(cks[2] - scale) <= tol
+
+
+@pytest.mark.gpu
 def test_stage_two_cfg4_size_fused_path_equals_aten_path():
     """BASELINE config 4 size (SWGAN_unet 512 -> 1024, the [1,64,512,512] bias-act and [64,513,513] blur shapes): the inference
     route (hav_style_demod / hav_styled_epilogue / direct upfirdn2d) against the same module on its autograd route (the

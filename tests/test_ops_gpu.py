@@ -645,3 +645,51 @@ def test_demod_autograd_node_matches_the_aten_statement(B, Cin, Cout, k):
     ref.backward(gd.double())
     for name, got, r in (("d", d, ref), ("gs", sd.grad, s64.grad), ("gW", Wd.grad, W64.grad)):
         assert (got.double().cpu() - r.detach()).abs().max().item() <= 2e-5 * r.detach().abs().max().item() + 1e-12, name
+
+
+def test_native_install_registers_the_bare_module_names_the_reference_imports():
+    """`havatar_amd.native.install()` puts the ctypes-backed modules under the BARE names the reference's
+    model/op/*.py import (`import fused`, model/op/fused_act.py:20; `import upfirdn2d as upfirdn2d_op`, model/op/upfirdn2d.py:19).
+    The calls below are the reference's own, argument for argument: fused_act.py:69 (forward), :32-34 (backward), :52-54 (double
+    backward), upfirdn2d.py:123-125 (forward), :34-45 (backward: up / down swapped, gradient pads)."""
+    import importlib
+    import sys
+    from oracle import oracle
+    import havatar_amd.native
+    for name in ("fused", "upfirdn2d"):
+        sys.modules.pop(name, None)
+    mods = havatar_amd.native.install()
+    fused = importlib.import_module("fused")
+    upfirdn2d_op = importlib.import_module("upfirdn2d")
+    assert fused is mods[0] and upfirdn2d_op is mods[1] and fused is sys.modules["fused"]
+    negative_slope, scale = 0.2, S2
+    x, b = synth.normal((2, 6, 9, 7), 31), synth.normal((6,), 32)
+    input, bias = _t(x), _t(b)
+    empty = input.new_empty(0)
+    out = fused.fused_bias_act(input, bias, empty, 3, 0, negative_slope, scale)                          # fused_act.py:69
+    assert np.array_equal(out.cpu().numpy(), oracle.fused_bias_act(x, b, None, 3, 0, negative_slope, scale))
+    g = synth.normal(x.shape, 33)
+    grad_output = _t(g)
+    grad_input = fused.fused_bias_act(grad_output.contiguous(), empty, out, 3, 1, negative_slope, scale)  # fused_act.py:32-34
+    assert np.array_equal(grad_input.cpu().numpy(), oracle.fused_bias_act(g, None, out.cpu().numpy(), 3, 1, negative_slope, scale))
+    gg, gb = synth.normal(x.shape, 34), synth.normal((6,), 35)
+    gradgrad_out = fused.fused_bias_act(_t(gg).contiguous(), _t(gb), out, 3, 1, negative_slope, scale)   # fused_act.py:52-54
+    assert np.array_equal(gradgrad_out.cpu().numpy(), oracle.fused_bias_act(gg, gb, out.cpu().numpy(), 3, 1, negative_slope, scale))
+    # upfirdn2d: [major, in_h, in_w, minor] input, [kh, kw] kernel (upfirdn2d.py:104-125)
+    xi = synth.normal((6, 11, 13, 1), 36)
+    k = (np.outer([1, 3, 3, 1], [1, 3, 3, 1]) / 64.0).astype(np.float32)
+    up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1 = 2, 2, 1, 1, 2, 1, 2, 1
+    o = upfirdn2d_op.upfirdn2d(_t(xi), _t(k), up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1)     # upfirdn2d.py:123-125
+    oo = oracle.upfirdn2d(xi, k, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1)
+    assert o.shape == oo.shape and linf(o.cpu().numpy(), oo) <= 1e-6
+    # the backward call: gradient w.r.t. the input = upfirdn2d of grad_output with the flipped kernel, up / down swapped (:34-45)
+    in_h, in_w, kh, kw = 11, 13, 4, 4
+    out_h, out_w = oo.shape[1], oo.shape[2]
+    g_pad_x0, g_pad_y0 = kw - pad_x0 - 1, kh - pad_y0 - 1
+    g_pad_x1 = in_w * up_x - out_w * down_x + pad_x0 - up_x + 1
+    g_pad_y1 = in_h * up_y - out_h * down_y + pad_y0 - up_y + 1
+    go = synth.normal(oo.shape, 37)
+    grad_kernel = np.ascontiguousarray(k[::-1, ::-1])
+    gi = upfirdn2d_op.upfirdn2d(_t(go), _t(grad_kernel), down_x, down_y, up_x, up_y, g_pad_x0, g_pad_x1, g_pad_y0, g_pad_y1)
+    gio = oracle.upfirdn2d(go, grad_kernel, down_x, down_y, up_x, up_y, g_pad_x0, g_pad_x1, g_pad_y0, g_pad_y1)
+    assert gi.shape == (6, in_h, in_w, 1) and linf(gi.cpu().numpy(), gio) <= 1e-6
