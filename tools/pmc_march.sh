@@ -11,9 +11,9 @@ OUT=gpurun_out/pmc_$TAG; rm -rf $OUT; mkdir -p $OUT
 for pass in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" \
             "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU" \
             "SQ_WAIT_INST_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS GRBM_GUI_ACTIVE" \
-            "TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TA_BUFFER_READ_WAVEFRONTS_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum"; do
+            "TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum"; do
   n=$(echo $pass | tr ' ' '_' | cut -c1-40)
-  LAUNCHES=3 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/p_$n -o pmc -- python tools/march_once.py > $OUT/p_$n.log 2>&1
+  LAUNCHES=3 timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/p_$n -o pmc -- python tools/march_once.py > $OUT/p_$n.log 2>&1
 done
 python - "$OUT" <<'PY' | tee gpurun_out/pmc_$TAG.txt
 import csv, glob, os, sys
