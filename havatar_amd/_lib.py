@@ -109,13 +109,13 @@ def lib():
         fn.restype = i32
     L.hav_conv3x3_wgrad_scratch_bytes.argtypes = [i32] * 5
     L.hav_conv3x3_wgrad_scratch_bytes.restype = i64
-    L.hav_conv3x3_wgrad.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    L.hav_conv3x3_wgrad.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     L.hav_conv3x3_wgrad.restype = i32
     L.hav_gemm_packed_bytes.argtypes = [i32, i32]
     L.hav_gemm_packed_bytes.restype = i64
     L.hav_gemm_pack.argtypes = [vp, vp, i32, i32, f32, vp]
     L.hav_gemm_pack.restype = i32
-    L.hav_gemm_split.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    L.hav_gemm_split.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.hav_gemm_split.restype = i32
     L.hav_upconv_finish.argtypes = [vp] * 7 + [f32, f32, i32, i32, i32, i32, i32, i32, vp]
     L.hav_upconv_finish.restype = i32

@@ -84,6 +84,36 @@ extern "C" int hav_conv3x3_pack(void* blob, const float* w, int Cout, int Cin, f
     return 0;
 }
 
+// Range control of the fp16 split (all kernels below): e with 2^e * (max |x| * extra) in [512, 1024).  `words` = hav_absmax's 256
+// partial maxima (bit patterns of non-negative floats: unsigned order = float order), folded here by every wave itself; `extra` = a
+// bound on what multiplies x before the split (max |s| of the modulation; 1 otherwise).  The exponent is clamped so that 2^e and
+// 2^-e stay normal floats; a zero, subnormal, infinite or NaN maximum gives 0 (scale 1).
+__device__ __forceinline__ int amax_pow2(const unsigned int* words, int lane, float extra)
+{
+    static_assert(HAV_ABSMAX_WORDS == 256, "four partial maxima per lane");
+    const uint4 w4 = reinterpret_cast<const uint4*>(words)[lane];
+    unsigned int mb = w4.x > w4.y ? w4.x : w4.y;
+    mb = w4.z > mb ? w4.z : mb;
+    mb = w4.w > mb ? w4.w : mb;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const unsigned int t = (unsigned int)__shfl_xor((int)mb, o, 64); mb = t > mb ? t : mb; }
+    mb = __float_as_uint(__uint_as_float(mb) * extra);
+    const int be = (int)((mb >> 23) & 0xFFu);          // biased exponent of the bound
+    if (be < 1 || be > 254) return 0;
+    const int e = 9 - (be - 127);
+    return e > 100 ? 100 : (e < -100 ? -100 : e);
+}
+__device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned int)(127 + e) << 23); }
+// max |s[0..n)| over the wave (the modulation of one sample)
+__device__ __forceinline__ float wave_absmax(const float* s, int n, int lane)
+{
+    float m = 0.f;
+    for (int c = lane; c < n; c += 64) m = fmaxf(m, fabsf(s[c]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    return m;
+}
+
 struct ConvArgs {
     float* y; const float* x; const uint4* blob;
     float* partial;          // K-split: [ksplit][B,Cout,H,W] raw accumulators (already scaled back), reduced by conv3x3_finish_kernel
@@ -124,22 +154,11 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(ConvArgs a)
     const float* sb = HAS_S ? a.s + (int64_t)b * Cin : nullptr;
     float in_sc = 1.0f, out_sc = 1.0f / CV_WSHIFT;
     if (a.in_amax) {
-        // power of two that brings max |x| into [512, 1024): exponent arithmetic on the bit patterns (clamped so that both factors stay
-        // normal floats); zero, subnormal, infinite or NaN maxima leave the scale at 1
-        static_assert(HAV_ABSMAX_WORDS == 256, "four partial maxima per lane");
-        const uint4 w4 = reinterpret_cast<const uint4*>(a.in_amax)[lane];          // every wave folds the 256 partial maxima itself
-        unsigned int mb = w4.x > w4.y ? w4.x : w4.y;
-        mb = w4.z > mb ? w4.z : mb;
-        mb = w4.w > mb ? w4.w : mb;
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) { const unsigned int t = (unsigned int)__shfl_xor((int)mb, o, 64); mb = t > mb ? t : mb; }
-        const int be = (int)((mb >> 23) & 0xFFu);          // biased exponent of max |x|
-        if (be >= 1 && be <= 254) {
-            int e = 9 - (be - 127);
-            e = e > 100 ? 100 : (e < -100 ? -100 : e);
-            in_sc = __uint_as_float((unsigned int)(127 + e) << 23);
-            out_sc = __uint_as_float((unsigned int)(127 - e - 8) << 23);          // 2^-e / 2^8
-        }
+        // power of two that brings max |s x| into [512, 1024) (with a modulation: bounded by max |x| * max |s_b|, all Cin of this sample
+        // whatever the K-split chunk); exact, undone in the epilogue
+        const int e = amax_pow2(a.in_amax, lane, HAS_S ? wave_absmax(sb, Cin, lane) : 1.0f);
+        in_sc = pow2f(e);
+        out_sc = pow2f(-e - 8);          // 2^-e / CV_WSHIFT
     }
 
     // staging tasks of this thread: (pixel of the patch, channel pair) -> one hi dword + one lo dword
@@ -294,19 +313,9 @@ __global__ void __launch_bounds__(256, 1) conv3x3_il_kernel(ConvArgs a)
     const float* sb = HAS_S ? a.s + (int64_t)b * Cin : nullptr;
     float in_sc = 1.0f, out_sc = 1.0f / CV_WSHIFT;
     if (a.in_amax) {          // see conv3x3_split_kernel
-        const uint4 w4m = reinterpret_cast<const uint4*>(a.in_amax)[lane];
-        unsigned int mb = w4m.x > w4m.y ? w4m.x : w4m.y;
-        mb = w4m.z > mb ? w4m.z : mb;
-        mb = w4m.w > mb ? w4m.w : mb;
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) { const unsigned int t = (unsigned int)__shfl_xor((int)mb, o, 64); mb = t > mb ? t : mb; }
-        const int be = (int)((mb >> 23) & 0xFFu);
-        if (be >= 1 && be <= 254) {
-            int e = 9 - (be - 127);
-            e = e > 100 ? 100 : (e < -100 ? -100 : e);
-            in_sc = __uint_as_float((unsigned int)(127 + e) << 23);
-            out_sc = __uint_as_float((unsigned int)(127 - e - 8) << 23);
-        }
+        const int e = amax_pow2(a.in_amax, lane, HAS_S ? wave_absmax(sb, Cin, lane) : 1.0f);
+        in_sc = pow2f(e);
+        out_sc = pow2f(-e - 8);
     }
     // staging tasks (pixel of the patch, channel pair); padding / idle slots load a valid address and are zeroed by their factor
     int t_off[CV_TPT], t_lds[CV_TPT], t_cp[CV_TPT];
@@ -622,6 +631,7 @@ extern "C" int hav_gemm_pack(void* blob, const float* w, int M, int K, float wmu
 
 struct GemmArgs {
     float* y; const float* x; const uint4* blob; const float* s;
+    const unsigned int* in_amax;          // optional, as ConvArgs::in_amax: max |x| words -> power-of-two range control of s * x
     int B, M, K, N;
 };
 
@@ -638,6 +648,12 @@ __global__ void __launch_bounds__(256, 2) gemm_split_kernel(GemmArgs a)
     const int mt0 = blockIdx.y * 4 + wm * 2;          // this wave's two 32-row M tiles
     const float* xb = a.x + (int64_t)b * K * N + n0;
     const float* sb = HAS_S ? a.s + (int64_t)b * K : nullptr;
+    float in_sc = 1.0f, out_sc = 1.0f / CV_WSHIFT;
+    if (a.in_amax) {          // see conv3x3_split_kernel
+        const int e = amax_pow2(a.in_amax, lane, HAS_S ? wave_absmax(sb, K, lane) : 1.0f);
+        in_sc = pow2f(e);
+        out_sc = pow2f(-e - 8);
+    }
 
     // staging task q of this thread: pixel p = tid & 127, channel pair cp = (tid >> 7) + 2 q  (0..15)
     const int t_p = tid & (GM_NT - 1), t_c0 = tid >> 7;
@@ -649,14 +665,14 @@ __global__ void __launch_bounds__(256, 2) gemm_split_kernel(GemmArgs a)
             const int k = 2 * (t_c0 + 2 * q);
             v[q][0] = src[(int64_t)k * N];
             v[q][1] = src[(int64_t)(k + 1) * N];
-            if (HAS_S) { sc[q][0] = sb[GM_KC * cc + k]; sc[q][1] = sb[GM_KC * cc + k + 1]; }
+            if (HAS_S) { sc[q][0] = sb[GM_KC * cc + k] * in_sc; sc[q][1] = sb[GM_KC * cc + k + 1] * in_sc; }
         }
     };
     auto stash = [&](int buf, const float (&v)[GM_TPT][2], const float (&sc)[GM_TPT][2]) {
 #pragma unroll
         for (int q = 0; q < GM_TPT; ++q) {
             const int cp = t_c0 + 2 * q, g = cp >> 3, ci = cp & 7;
-            const fl2_t f = {HAS_S ? v[q][0] * sc[q][0] : v[q][0], HAS_S ? v[q][1] * sc[q][1] : v[q][1]};
+            const fl2_t f = {v[q][0] * (HAS_S ? sc[q][0] : in_sc), v[q][1] * (HAS_S ? sc[q][1] : in_sc)};
             const h2_t hi = __builtin_convertvector(f, h2_t);
             const h2_t lo = __builtin_convertvector(f - __builtin_convertvector(hi, fl2_t), h2_t);
             const int at = (g * GM_NT + t_p) * CV_REC + ci;
@@ -718,17 +734,18 @@ __global__ void __launch_bounds__(256, 2) gemm_split_kernel(GemmArgs a)
             const int row = 32 * (mt0 + mi) + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (row < a.M) {
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) yb[(int64_t)row * N + 64 * wn + 32 * ni + j] = acc[mi][ni][r] * (1.0f / CV_WSHIFT);
+                for (int ni = 0; ni < 2; ++ni) yb[(int64_t)row * N + 64 * wn + 32 * ni + j] = acc[mi][ni][r] * out_sc;
             }
         }
 }
 
-extern "C" int hav_gemm_split(float* y, const float* x, const void* packed, const float* s, int B, int M, int K, int N, void* stream)
+extern "C" int hav_gemm_split(float* y, const float* x, const void* packed, const float* s, const void* in_amax, int B, int M, int K, int N,
+                              void* stream)
 {
     if (!y || !x || !packed || B < 1 || M < 1 || K < GM_KC || N < GM_NT) return HAV_EINVAL;
     if ((K % GM_KC) || (N % GM_NT)) return HAV_EUNSUP;
     GemmArgs a;
-    a.y = y; a.x = x; a.blob = (const uint4*)packed; a.s = s; a.B = B; a.M = M; a.K = K; a.N = N;
+    a.y = y; a.x = x; a.blob = (const uint4*)packed; a.s = s; a.in_amax = (const unsigned int*)in_amax; a.B = B; a.M = M; a.K = K; a.N = N;
     const dim3 grid((unsigned)(N / GM_NT), (unsigned)((M + 127) / 128), (unsigned)B);
     if (s) hipLaunchKernelGGL(gemm_split_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(gemm_split_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
@@ -839,7 +856,7 @@ extern "C" int hav_upconv_finish(float* y, const float* col, const float* fir4x4
 #define WG_XI 52            // dwords per input channel in a row slot: 3 shifts x 16 (8 hi + 8 lo) + 4 pad (16 lanes -> 16 bank groups)
 #define WG_GO 20            // dwords per output channel in a g buffer: 8 hi + 8 lo + 4 pad
 struct WgradArgs {
-    float* partial; const float* g; const float* x; const unsigned int* g_amax;
+    float* partial; const float* g; const float* x; const unsigned int* g_amax; const unsigned int* x_amax;
     int B, Cin, Cout, H, W, strips;
 };
 
@@ -852,22 +869,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_kernel(WgradArgs a)
     const int i0 = blockIdx.x * 32, o0 = blockIdx.y * 64;
     const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
     const int sw = W / 16;          // strips per image
-    float g_sc = 1.0f, out_sc = 1.0f;
-    if (a.g_amax) {
-        const uint4 w4m = reinterpret_cast<const uint4*>(a.g_amax)[lane];
-        unsigned int mb = w4m.x > w4m.y ? w4m.x : w4m.y;
-        mb = w4m.z > mb ? w4m.z : mb;
-        mb = w4m.w > mb ? w4m.w : mb;
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) { const unsigned int t = (unsigned int)__shfl_xor((int)mb, o, 64); mb = t > mb ? t : mb; }
-        const int be = (int)((mb >> 23) & 0xFFu);
-        if (be >= 1 && be <= 254) {
-            int e = 9 - (be - 127);
-            e = e > 100 ? 100 : (e < -100 ? -100 : e);
-            g_sc = __uint_as_float((unsigned int)(127 + e) << 23);
-            out_sc = __uint_as_float((unsigned int)(127 - e) << 23);
-        }
-    }
+    // both operands are activations: each gets its own power of two (max |g|, max |x| -> [512, 1024)), undone together on the way out
+    const int eg = a.g_amax ? amax_pow2(a.g_amax, lane, 1.0f) : 0, ex = a.x_amax ? amax_pow2(a.x_amax, lane, 1.0f) : 0;
+    const float g_sc = pow2f(eg), x_sc = pow2f(ex);
+    const float out_g = pow2f(-eg), out_x = pow2f(-ex);          // applied one after the other: |eg + ex| may pass 127
     // staging roles.  g: thread = (o = tid >> 2, 4 pixels q4 = tid & 3): one float4.  x: thread = (i = tid >> 3, pixel pair p8 = tid & 7)
     const int g_o = tid >> 2, g_q = tid & 3;
     const int x_i = tid >> 3, x_p = tid & 7;
@@ -903,10 +908,12 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_kernel(WgradArgs a)
         float pa1 = __shfl_up(r.a1, 1, 64), na0 = __shfl_down(r.a0, 1, 64);
         if (x_p == 0) pa1 = r.el;
         if (x_p == 7) na0 = r.er;
+        const float a0 = r.a0 * x_sc, a1 = r.a1 * x_sc;
+        pa1 *= x_sc; na0 *= x_sc;
         uint32_t hi, lo;
-        split2(pa1, r.a0, hi, lo);  dst[0 * 16 + x_p] = hi; dst[0 * 16 + 8 + x_p] = lo;          // kx = 0: element j = x[x0 + j - 1]
-        split2(r.a0, r.a1, hi, lo); dst[1 * 16 + x_p] = hi; dst[1 * 16 + 8 + x_p] = lo;          // kx = 1
-        split2(r.a1, na0, hi, lo);  dst[2 * 16 + x_p] = hi; dst[2 * 16 + 8 + x_p] = lo;          // kx = 2: element j = x[x0 + j + 1]
+        split2(pa1, a0, hi, lo);  dst[0 * 16 + x_p] = hi; dst[0 * 16 + 8 + x_p] = lo;          // kx = 0: element j = x[x0 + j - 1]
+        split2(a0, a1, hi, lo); dst[1 * 16 + x_p] = hi; dst[1 * 16 + 8 + x_p] = lo;          // kx = 1
+        split2(a1, na0, hi, lo);  dst[2 * 16 + x_p] = hi; dst[2 * 16 + 8 + x_p] = lo;          // kx = 2: element j = x[x0 + j + 1]
     };
     auto fetch_g = [&](int b, int x0, int row) {
         return *reinterpret_cast<const float4*>(a.g + (((int64_t)b * Cout + o0 + g_o) * H + row) * W + x0 + 4 * g_q);
@@ -963,7 +970,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_kernel(WgradArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int o = o0 + 32 * mo + (r & 3) + 8 * (r >> 2) + 4 * h;
-                pp[((int64_t)t * Cout + o) * Cin + i0 + j] = acc[q][r] * out_sc;
+                pp[((int64_t)t * Cout + o) * Cin + i0 + j] = acc[q][r] * out_g * out_x;
             }
         }
     }
@@ -1000,13 +1007,13 @@ extern "C" int64_t hav_conv3x3_wgrad_scratch_bytes(int B, int Cin, int Cout, int
     if (B < 1 || Cin < 32 || Cout < 64 || H < 1 || W < 16 || (Cin % 32) || (Cout % 64) || (W % 16)) return 0;
     return (int64_t)wgrad_ksplit(B, Cin, Cout, H, W) * 9 * Cout * Cin * 4;
 }
-extern "C" int hav_conv3x3_wgrad(float* gw, const float* g, const float* x, void* scratch, const void* g_amax, int B, int Cin, int Cout, int H,
-                                 int W, void* stream)
+extern "C" int hav_conv3x3_wgrad(float* gw, const float* g, const float* x, void* scratch, const void* g_amax, const void* x_amax, int B, int Cin,
+                                 int Cout, int H, int W, void* stream)
 {
     if (!gw || !g || !x || !scratch || B < 1 || H < 1) return HAV_EINVAL;
     if (Cin < 32 || Cout < 64 || W < 16 || (Cin % 32) || (Cout % 64) || (W % 16)) return HAV_EUNSUP;
     WgradArgs a;
-    a.partial = (float*)scratch; a.g = g; a.x = x; a.g_amax = (const unsigned int*)g_amax;
+    a.partial = (float*)scratch; a.g = g; a.x = x; a.g_amax = (const unsigned int*)g_amax; a.x_amax = (const unsigned int*)x_amax;
     a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.strips = B * (W / 16);
     const int ks = wgrad_ksplit(B, Cin, Cout, H, W);
     hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3((unsigned)(Cin / 32), (unsigned)(Cout / 64), (unsigned)ks), dim3(256), 0, (hipStream_t)stream, a);

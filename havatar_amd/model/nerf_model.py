@@ -2,6 +2,7 @@
 (reference model/nerf_model.py:10-117).  On HIP tensors at inference only `set_conditional_embedding` (the encoders) runs
 here; gather + PE + MLP are inside the fused ray-march kernel.  `sample_pts_triplane_feat` / `forward` keep the PyTorch
 statement for CPU tensors and autograd.  Only enc_mode='split' (the Trainer's choice) is implemented."""
+import logging
 import os
 
 import torch
@@ -11,6 +12,8 @@ from .network.embedder import get_embedder
 from .styleUnet import StyleGAN_zxc
 from ..utils.sh_util import eval_sh
 from ..utils.util import create_UniformBoxWarp, sample_from_triplane_new
+
+_MLP_MODE_LOGGED = False
 
 
 class _SplitKLinear(torch.autograd.Function):
@@ -135,8 +138,16 @@ class ConditionalTriplaneNeRFModel_multiRender_split_view(nn.Module):
         nn.Linear statement (rocBLAS), which is what CPU tensors always take."""
         if (x.is_cuda and x.dtype == torch.float32 and x.ndim == 2 and x.shape[1] == 176 and self.sh_deg == 0 and x.shape[0] >= 1024
                 and torch.is_grad_enabled() and os.environ.get("HAVATAR_TRAIN_MLP", "bf16") == "bf16"):
-            from ..native.mlp_train import fused_mlp
-            return fused_mlp(x, self.mlp_tensors())
+            from ..native import mlp_train
+            ws = self.mlp_tensors()
+            if [tuple(w.shape) for w in ws] == mlp_train._SHAPES:          # other widths (rgb_feat_dim != 3, ...) keep the ATen statement
+                global _MLP_MODE_LOGGED
+                if not _MLP_MODE_LOGGED:
+                    _MLP_MODE_LOGGED = True
+                    logging.getLogger("havatar_amd").info(
+                        "radiance MLP under autograd: bf16-operand MFMA node (HAVATAR_TRAIN_MLP=bf16; parameter gradients in the 2e-2 "
+                        "class of fp32 nn.Linear) -- HAVATAR_TRAIN_MLP=torch keeps the reference's fp32 layers")
+                return mlp_train.fused_mlp(x, ws)
         for layer in self.layers_xyz:
             x = self.relu(_linear(layer, x))
         alpha = _linear(self.fc_alpha, x)

@@ -73,7 +73,14 @@ class Trainer(torch.nn.Module):
             # the reference's chunk loop (:66-71) only bounds activation memory.  HIP tensors under autograd take all rays of the call as ONE
             # chunk: half the launches of a cfg5 step (4096 rays per frame = two 2048-ray chunks in the reference) and kernels twice
             # the size; 288 GB of HBM hold the [n, 176] field inputs of 0.5 M queries many times over.  CPU tensors chunk as the reference.
-            chunk = rays.shape[1] if rays.is_cuda else opt.chunksize // rays.shape[0]
+            # Bounded all the same (a grad-enabled full image -- 512^2 rays x 112 samples x 176 floats = 20 GB before gradients -- must
+            # not be one piece on any device): at most HAVATAR_TRAIN_CHUNK_RAYS rays per chunk over the batch (default 32768 = eight cfg5
+            # steps' worth, ~2.6 GB of field inputs), never less than the reference's chunk
+            if rays.is_cuda:
+                cap = max(int(os.environ.get("HAVATAR_TRAIN_CHUNK_RAYS", "32768")), opt.chunksize)
+                chunk = min(rays.shape[1], max(cap // rays.shape[0], 1))
+            else:
+                chunk = opt.chunksize // rays.shape[0]
             rb = get_minibatches(rays, chunksize=chunk, dim=1)
             bg = get_minibatches(background_prior, chunksize=chunk, dim=1) if background_prior is not None else None
             pred = [self.predict_and_render_radiance(mode, r, None if bg is None else bg[i], inv_head_T=inv_head_T) for i, r in enumerate(rb)]

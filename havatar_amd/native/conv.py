@@ -17,6 +17,26 @@ def _p(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+def _c(t):
+    return None if t is None else t.contiguous()
+
+
+def _stream(device):
+    """the current stream OF `device` (not of the current device)"""
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _autoscale_default():
+    return os.environ.get("HAVATAR_CONV_AUTOSCALE", "1") != "0"
+
+
+def _absmax(t, st):
+    """HAV_ABSMAX_WORDS partial maxima of |t| (hav_absmax: one pass, no host round trip) for the kernels' power-of-two range control"""
+    words = torch.empty(256, dtype=torch.int32, device=t.device)
+    _lib.check(_lib.lib().hav_absmax(_p(words), _p(t), t.numel(), st), "hav_absmax")
+    return words
+
+
 def eligible(x, weight, stride=1, padding=1):
     """weight [Cout,Cin,3,3]; x [B,Cin,H,W] float32 on a HIP device."""
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and weight.dim() == 4):
@@ -34,18 +54,18 @@ def pack(weight, wmul=1.0):
     L = _lib.lib()
     blob = torch.empty(int(L.hav_conv3x3_packed_bytes(Cout, Cin)), dtype=torch.uint8, device=w.device)
     with torch.cuda.device(w.device):
-        _lib.check(L.hav_conv3x3_pack(_p(blob), _p(w), Cout, Cin, float(wmul), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
-                   "hav_conv3x3_pack")
+        _lib.check(L.hav_conv3x3_pack(_p(blob), _p(w), Cout, Cin, float(wmul), _stream(w.device)), "hav_conv3x3_pack")
     return blob
 
 
 def conv3x3(x, packed, Cout, s=None, d=None, noise=None, noise_weight=None, bias=None, slope=0.2, gain=2 ** 0.5, act=True, autoscale=None):
     """y = act(d * conv3x3(s * x, W) + noise_weight * noise + bias) * gain; see include/havatar.h for the exact order.
-    autoscale (default on; HAVATAR_CONV_AUTOSCALE=0 turns the default off): the input is brought into fp16's comfortable range by an
-    exact power-of-two scale found on the device (hav_absmax: one pass over x) and undone in the epilogue -- gradients (1e-6) keep
-    their low parts, activations of any size cannot overflow the fp16 split.  ~1 % of a frame."""
+    autoscale (default on; HAVATAR_CONV_AUTOSCALE=0 turns the default off): s * x is brought into fp16's comfortable range by an
+    exact power-of-two scale found on the device (hav_absmax: one pass over x; the kernel multiplies the maximum by max |s_b|) and
+    undone in the epilogue -- gradients (1e-6) keep their low parts, activations and modulations of any size cannot overflow the
+    fp16 split.  ~1 % of a frame."""
     if autoscale is None:
-        autoscale = os.environ.get("HAVATAR_CONV_AUTOSCALE", "1") != "0"
+        autoscale = _autoscale_default()
     x = x.contiguous()
     B, Cin, H, W = x.shape
     y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device)
@@ -56,17 +76,13 @@ def conv3x3(x, packed, Cout, s=None, d=None, noise=None, noise_weight=None, bias
             nb = 1
         elif noise.numel() != H * W:
             raise RuntimeError("conv3x3: noise must be [1,1,H,W] or [B,1,H,W]")
-    f = lambda t: None if t is None else t.contiguous()
-    s, d, bias = f(s), f(d), f(bias)
+    s, d, bias, noise_weight = _c(s), _c(d), _c(bias), _c(noise_weight)
     L = _lib.lib()
     need = int(L.hav_conv3x3_scratch_bytes(B, Cin, Cout, H, W))          # small maps: K-split slices, summed in a second pass
     scratch = torch.empty(need, dtype=torch.uint8, device=x.device) if need else None
-    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    amax = None
     with torch.cuda.device(x.device):
-        if autoscale:
-            amax = torch.empty(256, dtype=torch.int32, device=x.device)          # HAV_ABSMAX_WORDS partial maxima
-            _lib.check(L.hav_absmax(_p(amax), _p(x), x.numel(), st), "hav_absmax")
+        st = _stream(x.device)
+        amax = _absmax(x, st) if autoscale else None
         rc = L.hav_conv3x3_split(_p(y), _p(x), _p(packed), _p(s), _p(d), _p(noise), _p(noise_weight), _p(bias), float(slope),
                                  float(gain), int(bool(act)), nb, B, Cin, Cout, H, W, _p(scratch), _p(amax), st)
     _lib.check(rc, "hav_conv3x3_split")
@@ -81,18 +97,19 @@ def wgrad_eligible(g, x):
 
 
 def wgrad3x3(g, x):
-    """gw [Cout,Cin,3,3] = d/dW of conv2d(x, W, stride 1, padding 1) given g = dL/dy (hav_conv3x3_wgrad: split-fp16 MFMA, fp32-class)."""
+    """gw [Cout,Cin,3,3] = d/dW of conv2d(x, W, stride 1, padding 1) given g = dL/dy (hav_conv3x3_wgrad: split-fp16 MFMA, fp32-class;
+    both operands under the power-of-two range control: g is gradient-sized, x whatever the activations are)."""
     g, x = g.contiguous(), x.contiguous()
     B, Cout, H, W = g.shape
     Cin = x.shape[1]
     L = _lib.lib()
     gw = torch.empty(Cout, Cin, 3, 3, dtype=torch.float32, device=g.device)
     scratch = torch.empty(int(L.hav_conv3x3_wgrad_scratch_bytes(B, Cin, Cout, H, W)), dtype=torch.uint8, device=g.device)
-    amax = torch.empty(256, dtype=torch.int32, device=g.device)
-    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     with torch.cuda.device(g.device):
-        _lib.check(L.hav_absmax(_p(amax), _p(g), g.numel(), st), "hav_absmax")
-        _lib.check(L.hav_conv3x3_wgrad(_p(gw), _p(g), _p(x), _p(scratch), _p(amax), B, Cin, Cout, H, W, st), "hav_conv3x3_wgrad")
+        st = _stream(g.device)
+        g_amax, x_amax = _absmax(g, st), _absmax(x, st)
+        _lib.check(L.hav_conv3x3_wgrad(_p(gw), _p(g), _p(x), _p(scratch), _p(g_amax), _p(x_amax), B, Cin, Cout, H, W, st),
+                   "hav_conv3x3_wgrad")
     return gw
 
 
@@ -100,7 +117,11 @@ class _Conv3x3Split(torch.autograd.Function):
     """conv2d(x, w, stride 1, padding 1) for training: the forward runs on hav_conv3x3_split (split-fp16 MFMA, fp32-class results,
     ~2x MIOpen's fp32 Winograd on the encoder shapes), and so does the data gradient, which is the same kind of convolution with
     the transposed, flipped filters; the weight gradient runs on hav_conv3x3_wgrad (wgrad3x3 below; ATen's convolution_backward only
-    for shapes that kernel does not take, HAVATAR_CONV_WGRAD=0 forces it)."""
+    for shapes that kernel does not take, HAVATAR_CONV_WGRAD=0 forces it).
+    Double backward (create_graph=True: the R1 and path-length regularisers of stage two, reference utils/styleUnet_util.py:74,92):
+    the backward then runs under grad mode and states both gradients with ATen's differentiable convolution ops instead of the
+    kernels -- slower, but the second-order graph is complete.  The weight gradient is skipped inside
+    conv2d_gradfix.no_weight_gradients(), as the reference's Conv2d backward does (model/op/conv2d_gradfix.py:155)."""
 
     @staticmethod
     def forward(ctx, x, w):
@@ -109,9 +130,15 @@ class _Conv3x3Split(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        from ..model.op import conv2d_gradfix
         x, w = ctx.saved_tensors
+        need_x = ctx.needs_input_grad[0]
+        need_w = ctx.needs_input_grad[1] and not conv2d_gradfix.weight_gradients_disabled
+        if torch.is_grad_enabled():          # create_graph=True: differentiable statements of both gradients
+            gx = torch.nn.grad.conv2d_input(x.shape, w, g, stride=1, padding=1) if need_x else None
+            gw = torch.nn.grad.conv2d_weight(x, w.shape, g, stride=1, padding=1) if need_w else None
+            return gx, gw
         g = g.contiguous()
-        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         gx = None
         if need_x and os.environ.get("HAVATAR_CONV_BWD", "1") != "0":
             # dL/dx is itself a 3x3 / stride 1 / padding 1 convolution of g with the transposed, flipped filters: the same kernel
@@ -153,15 +180,17 @@ def pack_upconv(weight, wmul=1.0):
     L = _lib.lib()
     blob = torch.empty(int(L.hav_gemm_packed_bytes(Cout * 9, Cin)), dtype=torch.uint8, device=w.device)
     with torch.cuda.device(w.device):
-        _lib.check(L.hav_gemm_pack(_p(blob), _p(a), Cout * 9, Cin, float(wmul), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
-                   "hav_gemm_pack")
+        _lib.check(L.hav_gemm_pack(_p(blob), _p(a), Cout * 9, Cin, float(wmul), _stream(w.device)), "hav_gemm_pack")
     return blob
 
 
-def upconv3x3(x, packed, Cout, fir, s=None, d=None, noise=None, noise_weight=None, bias=None, slope=0.2, gain=2 ** 0.5, act=True):
+def upconv3x3(x, packed, Cout, fir, s=None, d=None, noise=None, noise_weight=None, bias=None, slope=0.2, gain=2 ** 0.5, act=True,
+              autoscale=None):
     """y [B,Cout,2H,2W] = act(d * blur(conv_transpose2d(s * x, W, stride 2)) + noise_weight * noise + bias) * gain: the up-sampling
     StyledConv (model/styleUnet.py:236-243,565-599) as hav_gemm_split + hav_upconv_finish.  fir: the blur's [4,4] kernel (with the
-    factor^2 gain folded in, as Blur holds it)."""
+    factor^2 gain folded in, as Blur holds it).  autoscale: as conv3x3 (range control of s * x before the fp16 split)."""
+    if autoscale is None:
+        autoscale = _autoscale_default()
     x = x.contiguous()
     B, Cin, H, W = x.shape
     col = torch.empty(B, Cout * 9, H * W, dtype=torch.float32, device=x.device)
@@ -176,11 +205,12 @@ def upconv3x3(x, packed, Cout, fir, s=None, d=None, noise=None, noise_weight=Non
     fir = fir.contiguous()
     if tuple(fir.shape) != (4, 4) or fir.dtype != torch.float32:
         raise RuntimeError("upconv3x3: a [4,4] float32 FIR kernel is required")
+    s, d, bias, noise_weight = _c(s), _c(d), _c(bias), _c(noise_weight)
     L = _lib.lib()
-    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     with torch.cuda.device(x.device):
-        _lib.check(L.hav_gemm_split(_p(col), _p(x), _p(packed), _p(s.contiguous() if s is not None else None), B, Cout * 9, Cin, H * W, st),
-                   "hav_gemm_split")
+        st = _stream(x.device)
+        amax = _absmax(x, st) if autoscale else None
+        _lib.check(L.hav_gemm_split(_p(col), _p(x), _p(packed), _p(s), _p(amax), B, Cout * 9, Cin, H * W, st), "hav_gemm_split")
         _lib.check(L.hav_upconv_finish(_p(y), _p(col), _p(fir), _p(d), _p(noise), _p(noise_weight), _p(bias), float(slope), float(gain),
                                        int(bool(act)), nb, B, Cout, H, W, st), "hav_upconv_finish")
     return y

@@ -4,6 +4,7 @@ import ctypes as C
 
 import torch
 from torch.autograd import Function
+from torch.autograd.function import once_differentiable
 
 from .. import _lib
 
@@ -37,6 +38,7 @@ class TriplaneGather(Function):
         return feat
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dfeat):
         q, planes_cl = ctx.saved_tensors
         P, B, H, W, Cc = planes_cl.shape

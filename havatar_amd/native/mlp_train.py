@@ -9,6 +9,7 @@ import ctypes as C
 
 import torch
 from torch.autograd import Function
+from torch.autograd.function import once_differentiable
 
 from .. import _lib
 
@@ -21,10 +22,19 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# (W1,b1,W2,b2,Wa,ba,Wf,bf,Wc,bc) of the radiance MLP the kernels are written for (reference model/nerf_model.py:77-117 with 2C + 48 = 176
+# inputs, 128-wide hidden layers, a 64-wide feature layer and sh_deg 0: rgb 3)
+_SHAPES = [(128, 176), (128,), (128, 128), (128,), (1, 128), (1,), (64, 128), (64,), (3, 64), (3,)]
+
+
 def pack(weights):
     """Ten nn.Linear-layout fp32 tensors (W1,b1,W2,b2,Wa,ba,Wf,bf,Wc,bc) -> the bf16 fragment blob the kernels read."""
     L = _lib.lib()
     ws = [w.detach().contiguous() for w in weights]
+    got = [tuple(w.shape) for w in ws]
+    if got != _SHAPES or any(w.dtype != torch.float32 or not w.is_cuda for w in ws):
+        # the kernels hard-code these sizes and take raw pointers: refuse anything else (rgb_feat_dim != 3, other hidden widths, sh_deg > 0)
+        raise RuntimeError("mlp_train.pack: float32 HIP tensors of shapes %s required, got %s" % (_SHAPES, got))
     blob = torch.empty(int(L.hav_mlp_train_blob_bytes()), dtype=torch.uint8, device=ws[0].device)
     hw = _lib.HavMlpWeights(*[w.data_ptr() for w in ws])
     with torch.cuda.device(ws[0].device):
@@ -66,6 +76,7 @@ class FusedMlp(Function):
         return forward_only(X, blob)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, d_rf):
         X, blob = ctx.saved_tensors
         dX, grads = backward_only(X, d_rf.contiguous(), blob, ctx.shapes, need_dx=ctx.needs_input_grad[0])

@@ -5,6 +5,7 @@ import ctypes as C
 
 import torch
 from torch.autograd import Function
+from torch.autograd.function import once_differentiable
 
 from .. import _lib
 
@@ -53,6 +54,7 @@ class FieldInputs(Function):
         return X
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dX):
         pts, inv_T, vol, planes_cl = ctx.saved_tensors
         p = _field_params(pts, planes_cl, vol, ctx.boxes)
@@ -98,6 +100,7 @@ class Composite(Function):
         return rgb, acc, w, depth
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, d_rgb, d_acc, d_w, d_depth):
         rf, z, rd, noise, bg = ctx.saved_tensors
         n, S, RW = rf.shape
@@ -131,6 +134,7 @@ class Upsample3d2x(Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g):
         N, Cc, D, H, W = ctx.shape
         g = g.contiguous()
@@ -160,12 +164,21 @@ class Demod(Function):
         with torch.cuda.device(s.device):
             _lib.check(_lib.lib().hav_demod_fwd(_p(d), _p(q), _p(s), _p(W), float(scale), float(eps), B, Cin, Cout, KK, _stream()), "hav_demod_fwd")
         ctx.save_for_backward(s, W, d, q)
-        ctx.scale = float(scale)
+        ctx.scale, ctx.eps = float(scale), float(eps)
         return d
 
     @staticmethod
     def backward(ctx, gd):
         s, W, d, q = ctx.saved_tensors
+        if torch.is_grad_enabled():
+            # create_graph=True (path-length regulariser through the generator, reference utils/styleUnet_util.py:92): restate the node
+            # with ATen under autograd so that the second-order graph exists
+            with torch.enable_grad():
+                wsq = (ctx.scale * W).pow(2).sum((2, 3)).t()
+                dd = torch.rsqrt(torch.matmul(s * s, wsq) + ctx.eps)
+                need = [t for t, n in zip((s, W), ctx.needs_input_grad[:2]) if n and t.requires_grad]
+                got = iter(torch.autograd.grad(dd, need, gd, create_graph=True) if need else ())
+            return tuple(next(got) if (n and t.requires_grad) else None for t, n in zip((s, W), ctx.needs_input_grad[:2])) + (None, None)
         B, Cin = s.shape
         Cout, KK = W.shape[0], W.shape[2] * W.shape[3]
         gs, gW, gq = torch.empty_like(s), torch.empty_like(W), torch.empty_like(q)

@@ -167,7 +167,7 @@ int hav_composite_bwd(float* d_rf, const float* d_rgb, const float* d_acc, const
  * x, y NCHW float32; s [B,Cin], d [B,Cout], noise [H*W] or [B,H*W] (noise_batched), noise_weight (device scalar), bias [Cout] are
  * all nullable; act != 0 applies leaky-ReLU(slope) * gain, act == 0 leaves the sum as is (gain ignored).
  * Arithmetic: implicit GEMM on v_mfma_f32_32x32x16_f16 with split operands (x and W as hi + lo fp16, three products, fp32
- * accumulation): fp32-class results (same reasoning and the same fp16 range limit as HAV_MLP_SPLIT_F16: |s x| < 65504).
+ * accumulation): fp32-class results; the fp16 range limit of the split (|s x| < 65504) is lifted by `in_amax` below.
  * `packed` = hav_conv3x3_pack(W [Cout,Cin,3,3], wmul), hav_conv3x3_packed_bytes(Cout, Cin) bytes; wmul is folded into the weights
  * (EqualConv2d / ModulatedConv2d scale 1/sqrt(9 Cin)).  Needs Cin % 16 == 0, Cout % 64 == 0, H % 4 == 0, W % 32 == 0
  * (HAV_EUNSUP otherwise: the caller keeps its MIOpen route).
@@ -180,31 +180,35 @@ int64_t hav_conv3x3_scratch_bytes(int B, int Cin, int Cout, int H, int W);
 int hav_conv3x3_split(float* y, const float* x, const void* packed, const float* s, const float* d, const float* noise,
                       const float* noise_weight, const float* bias, float slope, float gain, int act, int noise_batched, int B,
                       int Cin, int Cout, int H, int W, void* scratch, const void* in_amax, void* stream);
-/* Range control for inputs far from 1 (gradients): hav_absmax leaves HAV_ABSMAX_WORDS partial maxima of |x| (bit patterns of
+/* Range control for inputs far from 1 (gradients, 1e5-sized activations): hav_absmax leaves HAV_ABSMAX_WORDS partial maxima of |x| (bit patterns of
  * non-negative floats, one per slice of x; no atomics, nothing to initialise) in a caller buffer of HAV_ABSMAX_WORDS * 4 bytes,
  * 16-byte aligned; passed as `in_amax` (NULL: off) the convolution folds them and scales its input by the power of two that brings
- * the maximum to [512, 1024) before the fp16 split and scales the result back -- exact, no host round trip.  Without it inputs below
- * 2^-3 gradually lose the low part of the split to fp16 subnormals (absolute operand error 2^-25) and inputs below 6e-8 vanish. */
+ * max |x| * max_i |s[b,i]| (a bound on what is split; max |x| without a modulation) to [512, 1024) before the fp16 split and scales
+ * the result back -- exact, no host round trip, no overflow whatever the sizes of x and s.  Without it inputs below 2^-3 gradually
+ * lose the low part of the split to fp16 subnormals (absolute operand error 2^-25), inputs below 6e-8 vanish and |s x| >= 65504
+ * becomes Inf.  hav_gemm_split (`in_amax`) and both operands of hav_conv3x3_wgrad (`g_amax`, `x_amax`) take the same words. */
 #define HAV_ABSMAX_WORDS 256
 int hav_absmax(void* out_bits, const float* x, int64_t n, void* stream);
 
 /* Weight gradient of the same convolution (training): gw[o,i,ky,kx] = sum_{b,y,x} g[b,o,y,x] * x[b,i,y+ky-1,x+kx-1] on the split-fp16
  * matrix path (Cin % 32 == 0, Cout % 64 == 0, W % 16 == 0).  scratch: hav_conv3x3_wgrad_scratch_bytes() bytes (K-split partial sums);
- * g_amax: HAV_ABSMAX_WORDS words from hav_absmax(g) or NULL (range control of the gradient-sized operand). */
+ * g_amax, x_amax: HAV_ABSMAX_WORDS words from hav_absmax(g) / hav_absmax(x) or NULL (range control of either operand: g is
+ * gradient-sized, x may be anything). */
 int64_t hav_conv3x3_wgrad_scratch_bytes(int B, int Cin, int Cout, int H, int W);
 int hav_conv3x3_wgrad(float* gw /*[Cout,Cin,3,3]*/, const float* g /*[B,Cout,H,W]*/, const float* x /*[B,Cin,H,W]*/, void* scratch,
-                      const void* g_amax, int B, int Cin, int Cout, int H, int W, void* stream);
+                      const void* g_amax, const void* x_amax, int B, int Cin, int Cout, int H, int W, void* stream);
 /* The up-sampling StyledConv of the StyleGAN blocks (model/styleUnet.py:236-243: conv_transpose2d(x * s, W, stride 2) -> 4x4 FIR with
  * padding (1,1) -> demodulation -> noise -> bias -> leaky-ReLU) in two launches:
  *   hav_gemm_split     y[b, m, n] = sum_k A[m, k] * (s[b, k] * x[b, k, n])    split-fp16 matrix path, fp32-class (K % 32 == 0, N % 128 == 0;
- *                      A packed by hav_gemm_pack from a row-major [M, K] matrix with `wmul` folded in; s nullable)
+ *                      A packed by hav_gemm_pack from a row-major [M, K] matrix with `wmul` folded in; s nullable; in_amax: words of
+ *                      hav_absmax(x) or NULL, range control as in hav_conv3x3_split)
  *   hav_upconv_finish  col [B, Cout*9, H*W] (row 9 o + 3 ky + kx: the product above with A[9 o + t, i] = W[i, o, t]) -> y [B, Cout, 2H, 2W]:
  *                      stride-2 scatter, FIR (`fir4x4`: the 16 taps as upfirdn2d takes them) and the epilogue
  *                      act(d[b,o] * . + noise_weight * noise + bias[o]) * gain, every term nullable as in hav_conv3x3_split. */
 int64_t hav_gemm_packed_bytes(int M, int K);
 int hav_gemm_pack(void* packed, const float* w /*[M,K]*/, int M, int K, float wmul, void* stream);
-int hav_gemm_split(float* y /*[B,M,N]*/, const float* x /*[B,K,N]*/, const void* packed, const float* s /*[B,K] or NULL*/, int B, int M,
-                   int K, int N, void* stream);
+int hav_gemm_split(float* y /*[B,M,N]*/, const float* x /*[B,K,N]*/, const void* packed, const float* s /*[B,K] or NULL*/,
+                   const void* in_amax, int B, int M, int K, int N, void* stream);
 int hav_upconv_finish(float* y, const float* col, const float* fir4x4, const float* d, const float* noise, const float* noise_weight,
                       const float* bias, float slope, float gain, int act, int noise_batched, int B, int Cout, int H, int W,
                       void* stream);

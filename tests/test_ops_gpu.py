@@ -625,6 +625,52 @@ def test_conv3x3_wgrad_matches_fp64_autograd(B, Cin, Cout, H, W):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("xmag,smag", [(1e5, 100.0), (3e7, 900.0), (1e-6, 1e-3), (1.0, 1.0)])
+def test_split_fp16_convolutions_keep_fp32_class_results_at_any_operand_size(xmag, smag):
+    """Range control of the fp16 split (include/havatar.h `in_amax` / `g_amax` / `x_amax`): 1e5-sized activations under a modulation of
+    ~100 (|s x| far beyond fp16's 65504), and tiny ones, through all four split-fp16 convolution kernels -- conv3x3 (64 x 128 and the
+    interleaved 128 x 128 kernel), the up-sampling product (hav_gemm_split) and the weight gradient (both operands) -- must stay
+    finite and within the fp32 route's own error of the fp64 result.  The reference runs these layers in fp32
+    (model/styleUnet.py:165-297), which has no such limit."""
+    from havatar_amd.native import conv
+    from havatar_amd.model.styleUnet import make_kernel
+    g = torch.Generator(device=DEV).manual_seed(int(smag) + 5)
+    B, H = 2, 32
+    for Cin, Cout in ((64, 64), (128, 256)):          # Cout = 64: the plain kernel; 256: the interleaved one
+        x = xmag * torch.randn(B, Cin, H, H, device=DEV, generator=g)
+        w = torch.randn(Cout, Cin, 3, 3, device=DEV, generator=g)
+        scale = 1.0 / (Cin * 9) ** 0.5
+        s = smag * (1.0 + 0.3 * torch.randn(B, Cin, device=DEV, generator=g))
+        s[1] *= 0.01          # per-sample modulation sizes differ
+        d = (0.5 + torch.rand(B, Cout, device=DEV, generator=g)) / smag
+        # (a) 3x3 stride 1
+        y = conv.conv3x3(x, conv.pack(w, scale), Cout, s=s, d=d, act=False)
+        xs64 = x.double() * s.double().view(B, Cin, 1, 1)
+        t64 = torch.nn.functional.conv2d(xs64, w.double() * scale, padding=1) * d.double().view(B, Cout, 1, 1)
+        t32 = torch.nn.functional.conv2d(x * s.view(B, Cin, 1, 1), w * scale, padding=1) * d.view(B, Cout, 1, 1)
+        assert torch.isfinite(y).all()
+        for b in range(B):          # per sample: the small-modulation sample is judged at its own size
+            floor = (t32[b].double() - t64[b]).abs().max().item()
+            assert (y[b].double() - t64[b]).abs().max().item() <= 3 * floor + 2e-6 * t64[b].abs().max().item(), (Cin, Cout, b)
+        # (b) the up-sampling product + blur
+        fir = (make_kernel((1, 3, 3, 1)) * 4).to(DEV)
+        yu = conv.upconv3x3(x, conv.pack_upconv(w, scale), Cout, fir, s=s, d=d, act=False)
+        z = torch.nn.functional.conv_transpose2d(xs64, (w.double() * scale).transpose(0, 1), stride=2)
+        tu = torch.nn.functional.conv2d(torch.nn.functional.pad(z, (1, 1, 1, 1)), fir.double().flip(0, 1).view(1, 1, 4, 4).expand(Cout, 1, 4, 4),
+                                        groups=Cout) * d.double().view(B, Cout, 1, 1)
+        assert torch.isfinite(yu).all()
+        for b in range(B):
+            assert (yu[b].double() - tu[b]).abs().max().item() <= 4e-6 * tu[b].abs().max().item(), (Cin, Cout, b)
+        # (c) the weight gradient: x at activation size, g gradient-sized
+        go = (3e-7 / xmag) * torch.randn(B, Cout, H, H, device=DEV, generator=g)
+        gw = conv.wgrad3x3(go, x)
+        w64 = w.double().requires_grad_(True)
+        torch.nn.functional.conv2d(x.double(), w64, padding=1).backward(go.double())
+        assert torch.isfinite(gw).all()
+        assert (gw.double() - w64.grad).abs().max().item() <= 4e-6 * w64.grad.abs().max().item(), (Cin, Cout)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,Cin,Cout,k", [(1, 16, 24, 3), (2, 512, 512, 3), (2, 256, 12, 1)])
 def test_demod_autograd_node_matches_the_aten_statement(B, Cin, Cout, k):
     """hav_demod_fwd / _bwd (native/train_ops.py::demod) vs the ATen statement of ModulatedConv2d's demodulation factors and its
@@ -645,6 +691,54 @@ def test_demod_autograd_node_matches_the_aten_statement(B, Cin, Cout, k):
     ref.backward(gd.double())
     for name, got, r in (("d", d, ref), ("gs", sd.grad, s64.grad), ("gW", Wd.grad, W64.grad)):
         assert (got.double().cpu() - r.detach()).abs().max().item() <= 2e-5 * r.detach().abs().max().item() + 1e-12, name
+
+
+def test_fused_training_nodes_support_double_backward_and_no_weight_gradients():
+    """Stage two differentiates THROUGH a backward pass (create_graph=True: R1 on the discriminator and the path-length regulariser on
+    the generator, reference utils/styleUnet_util.py:74,92) and switches weight gradients off around it
+    (conv2d_gradfix.no_weight_gradients, model/op/conv2d_gradfix.py:24-30,155).  The HIP training nodes of the StyleGAN blocks
+    (native/conv.py::_Conv3x3Split, native/train_ops.py::Demod) must give the same second-order gradients as the ATen statement;
+    the field-side nodes are once-differentiable and must say so instead of cutting the graph."""
+    from havatar_amd.native import conv
+    from havatar_amd.native.train_ops import demod, upsample3d_2x
+    from havatar_amd.model.op import conv2d_gradfix
+    g = torch.Generator(device=DEV).manual_seed(31)
+    B, Cin, Cout, H = 2, 32, 64, 32
+    x0 = torch.randn(B, Cin, H, H, device=DEV, generator=g)
+    w0 = torch.randn(Cout, Cin, 3, 3, device=DEV, generator=g) / (Cin * 9) ** 0.5
+    s0 = 1.0 + 0.3 * torch.randn(B, Cin, device=DEV, generator=g)
+    W0 = torch.randn(Cout, Cin, 3, 3, device=DEV, generator=g)
+    scale = 1.0 / (Cin * 9) ** 0.5
+
+    def penalty(conv_fn, demod_fn, dt):
+        x, w, s, W = (t.to(dt).clone().requires_grad_(True) for t in (x0, w0, s0, W0))
+        y = conv_fn(x * s.view(B, Cin, 1, 1), w) * demod_fn(s, W).view(B, Cout, 1, 1)
+        gx, gs = torch.autograd.grad(y.pow(2).sum(), (x, s), create_graph=True)          # first order, graph kept
+        (gx.pow(2).sum() + gs.pow(2).sum()).backward()                                       # second order
+        return [t.grad.double() for t in (x, w, s, W)]
+
+    aten_demod = lambda s, W: torch.rsqrt(torch.matmul(s * s, (scale * W).pow(2).sum((2, 3)).t()) + 1e-8)
+    want = penalty(lambda x, w: torch.nn.functional.conv2d(x, w, padding=1), aten_demod, torch.float64)
+    got = penalty(conv.conv3x3_autograd, lambda s, W: demod(s, W, scale, 1e-8), torch.float32)
+    for name, a, b in zip(("x", "w", "s", "W"), got, want):
+        assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item(), name
+
+    # no_weight_gradients(): the backward forms no weight gradient (and the data gradient is unchanged)
+    x, w = x0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+    y = conv.conv3x3_autograd(x, w)
+    with conv2d_gradfix.no_weight_gradients():
+        y.sum().backward(retain_graph=True)
+    assert w.grad is None and x.grad is not None
+    gx_only = x.grad.clone()
+    x.grad = None
+    y.sum().backward()
+    assert w.grad is not None and torch.equal(x.grad, gx_only)
+
+    # once-differentiable nodes refuse a double backward loudly
+    v = torch.randn(1, 2, 4, 4, 4, device=DEV, generator=g).requires_grad_(True)
+    gv, = torch.autograd.grad(upsample3d_2x(v).pow(2).sum(), v, create_graph=True)
+    with pytest.raises(RuntimeError, match="once_differentiable|differentiated twice|twice"):
+        gv.pow(2).sum().backward()
 
 
 def test_native_install_registers_the_bare_module_names_the_reference_imports():

@@ -70,7 +70,7 @@ for Cin, Cout, H in ((512, 512, 16), (512, 512, 32), (512, 256, 64), (256, 128, 
     col = torch.empty(1, Cout * 9, H * H, device=dev)
     y = torch.empty(1, Cout, 2 * H, 2 * H, device=dev)
     st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    g_ms = timed(lambda: L.hav_gemm_split(p(col), p(x), p(pk), p(s), 1, Cout * 9, Cin, H * H, st()))
+    g_ms = timed(lambda: L.hav_gemm_split(p(col), p(x), p(pk), p(s), None, 1, Cout * 9, Cin, H * H, st()))
     f_ms = timed(lambda: L.hav_upconv_finish(p(y), p(col), p(fir), p(d), None, None, None, 0.2, 2 ** 0.5, 1, 0, 1, Cout, H, H, st()))
     flop = 2.0 * 9 * Cout * Cin * H * H
     byt = 4.0 * (9 * Cout * H * H + 4 * Cout * H * H)
