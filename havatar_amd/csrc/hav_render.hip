@@ -17,9 +17,12 @@
 //    of layer l ARE the B operands of layer l+1 (lane = its query's column; register r of a 32-row tile holds rows
 //    (r&3)+8(r>>2)+4h, exactly the k-group an MFMA step consumes from the two half-waves), so activations never leave
 //    registers and never cross lanes between layers.  Only weights move: pre-permuted once into that k order ("fragment
-//    order", hav_mlp_pack) and LDS-resident.  Two arithmetic modes (HavRenderParams.mlp_mode):
-//      - split-operand bf16 (default): every fp32 operand = hi + mid + lo bf16 exactly, six partial products on
-//        v_mfma_f32_32x32x16_bf16 with fp32 accumulation (mfma_split3) -- fp32-sgemm-class results at 2.7x the matrix rate;
+//    order", hav_mlp_pack) and LDS-resident.  Three arithmetic modes (HavRenderParams.mlp_mode; PREC template parameter):
+//      - split-operand fp16 (HAV_MLP_SPLIT_F16, what Trainer / bench.py run): every fp32 operand = hi + lo fp16 (22 bits), three
+//        partial products on v_mfma_f32_32x32x16_f16 with fp32 accumulation (mfma_split2h); operands beyond fp16's range are
+//        caught by the range guard on the device, and the bf16 split renders the call instead (status HAV_STATUS_FP16_FALLBACK);
+//      - split-operand bf16 (HAV_MLP_SPLIT_BF16, mode 0 of the ABI and the guard's fallback): hi + mid + lo bf16 exactly, six
+//        partial products on v_mfma_f32_32x32x16_bf16 (mfma_split3) -- fp32-sgemm-class results over fp32's whole range;
 //      - exact fp32: v_mfma_f32_32x32x2_f32 (an fmaf chain).
 //  * Measured on gfx950 (tools/ubench): MFMA does not overlap with VALU work -- neither from the same wave nor from the other
 //    wave of the SIMD.  Kernel time = MFMA cycles + VALU issue cycles + unhidden tap latency, so the matrix work was cut
