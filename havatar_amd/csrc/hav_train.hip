@@ -10,6 +10,8 @@
 // Both are one wave per unit (query / ray) with lanes along channels or samples, so every plane row and every radiance-field row
 // is read and written coalesced; scatters are float atomics on rows (planes) or on single taps (volume).
 #include "hav_common.h"
+#include <stdlib.h>
+#include <string.h>
 
 #define PE_FREQS 8
 #define PE_DIM (6 * PE_FREQS)
@@ -51,7 +53,13 @@ __device__ __forceinline__ void plane_taps(float u, float v, int H, int W, int (
     w[0] = valid[0] ? wx0 * wy0 : 0.f; w[1] = valid[1] ? wx1 * wy0 : 0.f; w[2] = valid[2] ? wx0 * wy1 : 0.f; w[3] = valid[3] ? wx1 * wy1 : 0.f;
 }
 
-// MODE 0: X out.  MODE 1: dplanes / dvol scatter from dX.
+// MODE 0: X out.  MODE 1: dplanes / dvol scatter from dX, one row of float atomics per tap.  MODE 2 (C <= 64): the same scatter with
+// the taps of FI_RUN consecutive queries merged in registers first.  Queries arrive ray-major, sample-minor, so a wave that walks a run
+// of consecutive queries walks along a ray: in the plane the ray is (nearly) normal to, every sample lands on the same four texels; in
+// the other one consecutive bilinear cells share an edge.  Everything about a tap but its channel is wave-uniform (lane = channel), so
+// the texel ids live in SGPRs (readfirstlane), the match of old against new taps is scalar code with uniform branches, and a row of
+// atomics is only issued when a texel leaves the 2 x 2 window (or the run ends).  Sums are re-associated, not changed otherwise.
+#define FI_RUN 16
 template <int MODE>
 __global__ void __launch_bounds__(256) field_inputs_kernel(FieldArgs a)
 {
@@ -59,7 +67,15 @@ __global__ void __launch_bounds__(256) field_inputs_kernel(FieldArgs a)
     const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const int C = a.C, H = a.H, W = a.W, D = a.D, XW = 2 * C + PE_DIM;
     const size_t plane_sz = (size_t)a.B * H * W * C, vol_sz = (size_t)D * D * D;
-    for (int64_t i = wave0; i < a.n; i += nwaves) {
+    constexpr int RUN = MODE == 2 ? FI_RUN : 1;
+    const int64_t nruns = (a.n + RUN - 1) / RUN;
+    for (int64_t run = wave0; run < nruns; run += nwaves) {
+    // MODE 2: the window of each plane -- row ids (texel row of dplanes in units of C floats, -1 = empty) and this lane's pending sums
+    int wkey[2][4] = {{-1, -1, -1, -1}, {-1, -1, -1, -1}};
+    float wacc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    for (int qi = 0; qi < RUN; ++qi) {
+        const int64_t i = run * RUN + qi;
+        if (i >= a.n) break;
         const int b = (int)(i / a.n_per_b);
         const float px = a.pts[i * 3 + 0], py = a.pts[i * 3 + 1], pz = a.pts[i * 3 + 2];
         // ---- Deformation_Field_new: p_0 = p (identity), p_1 = (p + tau) M       (Skinning_Field.py:77-83)
@@ -92,19 +108,44 @@ __global__ void __launch_bounds__(256) field_inputs_kernel(FieldArgs a)
             int idx[4]; float w[4]; bool valid[4]; float wx0, wx1, wy0, wy1;
             plane_taps(p ? qz : qx, qy, H, W, idx, w, wx0, wx1, wy0, wy1, valid);
             const float* pl = a.planes + p * plane_sz + (size_t)b * H * W * C;
-            for (int c = lane; c < C; c += 64) {
+            // MODE 2 (C <= 64): exactly one trip for every lane (idle lanes take channel C - 1 with a zero gradient), so that the window
+            // bookkeeping below stays wave-uniform
+            for (int c0 = lane; MODE == 2 ? c0 == lane : c0 < C; c0 += 64) {
+                const int c = MODE == 2 ? min(c0, C - 1) : c0;
                 float t[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) t[k] = valid[k] ? pl[(size_t)idx[k] * C + c] : 0.f;
                 if (MODE == 0) {
                     a.X[i * XW + 2 * c + p] = ((t[0] * w[0] + t[1] * w[1]) + t[2] * w[2]) + t[3] * w[3];
                 } else {
-                    const float g = a.dX[i * XW + 2 * c + p];
-                    if (a.dplanes) {
+                    const float g = (MODE == 2 && lane >= C) ? 0.f : a.dX[i * XW + 2 * c + p];
+                    if (a.dplanes && MODE == 1) {
                         float* dpl = a.dplanes + p * plane_sz + (size_t)b * H * W * C;
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
                             if (valid[k]) atomicAdd(dpl + (size_t)idx[k] * C + c, w[k] * g);
+                    }
+                    if (a.dplanes && MODE == 2) {
+                        // new window: the four taps of this query; old sums move to the slot of the same texel or are flushed
+                        int nkey[4]; float nacc[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            nkey[k] = __builtin_amdgcn_readfirstlane(valid[k] ? b * H * W + idx[k] : -1);
+                            nacc[k] = w[k] * g;
+                        }
+                        float* dp0 = a.dplanes + p * plane_sz;
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) {
+                            const int ok = wkey[p][o];
+                            if (ok < 0) continue;
+                            if (ok == nkey[0]) nacc[0] += wacc[p][o];
+                            else if (ok == nkey[1]) nacc[1] += wacc[p][o];
+                            else if (ok == nkey[2]) nacc[2] += wacc[p][o];
+                            else if (ok == nkey[3]) nacc[3] += wacc[p][o];
+                            else if (lane < C) atomicAdd(dp0 + (size_t)ok * C + lane, wacc[p][o]);
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { wkey[p][k] = nkey[k]; wacc[p][k] = nacc[k]; }
                     }
                     const float ggx = g * ((t[1] - t[0]) * wy0 + (t[3] - t[2]) * wy1);
                     const float ggy = g * ((t[2] - t[0]) * wx0 + (t[3] - t[1]) * wx1);
@@ -134,6 +175,14 @@ __global__ void __launch_bounds__(256) field_inputs_kernel(FieldArgs a)
             const float dw = ((bone ? dh1 : dh0) - mix) / s;
             if (vin && tw * dw != 0.f) atomicAdd(a.dvol + vidx, tw * dw);   // clamped (border) coordinates: half the taps weigh 0
         }
+    }
+    if (MODE == 2 && a.dplanes) {          // end of the run: whatever is still in the windows
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+                if (wkey[p][o] >= 0 && lane < C) atomicAdd(a.dplanes + p * plane_sz + (size_t)wkey[p][o] * C + lane, wacc[p][o]);
+    }
     }
 }
 
@@ -182,7 +231,12 @@ extern "C" int hav_field_inputs_bwd(float* dplanes_cl, float* dvol, const float*
     if (p->n == 0) return 0;
     FieldArgs a = field_args(p, pts, inv_T, vol, planes_cl);
     a.dX = dX; a.dplanes = dplanes_cl; a.dvol = dvol;
-    hipLaunchKernelGGL(field_inputs_kernel<1>, dim3(field_blocks(p->n)), dim3(256), 0, (hipStream_t)stream, a);
+    // HAVATAR_FIELD_BWD=taps keeps the one-row-of-atomics-per-tap kernel (A/B runs); read once
+    static const bool per_tap = [] { const char* e = getenv("HAVATAR_FIELD_BWD"); return e && !strcmp(e, "taps"); }();
+    if (p->C <= 64 && !per_tap)
+        hipLaunchKernelGGL(field_inputs_kernel<2>, dim3(field_blocks((p->n + FI_RUN - 1) / FI_RUN)), dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(field_inputs_kernel<1>, dim3(field_blocks(p->n)), dim3(256), 0, (hipStream_t)stream, a);
     HAV_LAUNCH_CHECK();
     return 0;
 }
