@@ -126,6 +126,8 @@ def lib():
     L.hav_conv3x3_scratch_bytes.argtypes = [i32] * 5
     L.hav_conv3x3_scratch_bytes.restype = i64
     L.hav_conv3x3_split.argtypes = [vp] * 8 + [f32, f32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]
+    L.hav_conv3x3s2_split.argtypes = [vp] * 8 + [f32, f32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]
+    L.hav_conv3x3s2_split.restype = i32
     L.hav_absmax.argtypes = [vp, vp, i64, vp]
     L.hav_absmax.restype = i32
     L.hav_conv3x3_split.restype = i32

@@ -29,6 +29,7 @@
 // 18 fragments of a chunk in flight at once.  Global loads of chunk c+1 are issued before the MFMAs of chunk c, converted and written
 // to the other LDS buffer after them: one barrier per chunk.
 #include "hav_common.h"
+#include <atomic>
 
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
@@ -568,6 +569,172 @@ extern "C" int hav_conv3x3_split(float* y, const float* x, const void* packed, c
         hipLaunchKernelGGL(conv3x3_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, total);
         HAV_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Stride-2 3x3 convolution (the down-sampling ConvLayer / ConvBlock of the encoders: Blur -> EqualConv2d(stride 2, padding 0) ->
+// FusedLeakyReLU, model/styleUnet.py:326-368; MIOpen ran it as Im2d2Col + an fp32 GEMM) on the same split-fp16 path and the same packed
+// weights as the stride-1 kernel.  Workgroup = 64 (Cout) x [4 rows x 32 columns] of OUTPUT, so the chunk's input patch is 9 x 65
+// pixels; it is staged with even and odd columns apart ([row][column parity][column / 2]): tap (ky, kx) of output column j reads patch
+// column 2 j + kx = entry j + (kx >> 1) of parity kx & 1, i.e. consecutive lanes read consecutive 80-byte records as in the stride-1
+// kernel (records two apart would put 16 lanes on 8 bank groups).  Same MFMA work per output as stride 1, three times the staging.
+#define S2_PR (2 * CV_ROWS + 1)            // 9 patch rows
+#define S2_HC (CV_COLS + 1)                // 33 entries per (row, parity)
+#define S2_RECS (S2_PR * 2 * S2_HC)        // 594 records (9 of them -- odd column 65 -- never read)
+#define S2_TASKS (S2_RECS * 8)
+#define S2_TPT ((S2_TASKS + 255) / 256)    // 19
+struct ConvS2Args {
+    float* y; const float* x; const uint4* blob;
+    const unsigned int* in_amax;
+    const float* s; const float* d; const float* noise; const float* noise_weight; const float* bias;
+    float slope, gain;
+    int act, noise_batched;
+    int B, Cin, Cout, Hin, Win, Hout, Wout, pad;
+};
+
+template <bool HAS_S>
+__global__ void __launch_bounds__(256, 1) conv3x3s2_split_kernel(ConvS2Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s2_lds[];          // [2][S2_RECS * CV_REC]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int bw = a.Wout / CV_COLS;
+    const int px = blockIdx.x % bw, py = blockIdx.x / bw;
+    const int x0 = px * CV_COLS, y0 = py * CV_ROWS;          // output tile origin
+    const int mt = blockIdx.y * 2 + wm;
+    const int b = blockIdx.z;
+    const int Hin = a.Hin, Win = a.Win, Cin = a.Cin, NC = Cin / 16, MT = a.Cout / 32;
+    const int64_t HWin = (int64_t)Hin * Win;
+    const float* xb = a.x + (int64_t)b * Cin * HWin;
+    const float* sb = HAS_S ? a.s + (int64_t)b * Cin : nullptr;
+    float in_sc = 1.0f, out_sc = 1.0f / CV_WSHIFT;
+    if (a.in_amax) {          // see conv3x3_split_kernel
+        const int e = amax_pow2(a.in_amax, lane, HAS_S ? wave_absmax(sb, Cin, lane) : 1.0f);
+        in_sc = pow2f(e);
+        out_sc = pow2f(-e - 8);
+    }
+    // staging tasks: (record of the patch, channel pair)
+    int t_off[S2_TPT], t_lds[S2_TPT];
+    bool t_ok[S2_TPT];
+#pragma unroll
+    for (int q = 0; q < S2_TPT; ++q) {
+        const int task = tid + 256 * q;
+        const int cp = task / S2_RECS, rec = task - cp * S2_RECS;
+        const int prow = rec / (2 * S2_HC), rem = rec - prow * (2 * S2_HC);
+        const int par = rem / S2_HC, half = rem - par * S2_HC;
+        const int pcol = 2 * half + par;
+        const int gy = 2 * y0 + prow - a.pad, gx = 2 * x0 + pcol - a.pad;
+        t_ok[q] = task < S2_TASKS && pcol <= 2 * CV_COLS && gy >= 0 && gy < Hin && gx >= 0 && gx < Win;
+        t_off[q] = t_ok[q] ? (int)((2 * cp) * HWin + (int64_t)gy * Win + gx) : 0;
+        t_lds[q] = task < S2_TASKS ? rec * CV_REC + cp : -1;
+    }
+    float sv[S2_TPT][2];
+    auto fetch = [&](int cc, float (&v)[S2_TPT][2]) {
+        const float* src = xb + (int64_t)(16 * cc) * HWin;
+#pragma unroll
+        for (int q = 0; q < S2_TPT; ++q) {
+            v[q][0] = t_ok[q] ? src[t_off[q]] : 0.f;
+            v[q][1] = t_ok[q] ? src[t_off[q] + HWin] : 0.f;
+        }
+    };
+    auto stash = [&](int buf, int cc, const float (&v)[S2_TPT][2]) {
+        uint32_t* L = s2_lds + buf * (S2_RECS * CV_REC);
+#pragma unroll
+        for (int q = 0; q < S2_TPT; ++q) {
+            if (t_lds[q] < 0) continue;
+            float m0 = in_sc, m1 = in_sc;
+            if (HAS_S) {          // the chunk's 16 modulation factors: L1 hits, issued behind the matrix work
+                const int cp = (tid + 256 * q) / S2_RECS;
+                m0 *= sb[16 * cc + 2 * cp]; m1 *= sb[16 * cc + 2 * cp + 1];
+            }
+            const fl2_t f = {v[q][0] * m0, v[q][1] * m1};
+            const h2_t hi = __builtin_convertvector(f, h2_t);
+            const h2_t lo = __builtin_convertvector(f - __builtin_convertvector(hi, fl2_t), h2_t);
+            L[t_lds[q]] = __builtin_bit_cast(uint32_t, hi);
+            L[t_lds[q] + 8] = __builtin_bit_cast(uint32_t, lo);
+        }
+    };
+    f32x16 acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+
+    fetch(0, sv);
+    stash(0, 0, sv);
+    __syncthreads();
+    for (int cc = 0; cc < NC; ++cc) {
+        const int buf = cc & 1;
+        const uint4* ab = a.blob + ((int64_t)(cc * 9) * MT + mt) * 128 + lane;
+        uint4 A[9][2];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) { A[t][0] = ab[(int64_t)t * MT * 128]; A[t][1] = ab[(int64_t)t * MT * 128 + 64]; }
+        if (cc + 1 < NC) fetch(cc + 1, sv);
+        const uint32_t* L = s2_lds + buf * (S2_RECS * CV_REC);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ky = t / 3, kx = t - 3 * ky;
+            const f16x8_t ah = __builtin_bit_cast(f16x8_t, A[t][0]), al = __builtin_bit_cast(f16x8_t, A[t][1]);
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int rec = ((2 * (2 * wn + rr) + ky) * 2 + (kx & 1)) * S2_HC + j + (kx >> 1);
+                const uint4 bh = *reinterpret_cast<const uint4*>(L + rec * CV_REC + 4 * h);
+                const uint4 bl = *reinterpret_cast<const uint4*>(L + rec * CV_REC + 8 + 4 * h);
+                const f16x8_t xh = __builtin_bit_cast(f16x8_t, bh), xl = __builtin_bit_cast(f16x8_t, bl);
+                acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh, acc[rr], 0, 0, 0);
+                acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl, acc[rr], 0, 0, 0);
+                acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh, acc[rr], 0, 0, 0);
+            }
+        }
+        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]));          // operand registers are read after issue
+        if (cc + 1 < NC) stash(buf ^ 1, cc + 1, sv);
+        __syncthreads();
+    }
+    const int Ho = a.Hout, Wo = a.Wout;
+    const float nw = (a.noise && a.noise_weight) ? *a.noise_weight : 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int gy = y0 + 2 * wn + rr, gx = x0 + j;
+        const float nz = a.noise ? a.noise[(a.noise_batched ? (int64_t)b * Ho * Wo : 0) + (int64_t)gy * Wo + gx] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
+            float v = acc[rr][r] * out_sc;
+            if (a.d) v = v * a.d[(int64_t)b * a.Cout + co];
+            if (a.noise) v = v + nw * nz;
+            if (a.bias) v = v + a.bias[co];
+            if (a.act) v = (v > 0.f ? v : v * a.slope) * a.gain;
+            a.y[(((int64_t)b * a.Cout + co) * Ho + gy) * Wo + gx] = v;
+        }
+    }
+}
+
+extern "C" int hav_conv3x3s2_split(float* y, const float* x, const void* packed, const float* s, const float* d, const float* noise,
+                                   const float* noise_weight, const float* bias, float slope, float gain, int act, int noise_batched, int B,
+                                   int Cin, int Cout, int Hin, int Win, int pad, const void* in_amax, void* stream)
+{
+    if (!y || !x || !packed || B < 1 || Cin < 16 || Cout < 64 || Hin < 3 || Win < 3 || pad < 0 || pad > 1) return HAV_EINVAL;
+    const int Hout = (Hin + 2 * pad - 3) / 2 + 1, Wout = (Win + 2 * pad - 3) / 2 + 1;
+    if ((Cin % 16) || (Cout % 64) || (Hout % CV_ROWS) || (Wout % CV_COLS)) return HAV_EUNSUP;
+    if ((int64_t)Cin * Hin * Win > 0x7fffffffLL) return HAV_EUNSUP;          // 32-bit element offsets inside one sample
+    ConvS2Args a;
+    a.y = y; a.x = x; a.blob = (const uint4*)packed; a.in_amax = (const unsigned int*)in_amax;
+    a.s = s; a.d = d; a.noise = noise; a.noise_weight = noise_weight; a.bias = bias;
+    a.slope = slope; a.gain = gain; a.act = act; a.noise_batched = noise_batched;
+    a.B = B; a.Cin = Cin; a.Cout = Cout; a.Hin = Hin; a.Win = Win; a.Hout = Hout; a.Wout = Wout; a.pad = pad;
+    const size_t lds = 2 * (size_t)S2_RECS * CV_REC * sizeof(uint32_t);          // 95 KB: dynamic (above the 64 KB static limit)
+    static std::atomic<unsigned long long> attr_mask{0};          // per device: the attribute belongs to the device's copy of the kernel
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
+    if (!((attr_mask.load(std::memory_order_acquire) >> dev) & 1ull)) {
+        hipError_t e1 = hipFuncSetAttribute((const void*)conv3x3s2_split_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e2 = hipFuncSetAttribute((const void*)conv3x3s2_split_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e1 != hipSuccess || e2 != hipSuccess) return (int)(e1 != hipSuccess ? e1 : e2);
+        attr_mask.fetch_or(1ull << dev, std::memory_order_release);
+    }
+    const dim3 grid((unsigned)((Wout / CV_COLS) * (Hout / CV_ROWS)), (unsigned)(Cout / 64), (unsigned)B);
+    if (s) hipLaunchKernelGGL(conv3x3s2_split_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(conv3x3s2_split_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, a);
+    HAV_LAUNCH_CHECK();
     return 0;
 }
 

@@ -266,6 +266,22 @@ class ConvLayer(nn.Sequential):
 
     def forward(self, input):
         ec = self[0]
+        if (len(self) > 1 and isinstance(self[0], Blur) and isinstance(self[1], EqualConv2d) and input.is_cuda and input.dtype == torch.float32
+                and not torch.is_grad_enabled() and _fused_conv_enabled() and os.environ.get("HAVATAR_CONV_S2", "0") == "1"):
+            # HIP inference, down-sampling layer (opt-in): Blur (hav_upfirdn2d) -> EqualConv2d stride 2 + bias + leaky-ReLU as one kernel
+            # (hav_conv3x3s2_split) instead of MIOpen's Im2d2Col + fp32 GEMM + the activation launch.  Measured in the frame graph
+            # (profiles/r03_v2_frame_timeline_stride2.txt): 96.7 us per layer against ~80 us for the three launches it replaces -- the
+            # 9 x 65 patch costs three times the staging of the stride-1 kernel per MFMA -- so MIOpen stays the default
+            ec = self[1]
+            xb = self[0](input)
+            if xb.shape[-1] * xb.shape[-2] >= 1024 and _conv.s2_eligible(xb, ec.weight, ec.stride, ec.padding):
+                pk = ec._cached("w3x3", ec.weight, lambda: _conv.pack(ec.weight, ec.scale))
+                if len(self) > 2:
+                    return _conv.conv3x3s2(xb, pk, ec.weight.shape[0], ec.padding, bias=self[2].bias, slope=self[2].negative_slope,
+                                           gain=self[2].scale, act=True)
+                return _conv.conv3x3s2(xb, pk, ec.weight.shape[0], ec.padding, bias=ec.bias, act=False)
+            out = ec(xb)
+            return self[2](out) if len(self) > 2 else out
         if (isinstance(ec, EqualConv2d) and input.is_cuda and input.dtype == torch.float32 and not torch.is_grad_enabled()
                 and _fused_conv_enabled() and input.shape[-1] * input.shape[-2] >= 1024
                 and _conv.eligible(input, ec.weight, ec.stride, ec.padding)):

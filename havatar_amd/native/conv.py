@@ -89,6 +89,46 @@ def conv3x3(x, packed, Cout, s=None, d=None, noise=None, noise_weight=None, bias
     return y
 
 
+def s2_eligible(x, weight, stride=2, padding=0):
+    """weight [Cout,Cin,3,3]; x [B,Cin,Hin,Win] float32 on a HIP device: shapes hav_conv3x3s2_split takes."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and weight.dim() == 4):
+        return False
+    Cout, Cin, kh, kw = weight.shape
+    B, Ci, H, W = x.shape
+    if not (kh == 3 and kw == 3 and stride == 2 and padding in (0, 1) and Ci == Cin and Cin % 16 == 0 and Cout % 64 == 0):
+        return False
+    Ho, Wo = (H + 2 * padding - 3) // 2 + 1, (W + 2 * padding - 3) // 2 + 1
+    return H >= 3 and W >= 3 and Ho % 4 == 0 and Wo % 32 == 0 and Cin * H * W < 2 ** 31
+
+
+def conv3x3s2(x, packed, Cout, padding=0, s=None, d=None, noise=None, noise_weight=None, bias=None, slope=0.2, gain=2 ** 0.5, act=True,
+              autoscale=None):
+    """y = act(d * conv3x3(s * x, W, stride 2, padding) + noise_weight * noise + bias) * gain (hav_conv3x3s2_split; `packed` from pack()):
+    the down-sampling EqualConv2d of ConvLayer / ConvBlock (model/styleUnet.py:326-368) with bias + leaky-ReLU fused."""
+    if autoscale is None:
+        autoscale = _autoscale_default()
+    x = x.contiguous()
+    B, Cin, H, W = x.shape
+    Ho, Wo = (H + 2 * padding - 3) // 2 + 1, (W + 2 * padding - 3) // 2 + 1
+    y = torch.empty(B, Cout, Ho, Wo, dtype=torch.float32, device=x.device)
+    nb = 0
+    if noise is not None:
+        noise = noise.contiguous()
+        if noise.numel() == B * Ho * Wo and B > 1:
+            nb = 1
+        elif noise.numel() != Ho * Wo:
+            raise RuntimeError("conv3x3s2: noise must be [1,1,Hout,Wout] or [B,1,Hout,Wout]")
+    s, d, bias, noise_weight = _c(s), _c(d), _c(bias), _c(noise_weight)
+    L = _lib.lib()
+    with torch.cuda.device(x.device):
+        st = _stream(x.device)
+        amax = _absmax(x, st) if autoscale else None
+        rc = L.hav_conv3x3s2_split(_p(y), _p(x), _p(packed), _p(s), _p(d), _p(noise), _p(noise_weight), _p(bias), float(slope), float(gain),
+                                   int(bool(act)), nb, B, Cin, Cout, H, W, int(padding), _p(amax), st)
+    _lib.check(rc, "hav_conv3x3s2_split")
+    return y
+
+
 def wgrad_eligible(g, x):
     if not (g.is_cuda and g.dtype == torch.float32 and x.dtype == torch.float32 and g.dim() == 4 and x.dim() == 4):
         return False

@@ -536,6 +536,72 @@ def test_upconv3x3_matches_fp64_transposed_convolution_and_blur(B, Cin, Cout, H,
     assert (y0.double() - t0).abs().max().item() <= 2e-6 * t0.abs().max().item()
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W,pad", [(2, 64, 128, 257, 257, 0), (1, 512, 512, 65, 65, 0), (1, 128, 64, 64, 128, 1), (2, 32, 64, 9, 65, 0),
+                                                (1, 256, 256, 129, 129, 0)])
+def test_conv3x3_stride2_matches_fp64_and_the_layer_it_replaces(B, Cin, Cout, H, W, pad):
+    """hav_conv3x3s2_split (the down-sampling EqualConv2d of ConvLayer / ConvBlock after its Blur, reference model/styleUnet.py:326-368:
+    stride 2, padding 0 on the blurred (H+1)-sized map) against F.conv2d in fp64, with the fp32 ATen / MIOpen route it replaces as the
+    yardstick; all fused terms, odd input sizes, the zero-padded variant, run-to-run identical."""
+    from havatar_amd.native import conv
+    g = torch.Generator(device=DEV).manual_seed(B * 7 + Cin + Cout + H + pad)
+    x = torch.randn(B, Cin, H, W, device=DEV, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, device=DEV, generator=g)
+    scale = 1.0 / (Cin * 9) ** 0.5
+    Ho, Wo = (H + 2 * pad - 3) // 2 + 1, (W + 2 * pad - 3) // 2 + 1
+    s = 1.0 + 0.3 * torch.randn(B, Cin, device=DEV, generator=g)
+    d = 0.5 + torch.rand(B, Cout, device=DEV, generator=g)
+    noise = torch.randn(1, 1, Ho, Wo, device=DEV, generator=g)
+    nw = torch.full((1,), 0.37, device=DEV)
+    bias = 0.2 * torch.randn(Cout, device=DEV, generator=g)
+    assert conv.s2_eligible(x, w, 2, pad)
+
+    def chain(dt, full):
+        xs = x.to(dt) * s.to(dt).view(B, Cin, 1, 1) if full else x.to(dt)
+        v = torch.nn.functional.conv2d(xs, w.to(dt) * scale, stride=2, padding=pad)
+        if full:
+            v = v * d.to(dt).view(B, Cout, 1, 1) + nw.to(dt) * noise.to(dt)
+        v = v + bias.to(dt).view(1, -1, 1, 1)
+        return torch.nn.functional.leaky_relu(v, 0.2) * 2 ** 0.5
+
+    pk = conv.pack(w, scale)
+    for full in (False, True):
+        kw = dict(s=s, d=d, noise=noise, noise_weight=nw) if full else {}
+        y = conv.conv3x3s2(x, pk, Cout, pad, bias=bias, act=True, **kw)
+        assert y.shape == (B, Cout, Ho, Wo)
+        truth = chain(torch.float64, full)
+        err = (y.double() - truth).abs().max().item()
+        ref = (chain(torch.float32, full).double() - truth).abs().max().item()
+        assert err <= max(3 * ref, 2e-6 * truth.abs().max().item()), (full, err, ref)
+        for _ in range(3):
+            assert torch.equal(y, conv.conv3x3s2(x, pk, Cout, pad, bias=bias, act=True, **kw))
+    # plain sum, no epilogue
+    y0 = conv.conv3x3s2(x, pk, Cout, pad, act=False)
+    t0 = torch.nn.functional.conv2d(x.double(), w.double() * scale, stride=2, padding=pad)
+    assert (y0.double() - t0).abs().max().item() <= 2e-6 * t0.abs().max().item()
+
+
+def test_downsampling_convlayer_takes_the_stride2_kernel_and_matches_the_aten_route():
+    """ConvLayer(downsample=True) (Blur -> EqualConv2d stride 2 -> FusedLeakyReLU) at inference on HIP tensors: the fused route
+    (HAVATAR_CONV_S2=1: hav_upfirdn2d + hav_conv3x3s2_split) against the module's default MIOpen route."""
+    import os
+    from havatar_amd.model.styleUnet import ConvLayer
+    torch.manual_seed(5)
+    for cin, cout, H in ((64, 128, 256), (256, 512, 64)):
+        layer = ConvLayer(cin, cout, 3, downsample=True).to(DEV).eval()
+        layer[2].bias.data.normal_(0, 0.1)
+        x = torch.randn(2, cin, H, H, device=DEV)
+        with torch.no_grad():
+            want = layer(x)
+            os.environ["HAVATAR_CONV_S2"] = "1"
+            try:
+                got = layer(x)
+            finally:
+                del os.environ["HAVATAR_CONV_S2"]
+        assert got.shape == want.shape == (2, cout, H // 2, H // 2)
+        assert (got - want).abs().max().item() <= 1e-4 * want.abs().max().item()
+        assert not torch.equal(got, want)          # two different arithmetic routes really ran
+
+
 def test_conv3x3_full_occupancy_runs_are_bitwise_identical():
     """The interleaved kernel hangs VALU / LDS / memory work between its MFMAs; the matrix instructions keep reading their operand
     registers after issue, and a compiler that recycles such a register shows up as run-to-run differences once every
