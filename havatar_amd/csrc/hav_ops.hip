@@ -8,6 +8,8 @@
 //   model/op/fused_bias_act_kernel.cu:18-105, model/op/fused_bias_act.cpp:18-31
 //   model/op/upfirdn2d_kernel.cu:49-369,      model/op/upfirdn2d.cpp:17-31
 #include "hav_common.h"
+#include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 
 // ================================================================================================
@@ -726,6 +728,117 @@ static int ufd_launch_direct(float* out, const float* in, const float* k, const 
     return 0;
 }
 
+// Decimating FIR (up = 1, down = 2, FIR <= 4x4, minor = 1: `Downsample` / the Blur-free half of the discriminator and of FromRGB,
+// model/styleUnet.py:78-88) without LDS: a thread owns 4 consecutive output columns x SR output rows.  Its footprint is 10 input columns
+// per row, 8 of which are its own -- two 16-byte loads, disjoint between lanes, so a wave reads each input row segment exactly once --
+// and the last two are the first two of the next lane's segment, fetched from that lane's registers (ds_bpermute) instead of from memory
+// (the 3-loads-per-row version of this kernel was slower than the tiled one).  Lanes without a usable neighbour (last lane of a wave,
+// last strip of a row) load their two halo values themselves.  Out-of-image columns are masked after the load (the vector may run over
+// the end of a row into the next one: still inside the tensor), rows outside the image are not loaded at all; only windows that would
+// leave the tensor take the per-element path.  Tap order per output as everywhere (i ascending, then j): bit-identical results.
+template <int KH, int KW, int SR>
+__global__ void __launch_bounds__(256) ufd_down2_direct_f32_kernel(float* __restrict__ out, const float* __restrict__ in, const float* __restrict__ k,
+                                                                   UfdArgs a, int strips_x, int blocks_y, int64_t total, int64_t in_total)
+{
+    constexpr int NR = (SR - 1) * 2 + KH;
+    int64_t lb = blockIdx.x;
+    if ((gridDim.x & 7) == 0) lb = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);          // XCD-contiguous strip list
+    const int64_t gid0 = lb * blockDim.x + threadIdx.x;
+    const bool live = gid0 < total;
+    const int64_t gid = live ? gid0 : total - 1;          // idle lanes of the last wave shadow the last strip (they take part in the shuffles)
+    const int lane = threadIdx.x & 63;
+    const int sx = (int)(gid % strips_x);
+    int64_t t = gid / strips_x;
+    const int rb = (int)(t % blocks_y);
+    const int64_t m = t / blocks_y;
+    const int ox0 = 4 * sx, oy0 = rb * SR;
+    const int ix0 = 2 * ox0 - a.px0, iy0 = 2 * oy0 - a.py0;
+    float kreg[KH * KW];
+#pragma unroll
+    for (int i = 0; i < KH; ++i)
+#pragma unroll
+        for (int j = 0; j < KW; ++j) kreg[i * KW + j] = (i < a.kh && j < a.kw) ? k[(a.kh - 1 - i) * a.kw + (a.kw - 1 - j)] : 0.f;
+    const int64_t pbase = m * (int64_t)a.in_h * a.in_w;
+    // the halo comes from lane + 1 when that lane holds the next strip of the same row block
+    const bool nb_ok = lane < 63 && sx + 1 < strips_x && gid0 + 1 < total;
+    // 16-byte loads stay inside the tensor for every image row of the window?
+    const int ry0 = iy0 < 0 ? 0 : iy0, ry1 = iy0 + NR - 1 >= a.in_h ? a.in_h - 1 : iy0 + NR - 1;
+    const bool vec_ok = pbase + (int64_t)ry0 * a.in_w + ix0 >= 0 && pbase + (int64_t)ry1 * a.in_w + ix0 + 8 <= in_total;
+    bool cok[10];
+#pragma unroll
+    for (int c = 0; c < 10; ++c) cok[c] = ix0 + c >= 0 && ix0 + c < a.in_w;
+    float v[NR][10], own[NR][2];
+    // every load of the thread -- the two vectors per row and, for lanes without a neighbour, their own halo -- is issued before the first use
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int iy = iy0 + r;
+        const bool rok = iy >= 0 && iy < a.in_h;
+        const float* src = in + pbase + (int64_t)iy * a.in_w + ix0;
+        if (rok && vec_ok) {
+            typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+            const f4u q0 = *reinterpret_cast<const f4u*>(src), q1 = *reinterpret_cast<const f4u*>(src + 4);
+            v[r][0] = q0.x; v[r][1] = q0.y; v[r][2] = q0.z; v[r][3] = q0.w; v[r][4] = q1.x; v[r][5] = q1.y; v[r][6] = q1.z; v[r][7] = q1.w;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[r][c] = (rok && cok[c]) ? src[c] : 0.f;
+        }
+        own[r][0] = (!nb_ok && rok && cok[8]) ? src[8] : 0.f;
+        own[r][1] = (!nb_ok && rok && cok[9]) ? src[9] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[r][c] = cok[c] ? v[r][c] : 0.f;
+        const float h0 = __shfl_down(v[r][0], 1, 64), h1 = __shfl_down(v[r][1], 1, 64);          // already masked by their owner
+        v[r][8] = nb_ok ? h0 : own[r][0];
+        v[r][9] = nb_ok ? h1 : own[r][1];
+    }
+    float acc[SR][4];
+#pragma unroll
+    for (int q = 0; q < SR; ++q) acc[q][0] = acc[q][1] = acc[q][2] = acc[q][3] = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr)
+#pragma unroll
+        for (int j = 0; j < KW; ++j)
+#pragma unroll
+            for (int q = 0; q < SR; ++q) {
+                const int i = rr - q * 2;
+                if (i >= 0 && i < KH) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[q][c] = fmaf(v[rr][c * 2 + j], kreg[i * KW + j], acc[q][c]);
+                }
+            }
+    if (!live) return;
+    float* oplane = out + m * (int64_t)a.out_h * a.out_w;
+#pragma unroll
+    for (int q = 0; q < SR; ++q) {
+        const int oy = oy0 + q;
+        if (oy >= a.out_h) break;
+        float* dst = oplane + (int64_t)oy * a.out_w + ox0;
+        if (ox0 + 3 < a.out_w) {
+            typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+            const f4u o = {acc[q][0], acc[q][1], acc[q][2], acc[q][3]};
+            *reinterpret_cast<f4u*>(dst) = o;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (ox0 + c < a.out_w) dst[c] = acc[q][c];
+        }
+    }
+}
+
+template <int KH, int KW, int SR>
+static int ufd_launch_down2_direct(float* out, const float* in, const float* k, const UfdArgs& a, hipStream_t st)
+{
+    const int strips_x = (a.out_w + 3) / 4, blocks_y = (a.out_h + SR - 1) / SR;
+    const int64_t total = a.major * strips_x * blocks_y;
+    const int64_t blocks = ((total + 255) / 256 + 7) / 8 * 8;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return HAV_EUNSUP;
+    hipLaunchKernelGGL((ufd_down2_direct_f32_kernel<KH, KW, SR>), dim3((unsigned)blocks), dim3(256), 0, st, out, in, k, a, strips_x, blocks_y, total,
+                       a.major * (int64_t)a.in_h * a.in_w);
+    HAV_LAUNCH_CHECK();
+    return 0;
+}
+
 // x2 up-sampling FIR (up = 2, down = 1, FIR <= 4x4: `Upsample` of the ToRGB skip path, model/styleUnet.py:65-75) without LDS: a thread owns
 // an 8 x 8 output block = the 2x2-tap polyphase filters applied to a 6 x 6 input window held in registers (12 loads, 16 16-byte stores).
 // EY / EX = parity of the padding: with output rows Y0 = 8 rb the zero-stuffed coordinate of tap i of row Y0 + q is 2 a0 + EY + q + i,
@@ -839,6 +952,14 @@ static int ufd_launch(void* out_, const void* in_, const float* k, const UfdArgs
             if (up == 1 && dn == 1 && a.out_w >= 64 && a.in_w >= 64) {
                 if (kh <= 4 && kw <= 4 && (kh > 3 || kw > 3)) return ufd_launch_direct<1, 4, 4, 8>((float*)out, (const float*)in, k, a, st);
                 if (kh <= 3 && kw <= 3) return ufd_launch_direct<1, 3, 3, 8>((float*)out, (const float*)in, k, a, st);
+            }
+            // f32 decimation by 2 with a FIR of up to 4x4 taps stays on the LDS-tiled kernel: the direct kernel with the lane-to-lane halo
+            // (round 3) is bit-identical but no faster -- [64,513,513]: 22.3 us (4 rows per thread) / 23.5 us (8 rows) against 21.3 us,
+            // tools/ufd_ab.sh -- so it only runs on request (HAVATAR_UFD_DOWN2=direct|sr8, read once; the parity test drives all three)
+            if (up == 1 && dn == 2 && kh <= 4 && kw <= 4 && (kh > 2 || kw > 2) && a.out_w >= 64 && a.px0 >= 0 && a.py0 >= 0) {
+                static const int mode = [] { const char* e = getenv("HAVATAR_UFD_DOWN2"); return !e ? 0 : (!strcmp(e, "direct") ? 1 : (!strcmp(e, "sr8") ? 2 : 0)); }();
+                if (mode == 1) return ufd_launch_down2_direct<4, 4, 4>((float*)out, (const float*)in, k, a, st);
+                if (mode == 2) return ufd_launch_down2_direct<4, 4, 8>((float*)out, (const float*)in, k, a, st);
             }
             // f32 x2 up-sampling with a FIR of up to 4x4 taps (non-negative padding): the register-window kernel
             if (up == 2 && dn == 1 && kh <= 4 && kw <= 4 && a.px0 >= 0 && a.py0 >= 0 && a.out_w >= 64)

@@ -111,6 +111,11 @@ def test_upfirdn2d_matches_reference_vectors_and_grads():
     # x2 up-sampling through the register-window kernel (f32, out_w >= 64): both padding parities, ragged sizes, a non-square FIR
     (3, 64, 64, 1, 4, 4, (2, 2), (1, 1), (2, 1, 2, 1)), (2, 37, 50, 1, 4, 4, (2, 2), (1, 1), (1, 2, 3, 0)),
     (1, 128, 96, 1, 3, 4, (2, 2), (1, 1), (3, 2, 0, 5)), (12, 256, 256, 1, 4, 4, (2, 2), (1, 1), (2, 1, 2, 1)),
+    # decimation by 2 at the sizes the direct kernel would take (f32, out_w >= 64): ragged sizes, odd pads, a non-square FIR, a row that
+    # ends inside a wave, the BASELINE cfg4 shape (the tiled kernel by default; the direct one in the bit-identity test below)
+    (3, 131, 260, 1, 4, 4, (1, 1), (2, 2), (1, 1, 1, 1)), (2, 140, 259, 1, 4, 4, (1, 1), (2, 2), (2, 1, 0, 3)),
+    (2, 66, 300, 1, 3, 4, (1, 1), (2, 2), (0, 0, 1, 1)), (5, 513, 513, 1, 4, 4, (1, 1), (2, 2), (1, 1, 1, 1)),
+    (1, 9, 128, 1, 4, 4, (1, 1), (2, 2), (3, 3, 3, 3)),
     # generic kernel: minor > 1, anisotropic factors, large FIR, negative pads
     (2, 12, 9, 3, 5, 3, (3, 2), (2, 3), (2, 3, 1, 4)), (3, 20, 22, 1, 7, 7, (1, 1), (1, 1), (3, 3, 3, 3)),
     (2, 14, 15, 2, 4, 4, (1, 1), (1, 1), (-1, 2, -2, 3)), (1, 9, 9, 1, 3, 3, (2, 2), (2, 2), (1, 1, 1, 1)),
@@ -127,6 +132,30 @@ def test_upfirdn2d_native_vs_oracle(case):
     assert linf(y.cpu().numpy(), yo) <= 1e-5 * max(1.0, float(np.abs(yo).max()))
     y64 = op.upfirdn2d(_t(x, torch.float64), _t(k), up[0], up[1], dn[0], dn[1], *pad)
     assert linf(y64.cpu().numpy(), oracle.upfirdn2d(x.astype(np.float64), k, up[0], up[1], dn[0], dn[1], *pad)) <= 1e-12
+
+
+def test_upfirdn2d_decimating_direct_kernel_is_bit_identical_to_the_tiled_one(tmp_path):
+    """The LDS-free decimating kernel (ufd_down2_direct_f32_kernel, opt-in: HAVATAR_UFD_DOWN2=direct|sr8) keeps the tap order of the tiled
+    kernel: same bits.  The kernel choice is read once per process, so each variant runs in a child process."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+        "from havatar_amd.native import upfirdn2d as op\n"
+        "g = torch.Generator(device='cuda:0').manual_seed(3)\n"
+        "x = torch.randn(7, 513, 513, 1, device='cuda:0', generator=g); k = torch.randn(4, 4, device='cuda:0', generator=g)\n"
+        "y = op.upfirdn2d(x, k, 1, 1, 2, 2, 1, 1, 1, 1); z = op.upfirdn2d(x[:, :300, :411].contiguous(), k, 1, 1, 2, 2, 2, 1, 1, 2)\n"
+        "np.savez(sys.argv[1], y=y.cpu().numpy(), z=z.cpu().numpy())\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    outs = {}
+    for mode in ("direct", "tiled", "sr8"):
+        env = dict(os.environ, HAVATAR_UFD_DOWN2=mode)
+        f = str(tmp_path / (mode + ".npz"))
+        subprocess.run([sys.executable, "-c", code, f], check=True, env=env, timeout=300)
+        outs[mode] = np.load(f)
+    for key in ("y", "z"):
+        assert np.array_equal(outs["direct"][key], outs["tiled"][key]), key
+        assert np.array_equal(outs["sr8"][key], outs["tiled"][key]), key
 
 
 def test_upfirdn2d_half_precisions_and_errors():
