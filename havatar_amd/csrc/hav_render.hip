@@ -1546,6 +1546,17 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
         if (tid < 4) locks[tid] = 0;
         __syncthreads();
     }
+#ifdef HAV_HALF_WAVES
+    // experiment (complete results, half the waves): 1 = waves 4..7 exit, one live wave per SIMD (waves w and w + 4 share a SIMD,
+    // tools/ubench/simd_map.hip); 2 = the odd waves exit, the same number of live waves but still two on SIMDs 0 and 2.  The live
+    // waves deal the blocks among themselves.
+    if (HAV_HALF_WAVES == 1 ? wave >= 4 : (wave & 1)) return;
+    const int wave_rank = HAV_HALF_WAVES == 1 ? wave : wave >> 1;
+    constexpr int WAVES_LIVE = MARCH_WAVES / 2;
+#else
+    const int wave_rank = wave;
+    constexpr int WAVES_LIVE = MARCH_WAVES;
+#endif
 
     const int S_c = a.p.S_c, S_f = a.p.S_f, S_fp = a.S_fp, S_half = (S_c + 1) >> 1;
     const int R = a.p.R;
@@ -1563,7 +1574,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
         span = nblk - base; if (span > chunk) span = chunk; if (span < 0) span = 0;
     } else { base = 0; span = nblk; lb = blockIdx.x; nbx = gridDim.x; }
 
-    for (long long local = (long long)lb * MARCH_WAVES + wave; local < span; local += (long long)nbx * MARCH_WAVES) {
+    for (long long local = (long long)lb * WAVES_LIVE + wave_rank; local < span; local += (long long)nbx * WAVES_LIVE) {
         const long long blk = base + local;
         const int b = (int)(blk / bpf);
         const int r0 = (int)(blk - (long long)b * bpf) * 32 + j;
@@ -1861,6 +1872,11 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
             // ---- inverse-CDF resampling (utils/nerf_util.py:76-117): one ray per lane, one sequential sweep over the CDF ----
             if (pass == 0 && S_fp > 0) {
                 const int nw = S_c - 2, nb = S_c - 1;
+#ifdef HAV_WROW_FENCE
+                // the coarse weights were stored moments ago by this wave and are read back here
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
                 float sum = 0.f;
                 for (int i = 0; i < nw; ++i) sum += (HAV_SELF_LOAD(CACHE ? &wrow[(1 + i) * 32 + j] : &wpark[1 + i]) + 1e-5f);
                 float run = 0.f, cdf_lo = 0.f;
