@@ -128,6 +128,14 @@ def lib():
     L.hav_conv3x3_split.argtypes = [vp] * 8 + [f32, f32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]
     L.hav_conv3x3s2_split.argtypes = [vp] * 8 + [f32, f32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]
     L.hav_conv3x3s2_split.restype = i32
+    L.hav_conv3x3_pack_t.argtypes = [vp, vp, i32, i32, f32, vp]
+    L.hav_conv3x3_pack_t.restype = i32
+    L.hav_conv3x3_wgrad_mod.argtypes = [vp, vp, vp, vp, f32, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    L.hav_conv3x3_wgrad_mod.restype = i32
+    L.hav_conv_block_bwd.argtypes = [vp] * 11 + [f32, f32, i32, i32, i32, i32, i64, vp]
+    L.hav_conv_block_bwd.restype = i32
+    L.hav_mod_input_bwd.argtypes = [vp, vp, vp, vp, i32, i32, i64, vp]
+    L.hav_mod_input_bwd.restype = i32
     L.hav_absmax.argtypes = [vp, vp, i64, vp]
     L.hav_absmax.restype = i32
     L.hav_conv3x3_split.restype = i32

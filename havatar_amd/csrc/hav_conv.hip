@@ -48,8 +48,10 @@ typedef float fl2_t __attribute__((ext_vector_type(2)));
 extern "C" int64_t hav_conv3x3_packed_bytes(int Cout, int Cin) { return (int64_t)(Cin / 16) * 9 * (Cout / 32) * 2 * 64 * 16; }
 
 // fragment (chunk cc, tap t, M tile m, part): lane (i, h) holds W[32m + i][16cc + 8h + e][t] * wmul * 2^8, e = 0..7, as fp16 hi or lo
+// transposed != 0: the filters of the DATA GRADIENT, W'[o' = i][i' = o][t] = W[o][i][8 - t] (Cout, Cin are those of W'), read straight
+// from W [Cin, Cout, 3, 3] -- no flip / transpose / contiguous passes in front of the pack
 __global__ void __launch_bounds__(256) conv3x3_pack_kernel(uint4* __restrict__ blob, const float* __restrict__ w, int Cout, int Cin, float wmul,
-                                                           int64_t total)
+                                                           int64_t total, int transposed)
 {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
@@ -65,7 +67,10 @@ __global__ void __launch_bounds__(256) conv3x3_pack_kernel(uint4* __restrict__ b
     for (int d = 0; d < 4; ++d) {
         float v[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) v[u] = w[((int64_t)(32 * m + i) * Cin + 16 * cc + 8 * h + 2 * d + u) * 9 + t] * (wmul * CV_WSHIFT);
+        for (int u = 0; u < 2; ++u) {
+            const int o = 32 * m + i, ci = 16 * cc + 8 * h + 2 * d + u;
+            v[u] = (transposed ? w[((int64_t)ci * Cout + o) * 9 + (8 - t)] : w[((int64_t)o * Cin + ci) * 9 + t]) * (wmul * CV_WSHIFT);
+        }
         const fl2_t f = {v[0], v[1]};
         const h2_t hi = __builtin_convertvector(f, h2_t);
         const h2_t lo = __builtin_convertvector(f - __builtin_convertvector(hi, fl2_t), h2_t);
@@ -80,7 +85,19 @@ extern "C" int hav_conv3x3_pack(void* blob, const float* w, int Cout, int Cin, f
     if ((Cout % 32) || (Cin % 16)) return HAV_EUNSUP;
     const int64_t total = hav_conv3x3_packed_bytes(Cout, Cin) / 16;
     hipLaunchKernelGGL(conv3x3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (uint4*)blob, w, Cout, Cin,
-                       wmul, total);
+                       wmul, total, 0);
+    HAV_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int hav_conv3x3_pack_t(void* blob, const float* w, int Cout_w, int Cin_w, float wmul, void* stream)
+{
+    // w [Cout_w, Cin_w, 3, 3] -> the blob of the convolution with Cin_w output and Cout_w input channels (flipped taps)
+    if (!blob || !w || Cout_w < 16 || Cin_w < 32) return HAV_EINVAL;
+    if ((Cout_w % 16) || (Cin_w % 32)) return HAV_EUNSUP;
+    const int64_t total = hav_conv3x3_packed_bytes(Cin_w, Cout_w) / 16;
+    hipLaunchKernelGGL(conv3x3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (uint4*)blob, w, Cin_w, Cout_w,
+                       wmul, total, 1);
     HAV_LAUNCH_CHECK();
     return 0;
 }
@@ -1024,6 +1041,7 @@ extern "C" int hav_upconv_finish(float* y, const float* col, const float* fir4x4
 #define WG_GO 20            // dwords per output channel in a g buffer: 8 hi + 8 lo + 4 pad
 struct WgradArgs {
     float* partial; const float* g; const float* x; const unsigned int* g_amax; const unsigned int* x_amax;
+    const float* xs;          // optional [B, Cin]: the x operand is xs[b, i] * x (the modulated input of a ModulatedConv2d)
     int B, Cin, Cout, H, W, strips;
 };
 
@@ -1037,7 +1055,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_kernel(WgradArgs a)
     const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout;
     const int sw = W / 16;          // strips per image
     // both operands are activations: each gets its own power of two (max |g|, max |x| -> [512, 1024)), undone together on the way out
-    const int eg = a.g_amax ? amax_pow2(a.g_amax, lane, 1.0f) : 0, ex = a.x_amax ? amax_pow2(a.x_amax, lane, 1.0f) : 0;
+    const int eg = a.g_amax ? amax_pow2(a.g_amax, lane, 1.0f) : 0;
+    const int ex = a.x_amax ? amax_pow2(a.x_amax, lane, a.xs ? wave_absmax(a.xs, a.B * Cin, lane) : 1.0f) : 0;
     const float g_sc = pow2f(eg), x_sc = pow2f(ex);
     const float out_g = pow2f(-eg), out_x = pow2f(-ex);          // applied one after the other: |eg + ex| may pass 127
     // staging roles.  g: thread = (o = tid >> 2, 4 pixels q4 = tid & 3): one float4.  x: thread = (i = tid >> 3, pixel pair p8 = tid & 7)
@@ -1057,9 +1076,10 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_kernel(WgradArgs a)
     };
     // input row `row` of strip (b, x0) -> ring slot (row + 1) & 3, three shifted copies; rows outside the image are zeros.  fetch_*
     // only issue the loads; stash_* (conversion, LDS writes) run after the step's MFMAs so that the loads fly under them
-    struct XR { float a0, a1, el, er; };
+    struct XR { float a0, a1, el, er, sc; };
     auto fetch_x = [&](int b, int x0, int row) {
-        XR r = {0.f, 0.f, 0.f, 0.f};
+        XR r = {0.f, 0.f, 0.f, 0.f, x_sc};
+        if (a.xs) r.sc = x_sc * a.xs[(int64_t)b * Cin + i0 + x_i];
         if (row >= 0 && row < H) {
             const float* src = a.x + (((int64_t)b * Cin + i0 + x_i) * H + row) * W + x0;
             const float2 v = *reinterpret_cast<const float2*>(src + 2 * x_p);
@@ -1075,8 +1095,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_kernel(WgradArgs a)
         float pa1 = __shfl_up(r.a1, 1, 64), na0 = __shfl_down(r.a0, 1, 64);
         if (x_p == 0) pa1 = r.el;
         if (x_p == 7) na0 = r.er;
-        const float a0 = r.a0 * x_sc, a1 = r.a1 * x_sc;
-        pa1 *= x_sc; na0 *= x_sc;
+        const float a0 = r.a0 * r.sc, a1 = r.a1 * r.sc;
+        pa1 *= r.sc; na0 *= r.sc;
         uint32_t hi, lo;
         split2(pa1, a0, hi, lo);  dst[0 * 16 + x_p] = hi; dst[0 * 16 + 8 + x_p] = lo;          // kx = 0: element j = x[x0 + j - 1]
         split2(a0, a1, hi, lo); dst[1 * 16 + x_p] = hi; dst[1 * 16 + 8 + x_p] = lo;          // kx = 1
@@ -1104,7 +1124,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_kernel(WgradArgs a)
         for (int y = 0; y < H; ++y) {
             // next step's operands: input row y + 2 (its slot held row y - 2) and g row y + 1 (other buffer): loads now, LDS after the MFMAs
             const bool more = y + 1 < H;
-            XR nx = {0.f, 0.f, 0.f, 0.f};
+            XR nx = {0.f, 0.f, 0.f, 0.f, 0.f};
             float4 ng = make_float4(0.f, 0.f, 0.f, 0.f);
             if (more) { nx = fetch_x(b, x0, y + 2); ng = fetch_g(b, x0, y + 1); }
             const uint32_t* G = gs[y & 1] + (32 * mo + j) * WG_GO + 4 * h;
@@ -1143,7 +1163,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_kernel(WgradArgs a)
     }
 }
 
-__global__ void __launch_bounds__(256) conv3x3_wgrad_reduce_kernel(float* __restrict__ gw, const float* __restrict__ partial, int ks, int Cout, int Cin)
+__global__ void __launch_bounds__(256) conv3x3_wgrad_reduce_kernel(float* __restrict__ gw, const float* __restrict__ partial, int ks, int Cout, int Cin,
+                                                                   float out_mul)
 {
     const int64_t n = (int64_t)Cout * Cin;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
@@ -1155,7 +1176,7 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_reduce_kernel(float* __rest
             v[t] = s;
         }
 #pragma unroll
-        for (int t = 0; t < 9; ++t) gw[e * 9 + t] = v[t];
+        for (int t = 0; t < 9; ++t) gw[e * 9 + t] = v[t] * out_mul;
     }
 }
 
@@ -1174,13 +1195,27 @@ extern "C" int64_t hav_conv3x3_wgrad_scratch_bytes(int B, int Cin, int Cout, int
     if (B < 1 || Cin < 32 || Cout < 64 || H < 1 || W < 16 || (Cin % 32) || (Cout % 64) || (W % 16)) return 0;
     return (int64_t)wgrad_ksplit(B, Cin, Cout, H, W) * 9 * Cout * Cin * 4;
 }
+static int wgrad_launch(float* gw, const float* g, const float* x, const float* xs, float out_mul, void* scratch, const void* g_amax,
+                        const void* x_amax, int B, int Cin, int Cout, int H, int W, void* stream);
 extern "C" int hav_conv3x3_wgrad(float* gw, const float* g, const float* x, void* scratch, const void* g_amax, const void* x_amax, int B, int Cin,
                                  int Cout, int H, int W, void* stream)
+{
+    return wgrad_launch(gw, g, x, nullptr, 1.0f, scratch, g_amax, x_amax, B, Cin, Cout, H, W, stream);
+}
+// the same with the x operand modulated (xs [B, Cin] * x) and the result scaled by out_mul: the weight gradient of a ModulatedConv2d /
+// EqualConv2d PARAMETER (out_mul = its 1 / sqrt(9 Cin) scale) in one go
+extern "C" int hav_conv3x3_wgrad_mod(float* gw, const float* g, const float* x, const float* xs, float out_mul, void* scratch, const void* g_amax,
+                                     const void* x_amax, int B, int Cin, int Cout, int H, int W, void* stream)
+{
+    return wgrad_launch(gw, g, x, xs, out_mul, scratch, g_amax, x_amax, B, Cin, Cout, H, W, stream);
+}
+static int wgrad_launch(float* gw, const float* g, const float* x, const float* xs, float out_mul, void* scratch, const void* g_amax,
+                        const void* x_amax, int B, int Cin, int Cout, int H, int W, void* stream)
 {
     if (!gw || !g || !x || !scratch || B < 1 || H < 1) return HAV_EINVAL;
     if (Cin < 32 || Cout < 64 || W < 16 || (Cin % 32) || (Cout % 64) || (W % 16)) return HAV_EUNSUP;
     WgradArgs a;
-    a.partial = (float*)scratch; a.g = g; a.x = x; a.g_amax = (const unsigned int*)g_amax; a.x_amax = (const unsigned int*)x_amax;
+    a.partial = (float*)scratch; a.g = g; a.x = x; a.g_amax = (const unsigned int*)g_amax; a.x_amax = (const unsigned int*)x_amax; a.xs = xs;
     a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.strips = B * (W / 16);
     const int ks = wgrad_ksplit(B, Cin, Cout, H, W);
     hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3((unsigned)(Cin / 32), (unsigned)(Cout / 64), (unsigned)ks), dim3(256), 0, (hipStream_t)stream, a);
@@ -1188,7 +1223,131 @@ extern "C" int hav_conv3x3_wgrad(float* gw, const float* g, const float* x, void
     const int64_t n = (int64_t)Cout * Cin;
     int64_t blocks = (n + 255) / 256;
     if (blocks > (int64_t)hav_num_cus() * 8) blocks = (int64_t)hav_num_cus() * 8;
-    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gw, (const float*)scratch, ks, Cout, Cin);
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gw, (const float*)scratch, ks, Cout, Cin, out_mul);
+    HAV_LAUNCH_CHECK();
+    return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Backward glue of a fused convolution block under autograd (native/conv.py::_FusedConvBlock): what ATen ran as ~20 small launches
+// per layer (activation gradient, three reductions, two broadcasts, the d / s scalings) in three:
+//   block_bwd_pre       gc = d[b,o] * g_pre,  g_pre = g * gain * act'(y);  per (b, o): S0 = sum g_pre, S1 = sum g_pre * noise,
+//                       S2 = sum g_pre * pre   (pre = the pre-activation, recovered from the block's output y: the leaky-ReLU is
+//                       invertible -- sign(y), then y / gain (/ slope))
+//   block_bwd_finalize  gd[b,o] = (S2 - nw S1 - bias[o] S0) / d[b,o]   (= sum g_pre * conv_raw),  gbias[o] = sum_b S0,  gnw = sum S1
+//   mod_input_bwd       gs[b,i] = sum_p x * gxs,  gx = s[b,i] * gxs   (in place)
+struct BlockBwdArgs {
+    float* gc; float* sums;          // [B,Cout,H,W], [B*Cout][3]
+    const float* g; const float* y; const float* d; const float* noise;
+    float slope, gain;
+    int act, noise_batched, Cout;
+    int64_t HW;
+};
+__device__ __forceinline__ float block_sum256(float v, float* red)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void __launch_bounds__(256) block_bwd_pre_kernel(BlockBwdArgs a)
+{
+    __shared__ float red[4];
+    const int bo = blockIdx.x, b = bo / a.Cout;
+    const float dd = a.d ? a.d[bo] : 1.0f;
+    const float* g = a.g + (int64_t)bo * a.HW;
+    const float* y = a.y + (int64_t)bo * a.HW;
+    const float* nz = a.noise ? a.noise + (a.noise_batched ? (int64_t)b * a.HW : 0) : nullptr;
+    float* gc = a.gc + (int64_t)bo * a.HW;
+    const float inv_gain = 1.0f / a.gain, inv_slope = 1.0f / a.slope;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int64_t p = 4 * (int64_t)threadIdx.x; p < a.HW; p += 1024) {          // HW % 4 == 0 (the convolution kernels need W % 32 == 0)
+        const float4 gv = *reinterpret_cast<const float4*>(g + p), yv = *reinterpret_cast<const float4*>(y + p);
+        const float4 nv = nz ? *reinterpret_cast<const float4*>(nz + p) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float ge[4] = {gv.x, gv.y, gv.z, gv.w}, ye[4] = {yv.x, yv.y, yv.z, yv.w}, ne[4] = {nv.x, nv.y, nv.z, nv.w};
+        float oe[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float gp = ge[k], pre = ye[k];
+            if (a.act) {
+                const bool pos = ye[k] > 0.f;
+                gp = ge[k] * (pos ? a.gain : a.gain * a.slope);
+                pre = ye[k] * (pos ? inv_gain : inv_gain * inv_slope);
+            }
+            s0 += gp; s1 = fmaf(gp, ne[k], s1); s2 = fmaf(gp, pre, s2);
+            oe[k] = gp * dd;
+        }
+        *reinterpret_cast<float4*>(gc + p) = make_float4(oe[0], oe[1], oe[2], oe[3]);
+    }
+    s0 = block_sum256(s0, red); s1 = block_sum256(s1, red); s2 = block_sum256(s2, red);
+    if (threadIdx.x == 0) { a.sums[3 * (int64_t)bo] = s0; a.sums[3 * (int64_t)bo + 1] = s1; a.sums[3 * (int64_t)bo + 2] = s2; }
+}
+__global__ void __launch_bounds__(256) block_bwd_finalize_kernel(float* __restrict__ gd, float* __restrict__ gbias, float* __restrict__ gnw,
+                                                                const float* __restrict__ sums, const float* __restrict__ d,
+                                                                const float* __restrict__ bias, const float* __restrict__ noise_weight, int B, int Cout)
+{
+    __shared__ float red[4];
+    const float nw = noise_weight ? *noise_weight : 0.f;
+    float tot1 = 0.f;
+    for (int o = threadIdx.x; o < Cout; o += 256) {
+        float sb = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float* s = sums + 3 * ((int64_t)b * Cout + o);
+            sb += s[0]; tot1 += s[1];
+            if (gd) gd[(int64_t)b * Cout + o] = ((s[2] - nw * s[1]) - (bias ? bias[o] : 0.f) * s[0]) / d[(int64_t)b * Cout + o];
+        }
+        if (gbias) gbias[o] = sb;
+    }
+    tot1 = block_sum256(tot1, red);
+    if (gnw && threadIdx.x == 0) *gnw = tot1;
+}
+extern "C" int hav_conv_block_bwd(float* gc, float* gd, float* gbias, float* gnw, float* sums_scratch /*[B*Cout*3]*/, const float* g, const float* y,
+                                  const float* d, const float* noise, const float* noise_weight, const float* bias, float slope, float gain, int act,
+                                  int noise_batched, int B, int Cout, int64_t HW, void* stream)
+{
+    if (!gc || !sums_scratch || !g || !y || B < 1 || Cout < 1 || HW < 4 || (gd && !d) || (gnw && !noise)) return HAV_EINVAL;
+    if (HW % 4) return HAV_EUNSUP;
+    if (act && (!(slope > 0.f) || !(gain > 0.f))) return HAV_EUNSUP;          // the activation must be invertible
+    BlockBwdArgs a;
+    a.gc = gc; a.sums = sums_scratch; a.g = g; a.y = y; a.d = d; a.noise = noise; a.slope = slope; a.gain = gain; a.act = act;
+    a.noise_batched = noise_batched; a.Cout = Cout; a.HW = HW;
+    hipLaunchKernelGGL(block_bwd_pre_kernel, dim3((unsigned)(B * Cout)), dim3(256), 0, (hipStream_t)stream, a);
+    HAV_LAUNCH_CHECK();
+    if (gd || gbias || gnw) {
+        hipLaunchKernelGGL(block_bwd_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, gd, gbias, gnw, (const float*)sums_scratch, d, bias,
+                           noise_weight, B, Cout);
+        HAV_LAUNCH_CHECK();
+    }
+    return 0;
+}
+__global__ void __launch_bounds__(256) mod_input_bwd_kernel(float* __restrict__ gx, float* __restrict__ gs, const float* __restrict__ x,
+                                                           const float* __restrict__ s, int64_t HW)
+{
+    __shared__ float red[4];
+    const int bi = blockIdx.x;
+    const float sv = s[bi];
+    float* gp = gx + (int64_t)bi * HW;
+    const float* xp = x + (int64_t)bi * HW;
+    float acc = 0.f;
+    for (int64_t p = 4 * (int64_t)threadIdx.x; p < HW; p += 1024) {
+        float4 gv = *reinterpret_cast<const float4*>(gp + p);
+        const float4 xv = *reinterpret_cast<const float4*>(xp + p);
+        acc = fmaf(gv.x, xv.x, acc); acc = fmaf(gv.y, xv.y, acc); acc = fmaf(gv.z, xv.z, acc); acc = fmaf(gv.w, xv.w, acc);
+        gv.x *= sv; gv.y *= sv; gv.z *= sv; gv.w *= sv;
+        *reinterpret_cast<float4*>(gp + p) = gv;
+    }
+    acc = block_sum256(acc, red);
+    if (threadIdx.x == 0) gs[bi] = acc;
+}
+extern "C" int hav_mod_input_bwd(float* gx_inout, float* gs, const float* x, const float* s, int B, int Cin, int64_t HW, void* stream)
+{
+    if (!gx_inout || !gs || !x || !s || B < 1 || Cin < 1 || HW < 4) return HAV_EINVAL;
+    if (HW % 4) return HAV_EUNSUP;
+    hipLaunchKernelGGL(mod_input_bwd_kernel, dim3((unsigned)(B * Cin)), dim3(256), 0, (hipStream_t)stream, gx_inout, gs, x, s, HW);
     HAV_LAUNCH_CHECK();
     return 0;
 }

@@ -282,6 +282,13 @@ class ConvLayer(nn.Sequential):
                 return _conv.conv3x3s2(xb, pk, ec.weight.shape[0], ec.padding, bias=ec.bias, act=False)
             out = ec(xb)
             return self[2](out) if len(self) > 2 else out
+        if (isinstance(ec, EqualConv2d) and input.is_cuda and input.dtype == torch.float32 and torch.is_grad_enabled()
+                and _fused_conv_enabled() and ec.stride == 1 and ec.padding == 1 and input.shape[-1] * input.shape[-2] >= 1024
+                and _conv.block_eligible(input, ec.weight)):
+            # HIP training: EqualConv2d 3x3 + bias + leaky-ReLU as one autograd node (native/conv.py::_FusedConvBlock)
+            if len(self) > 1:
+                return _conv.fused_block(input, ec.weight, ec.scale, bias=self[1].bias, slope=self[1].negative_slope, gain=self[1].scale, act=True)
+            return _conv.fused_block(input, ec.weight, ec.scale, bias=ec.bias, act=False)
         if (isinstance(ec, EqualConv2d) and input.is_cuda and input.dtype == torch.float32 and not torch.is_grad_enabled()
                 and _fused_conv_enabled() and input.shape[-1] * input.shape[-2] >= 1024
                 and _conv.eligible(input, ec.weight, ec.stride, ec.padding)):
@@ -403,6 +410,16 @@ class StyledConv(nn.Module):
             return _conv.upconv3x3(input, self.conv.packed_upconv(), self.conv.out_channel, self.conv.blur.kernel, s=s, d=d, noise=noise,
                                    noise_weight=self.noise.weight, bias=self.activate.bias, slope=self.activate.negative_slope,
                                    gain=self.activate.scale, act=True)
+        if (input.is_cuda and input.dtype == torch.float32 and torch.is_grad_enabled() and self.conv.kernel_size == 3
+                and not self.conv.upsample and not self.conv.downsample and _fused_conv_enabled()
+                and input.shape[-1] * input.shape[-2] >= 1024 and _conv.block_eligible(input, self.conv.weight[0])):
+            # HIP training, 3x3: the whole block as one autograd node (native/conv.py::_FusedConvBlock)
+            s, d = self.conv.style_vectors(style)
+            if noise is None:
+                b, _, h, w = input.shape
+                noise = input.new_empty(b, 1, h, w).normal_()
+            return _conv.fused_block(input, self.conv.weight[0], self.conv.scale, s=s, d=d, noise=noise, noise_weight=self.noise.weight,
+                                     bias=self.activate.bias, slope=self.activate.negative_slope, gain=self.activate.scale, act=True)
         if self.conv._hip_inference(input):
             # HIP inference: demodulation * noise injection + bias + leaky-relu in ONE pass (hav_styled_epilogue) instead of four
             from ..native import fused

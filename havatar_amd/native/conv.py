@@ -58,6 +58,18 @@ def pack(weight, wmul=1.0):
     return blob
 
 
+def pack_t(weight, wmul=1.0):
+    """[Cout,Cin,3,3] float32 -> the fragment blob of the DATA GRADIENT's convolution (Cin outputs, Cout inputs, flipped taps), packed
+    straight from `weight` (hav_conv3x3_pack_t): no flip / transpose / contiguous passes."""
+    w = weight.detach().contiguous()
+    Cout, Cin = w.shape[:2]
+    L = _lib.lib()
+    blob = torch.empty(int(L.hav_conv3x3_packed_bytes(Cin, Cout)), dtype=torch.uint8, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(L.hav_conv3x3_pack_t(_p(blob), _p(w), Cout, Cin, float(wmul), _stream(w.device)), "hav_conv3x3_pack_t")
+    return blob
+
+
 def conv3x3(x, packed, Cout, s=None, d=None, noise=None, noise_weight=None, bias=None, slope=0.2, gain=2 ** 0.5, act=True, autoscale=None):
     """y = act(d * conv3x3(s * x, W) + noise_weight * noise + bias) * gain; see include/havatar.h for the exact order.
     autoscale (default on; HAVATAR_CONV_AUTOSCALE=0 turns the default off): s * x is brought into fp16's comfortable range by an
@@ -136,10 +148,11 @@ def wgrad_eligible(g, x):
     return x.shape[0] == B and tuple(x.shape[2:]) == (H, W) and x.shape[1] % 32 == 0 and Cout % 64 == 0 and W % 16 == 0
 
 
-def wgrad3x3(g, x):
-    """gw [Cout,Cin,3,3] = d/dW of conv2d(x, W, stride 1, padding 1) given g = dL/dy (hav_conv3x3_wgrad: split-fp16 MFMA, fp32-class;
-    both operands under the power-of-two range control: g is gradient-sized, x whatever the activations are)."""
-    g, x = g.contiguous(), x.contiguous()
+def wgrad3x3(g, x, xs=None, out_mul=1.0):
+    """gw [Cout,Cin,3,3] = out_mul * d/dW of conv2d(xs * x, W, stride 1, padding 1) given g = dL/dy (hav_conv3x3_wgrad_mod: split-fp16 MFMA,
+    fp32-class; both operands under the power-of-two range control: g is gradient-sized, x whatever the activations are).  xs [B,Cin]:
+    the modulation of a ModulatedConv2d (None: plain)."""
+    g, x, xs = g.contiguous(), x.contiguous(), _c(xs)
     B, Cout, H, W = g.shape
     Cin = x.shape[1]
     L = _lib.lib()
@@ -148,8 +161,8 @@ def wgrad3x3(g, x):
     with torch.cuda.device(g.device):
         st = _stream(g.device)
         g_amax, x_amax = _absmax(g, st), _absmax(x, st)
-        _lib.check(L.hav_conv3x3_wgrad(_p(gw), _p(g), _p(x), _p(scratch), _p(g_amax), _p(x_amax), B, Cin, Cout, H, W, st),
-                   "hav_conv3x3_wgrad")
+        _lib.check(L.hav_conv3x3_wgrad_mod(_p(gw), _p(g), _p(x), _p(xs), float(out_mul), _p(scratch), _p(g_amax), _p(x_amax), B, Cin, Cout,
+                                           H, W, st), "hav_conv3x3_wgrad_mod")
     return gw
 
 
@@ -199,6 +212,100 @@ class _Conv3x3Split(torch.autograd.Function):
 def conv3x3_autograd(x, w):
     """x [B,Cin,H,W], w [Cout,Cin,3,3] (already scaled): differentiable 3x3 / stride 1 / padding 1 convolution, see _Conv3x3Split."""
     return _Conv3x3Split.apply(x.contiguous(), w.contiguous())
+
+
+def block_eligible(x, weight):
+    """x [B,Cin,H,W], weight [Cout,Cin,3,3]: shapes for which the forward, the data gradient (the transposed convolution: Cin and Cout
+    swap roles) and the weight gradient of fused_block all run on this library's kernels."""
+    if not eligible(x, weight):
+        return False
+    Cout, Cin = weight.shape[:2]
+    return Cin % 64 == 0 and Cout % 64 == 0 and os.environ.get("HAVATAR_FUSED_BLOCK", "1") != "0"
+
+
+class _FusedConvBlock(torch.autograd.Function):
+    """y = act(d * conv3x3(s * x, scale * W) + nw * noise + bias) * gain -- a whole StyledConv / ConvLayer (reference
+    model/styleUnet.py:165-310,326-368,565-599) as ONE autograd node: forward = pack + range control + hav_conv3x3_split; backward =
+    hav_conv_block_bwd (activation gradient, the d / bias / noise-weight gradients) -> the data gradient on hav_conv3x3_split with filters
+    packed by hav_conv3x3_pack_t -> hav_mod_input_bwd (s gradient, input scaling) -> hav_conv3x3_wgrad_mod (weight PARAMETER gradient).
+    About a dozen launches where the unfused statement under autograd ran ~40 (scale, modulate, demodulate, noise, bias, activation and
+    their gradients as separate ATen kernels).  W is the raw parameter; `scale` is folded into the packs and the weight gradient.
+    Under create_graph=True the backward restates the block with differentiable ATen ops; inside
+    conv2d_gradfix.no_weight_gradients() no weight gradient is formed."""
+
+    @staticmethod
+    def forward(ctx, x, W, s, d, noise, nw, bias, scale, slope, gain, act):
+        x, W = x.contiguous(), W.contiguous()
+        y = conv3x3(x, pack(W, scale), W.shape[0], s=s, d=d, noise=noise, noise_weight=nw, bias=bias, slope=slope, gain=gain, act=act)
+        ctx.save_for_backward(x, W, s, d, noise, nw, bias, y)
+        ctx.cfg = (float(scale), float(slope), float(gain), bool(act))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        from ..model.op import conv2d_gradfix
+        x, W, s, d, noise, nw, bias, y = ctx.saved_tensors
+        scale, slope, gain, act = ctx.cfg
+        need = ctx.needs_input_grad
+        B, Cout, H, Wd = y.shape
+        Cin = x.shape[1]
+        if torch.is_grad_enabled():          # create_graph=True: the block as differentiable ATen ops
+            with torch.enable_grad():
+                v = torch.nn.functional.conv2d(x * s.view(B, Cin, 1, 1) if s is not None else x, W * scale, padding=1)
+                if d is not None:
+                    v = v * d.view(B, Cout, 1, 1)
+                if noise is not None:
+                    v = v + nw * noise
+                if bias is not None:
+                    v = v + bias.view(1, -1, 1, 1)
+                if act:
+                    v = torch.nn.functional.leaky_relu(v, slope) * gain
+                slots = {0: x, 1: W, 2: s, 3: d, 5: nw, 6: bias}
+                if conv2d_gradfix.weight_gradients_disabled:
+                    slots.pop(1)
+                idx = [k for k, t in slots.items() if t is not None and need[k] and t.requires_grad]
+                got = torch.autograd.grad(v, [slots[k] for k in idx], g, create_graph=True, allow_unused=True) if idx else ()
+            out = [None] * 11
+            for k, gk in zip(idx, got):
+                out[k] = gk
+            return tuple(out)
+        g = g.contiguous()
+        L = _lib.lib()
+        dev = y.device
+        gc = torch.empty_like(y)
+        sums = torch.empty(B * Cout * 3, dtype=torch.float32, device=dev)
+        gd = torch.empty(B, Cout, dtype=torch.float32, device=dev) if (d is not None and need[3]) else None
+        gb = torch.empty(Cout, dtype=torch.float32, device=dev) if (bias is not None and need[6]) else None
+        gnw = torch.empty(1, dtype=torch.float32, device=dev) if (noise is not None and nw is not None and need[5]) else None
+        nb = 1 if (noise is not None and B > 1 and noise.numel() == B * H * Wd) else 0
+        with torch.cuda.device(dev):
+            st = _stream(dev)
+            _lib.check(L.hav_conv_block_bwd(_p(gc), _p(gd), _p(gb), _p(gnw), _p(sums), _p(g), _p(y), _p(d), _p(noise), _p(nw), _p(bias), slope, gain,
+                                            int(act), nb, B, Cout, H * Wd, st), "hav_conv_block_bwd")
+        gx = gs = None
+        if need[0] or (s is not None and need[2]):
+            gx = conv3x3(gc, pack_t(W, scale), Cin, act=False, autoscale=True)          # dL/d(s x): gradient-sized, see hav_absmax
+            if s is not None:
+                gs = torch.empty(B, Cin, dtype=torch.float32, device=dev)
+                with torch.cuda.device(dev):
+                    _lib.check(L.hav_mod_input_bwd(_p(gx), _p(gs), _p(x), _p(s), B, Cin, H * Wd, _stream(dev)), "hav_mod_input_bwd")
+        gW = None
+        if need[1] and not conv2d_gradfix.weight_gradients_disabled:
+            gW = wgrad3x3(gc, x, xs=s, out_mul=scale)
+        if gnw is not None and nw.shape != gnw.shape:
+            gnw = gnw.view(nw.shape)
+        if gb is not None and bias.shape != gb.shape:
+            gb = gb.view(bias.shape)
+        return (gx if need[0] else None), gW, (gs if need[2] else None), gd, None, gnw, gb, None, None, None, None
+
+
+def fused_block(x, W, scale, s=None, d=None, noise=None, noise_weight=None, bias=None, slope=0.2, gain=2 ** 0.5, act=True):
+    """see _FusedConvBlock; x [B,Cin,H,W], W [Cout,Cin,3,3] raw parameter, s [B,Cin], d [B,Cout], noise [1|B,1,H,W] (not differentiated),
+    noise_weight [1], bias [Cout]; callers check block_eligible(x, W)."""
+    f = lambda t: None if t is None else t.contiguous()
+    if noise is not None and noise_weight is None:
+        noise = None
+    return _FusedConvBlock.apply(x, W, f(s), f(d), f(noise), f(noise_weight), f(bias), scale, slope, gain, act)
 
 
 def upconv_eligible(x, weight):

@@ -174,6 +174,10 @@ int hav_composite_bwd(float* d_rf, const float* d_rgb, const float* d_acc, const
  * ------------------------------------------------------------------------------------------ */
 int64_t hav_conv3x3_packed_bytes(int Cout, int Cin);
 int hav_conv3x3_pack(void* packed, const float* w, int Cout, int Cin, float wmul, void* stream);
+/* hav_conv3x3_pack_t: the blob of the DATA GRADIENT of the convolution with filters w [Cout_w,Cin_w,3,3] -- the convolution with
+ * Cin_w output and Cout_w input channels and filters W'[i][o][t] = w[o][i][8 - t] -- packed straight from w (hav_conv3x3_packed_bytes(Cin_w,
+ * Cout_w) bytes; Cout_w % 16 == 0, Cin_w % 32 == 0). */
+int hav_conv3x3_pack_t(void* packed, const float* w, int Cout_w, int Cin_w, float wmul, void* stream);
 /* Maps with too few 64 x 128 output tiles to fill the GPU (32^2) split the channel range over 2-4 workgroups and add the slices up in a
  * second, deterministic pass: hav_conv3x3_scratch_bytes() bytes of caller scratch (0: not needed; NULL: never split). */
 int64_t hav_conv3x3_scratch_bytes(int B, int Cin, int Cout, int H, int W);
@@ -204,6 +208,22 @@ int hav_absmax(void* out_bits, const float* x, int64_t n, void* stream);
 int64_t hav_conv3x3_wgrad_scratch_bytes(int B, int Cin, int Cout, int H, int W);
 int hav_conv3x3_wgrad(float* gw /*[Cout,Cin,3,3]*/, const float* g /*[B,Cout,H,W]*/, const float* x /*[B,Cin,H,W]*/, void* scratch,
                       const void* g_amax, const void* x_amax, int B, int Cin, int Cout, int H, int W, void* stream);
+/* The same with the x operand modulated (xs [B,Cin] * x, NULL: plain) and the result multiplied by out_mul: the gradient of the raw
+ * ModulatedConv2d / EqualConv2d weight PARAMETER (out_mul = the layer's 1/sqrt(9 Cin) scale) given g = dL/d(conv output). */
+int hav_conv3x3_wgrad_mod(float* gw, const float* g, const float* x, const float* xs, float out_mul, void* scratch, const void* g_amax,
+                          const void* x_amax, int B, int Cin, int Cout, int H, int W, void* stream);
+/* Backward glue of one fused convolution block y = act(d * conv(s * x, W) + noise_weight * noise + bias) * gain under autograd (what
+ * ATen runs as ~20 small launches per layer: reference model/styleUnet.py:165-310 + model/op/fused_act.py:20-52 under autograd):
+ *   hav_conv_block_bwd   g = dL/dy, y = the block's output ->
+ *                        gc [B,Cout,HW] = d * g_pre  (g_pre = g * gain * act'(y): the gradient of the raw convolution output),
+ *                        gd [B,Cout] = sum_p g_pre * conv_raw,  gbias [Cout] = sum_{b,p} g_pre,  gnw [1] = sum g_pre * noise
+ *                        (each output nullable; d / noise / bias nullable as in the forward; the pre-activation is recovered from y,
+ *                        so act != 0 needs slope > 0 and gain > 0); sums_scratch: B * Cout * 3 floats; HW % 4 == 0
+ *   hav_mod_input_bwd    gxs = dL/d(s * x) in gx_inout ->  gs [B,Cin] = sum_p x * gxs,  gx_inout = s * gxs */
+int hav_conv_block_bwd(float* gc, float* gd, float* gbias, float* gnw, float* sums_scratch, const float* g, const float* y, const float* d,
+                       const float* noise, const float* noise_weight, const float* bias, float slope, float gain, int act, int noise_batched,
+                       int B, int Cout, int64_t HW, void* stream);
+int hav_mod_input_bwd(float* gx_inout, float* gs, const float* x, const float* s, int B, int Cin, int64_t HW, void* stream);
 /* The up-sampling StyledConv of the StyleGAN blocks (model/styleUnet.py:236-243: conv_transpose2d(x * s, W, stride 2) -> 4x4 FIR with
  * padding (1,1) -> demodulation -> noise -> bias -> leaky-ReLU) in two launches:
  *   hav_gemm_split     y[b, m, n] = sum_k A[m, k] * (s[b, k] * x[b, k, n])    split-fp16 matrix path, fp32-class (K % 32 == 0, N % 128 == 0;

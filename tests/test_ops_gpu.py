@@ -788,6 +788,50 @@ def test_demod_autograd_node_matches_the_aten_statement(B, Cin, Cout, k):
         assert (got.double().cpu() - r.detach()).abs().max().item() <= 2e-5 * r.detach().abs().max().item() + 1e-12, name
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,modulated,act", [(2, 64, 128, 32, True, True), (1, 128, 64, 64, True, True), (2, 64, 64, 32, False, True),
+                                                         (2, 128, 128, 32, False, False), (2, 64, 64, 32, "nodemod", True)])
+def test_fused_conv_block_node_matches_fp64_autograd(B, Cin, Cout, H, modulated, act):
+    """native/conv.py::_FusedConvBlock (a whole StyledConv / ConvLayer as one autograd node: hav_conv3x3_split forward, hav_conv_block_bwd +
+    hav_conv3x3_pack_t + hav_mod_input_bwd + hav_conv3x3_wgrad_mod backward) against the unfused statement under fp64 autograd
+    (reference model/styleUnet.py:165-310,326-368,565-599); yardstick = the same statement under fp32 autograd (ATen / MIOpen)."""
+    from havatar_amd.native import conv
+    g_ = torch.Generator(device=DEV).manual_seed(B + Cin + Cout + H)
+    r = lambda *sh: torch.randn(*sh, device=DEV, generator=g_)
+    x0, W0 = r(B, Cin, H, H), r(Cout, Cin, 3, 3)
+    scale = 1.0 / (Cin * 9) ** 0.5
+    s0 = 1.0 + 0.3 * r(B, Cin) if modulated else None
+    d0 = 0.5 + torch.rand(B, Cout, device=DEV, generator=g_) if modulated is True else None
+    noise = r(B if B > 1 else 1, 1, H, H) if modulated else None
+    nw0 = torch.full((1,), 0.37, device=DEV) if modulated else None
+    b0 = 0.2 * r(Cout)
+    go = r(B, Cout, H, H) * 1e-3
+
+    def run(dt, fused):
+        mk = lambda t: None if t is None else t.to(dt).clone().requires_grad_(True)
+        x, W, s, d, nw, b = mk(x0), mk(W0), mk(s0), mk(d0), mk(nw0), mk(b0)
+        if fused:
+            assert conv.block_eligible(x, W)
+            y = conv.fused_block(x, W, scale, s=s, d=d, noise=noise, noise_weight=nw, bias=b, act=act)
+        else:
+            v = torch.nn.functional.conv2d(x * s.view(B, Cin, 1, 1) if s is not None else x, W * scale, padding=1)
+            if d is not None:
+                v = v * d.view(B, Cout, 1, 1)
+            if noise is not None:
+                v = v + nw * noise.to(dt)
+            v = v + b.view(1, -1, 1, 1)
+            y = torch.nn.functional.leaky_relu(v, 0.2) * 2 ** 0.5 if act else v
+        y.backward(go.to(dt))
+        return [y.detach().double()] + [None if t is None else t.grad.double() for t in (x, W, s, d, nw, b)]
+
+    truth, f32, got = run(torch.float64, False), run(torch.float32, False), run(torch.float32, True)
+    for name, t_, f_, g in zip(("y", "gx", "gW", "gs", "gd", "gnw", "gb"), truth, f32, got):
+        if t_ is None:
+            assert g is None, name
+            continue
+        floor = (f_ - t_).abs().max().item()
+        assert (g - t_).abs().max().item() <= 4 * floor + 1e-5 * t_.abs().max().item(), (name, (g - t_).abs().max().item(), floor)
+
+
 def test_fused_training_nodes_support_double_backward_and_no_weight_gradients():
     """Stage two differentiates THROUGH a backward pass (create_graph=True: R1 on the discriminator and the path-length regulariser on
     the generator, reference utils/styleUnet_util.py:74,92) and switches weight gradients off around it
