@@ -1785,6 +1785,14 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                             wmax = fmaxf(wmax, wgt);
                             if (h == 0) slot[(size_t)ec * ENTF + H2F + 128 + j] = wgt;      // one writer per address
                             if (a.dbg_zfine && h == 0 && rayok) a.dbg_zfine[gr * S_fp + sidx] = zc;
+#ifdef HAV_DEBUG_DUMP3
+                            // diagnostic build (tools/stress_diag.py DUMP=3): the parked density head and the weight of every merged sample
+                            if (a.dbg_zfine && h == 0 && rayok) {
+                                const long long plane = (long long)a.p.B * a.p.R * S_fp;
+                                a.dbg_zfine[plane + gr * S_fp + sidx] = raw.w;
+                                a.dbg_zfine[2 * plane + gr * S_fp + sidx] = raw.x;
+                            }
+#endif
                         }
                     }
                 }

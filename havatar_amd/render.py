@@ -175,7 +175,7 @@ class RayMarcher:
         zf = None
         with torch.cuda.device(dev):
             if dbg_zfine and S_fp > 0:
-                zf = e(B * R, S_fp)
+                zf = e(int(dbg_zfine) * B * R, S_fp)          # (an int > 1: room for the extra planes a -DHAV_DEBUG_DUMP3 build writes)
                 p.dbg_zfine = zf.data_ptr()
             rc = L.hav_render_rays(C.byref(p), _ptr(rays), _ptr(bg), _ptr(inv_T), _ptr(self.planes_cl), _ptr(vol),
                                    _ptr(self.blob), _ptr(t_rand), _ptr(u_rand), _ptr(noise_c), _ptr(noise_f),

@@ -14,17 +14,30 @@ rm = RayMarcher(sc["nerf_scale"], sc["nerf_trans"], sc["skin_scale"], sc["skin_t
 rm.set_mlp(*[t(sc["mlp"][k]) for k in ("W1", "b1", "W2", "b2", "Wa", "ba", "Wf", "bf", "Wc", "bc")])
 rm.set_triplane(t(sc["planes"]))
 args = (rays, bg, t(sc["inv_T"]), t(sc["vol"]), 64, 16)
-names = ("rgb_c", "d_c", "a_c", "wmax", "rgb_f", "d_f", "a_f")
+DUMP = int(os.environ.get("DUMP", "0"))          # 1: also compare the merged fine depths; 3: + the parked density / red heads (-DHAV_DEBUG_DUMP3 build)
+names = ("rgb_c", "d_c", "a_c", "wmax", "rgb_f", "d_f", "a_f") + (("dump",) if DUMP else ())
 for perturb in (True, False):
     def go():
         if rm.rng_counter is not None: rm.rng_counter.zero_()
-        return rm.render(*args, perturb=perturb, coarse_outputs=False)
+        return rm.render(*args, perturb=perturb, coarse_outputs=False, dbg_zfine=DUMP)
     ref = [o.clone() if o is not None else None for o in go()]
     nbad = 0
     for i in range(N):
         out = go(); torch.cuda.synchronize()
         for nm, a, b in zip(names, ref, out):
             if a is None or torch.equal(a, b): continue
+            if nm == "dump":          # [planes * rays, S_fp]: which plane (0 depths, 1 density head, 2 red head), which rays, first differing sample
+                S_fp = a.shape[1]
+                pl = a.reshape(DUMP, -1, S_fp); pb = b.reshape(DUMP, -1, S_fp)
+                for k in range(DUMP):
+                    dd = (pl[k] != pb[k])
+                    if dd.any():
+                        rr = torch.nonzero(dd.any(1)).flatten()
+                        first = [int(torch.nonzero(dd[r]).flatten()[0]) for r in rr[:8].tolist()]
+                        print("  launch %d dump plane %d: %d rays differ %s first differing merged sample %s, %d samples differ in ray %d" %
+                              (i, k, rr.numel(), rr[:8].tolist(), first, int(dd[rr[0]].sum()), int(rr[0])))
+                nbad += 1
+                continue
             d = (a - b).abs().reshape(a.shape[1], -1).amax(1)
             idx = torch.nonzero(d > 0).flatten()
             nbad += 1
