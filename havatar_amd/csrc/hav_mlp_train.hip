@@ -258,9 +258,12 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(float* __restrict__ rf,
     for (int t = wave; t < ntiles; t += nwaves) {
         // the weights are loop-invariant: opaque per-tile bases keep the compiler from hoisting ~200 fragment loads (800 VGPRs) out of
         // the tile loop and spilling them
-        const uint4* fr_ = fragp + lane;
-        const float* vec = vec_in;
-        asm volatile("" : "+v"(fr_), "+s"(vec));
+        // (the OFFSETS are made opaque, not the pointers: a pointer that has been through an asm statement loses its global address space
+        // and every access through it becomes a FLAT instruction -- 248 / 458 of them in these two kernels before round 3)
+        int fr_off = lane, vec_off = 0;
+        asm volatile("" : "+v"(fr_off), "+s"(vec_off));
+        const uint4* fr_ = fragp + fr_off;
+        const float* vec = vec_in + vec_off;
         TrainCtx C{fr_, vec, lane, j, h};
         const long long q = (long long)t * 32 + j;
         const bool valid = q < n;
@@ -333,9 +336,10 @@ __global__ void __launch_bounds__(256) mlp_bwd_data_kernel(float* __restrict__ d
         if (eHi >= 0 && eHi < 8) hi[eHi >> 1] = 0x3F80u << (16 * (eHi & 1));
     }
     for (int t = wave; t < ntiles; t += nwaves) {
-        const uint4* fr_ = fragp + lane;          // opaque per tile (see mlp_fwd_kernel)
-        const float* vec = vec_in;
-        asm volatile("" : "+v"(fr_), "+s"(vec));
+        int fr_off = lane, vec_off = 0;          // opaque per tile (see mlp_fwd_kernel)
+        asm volatile("" : "+v"(fr_off), "+s"(vec_off));
+        const uint4* fr_ = fragp + fr_off;
+        const float* vec = vec_in + vec_off;
         TrainCtx C{fr_, vec, lane, j, h};
         const long long q = (long long)t * 32 + j;
         const bool valid = q < n;

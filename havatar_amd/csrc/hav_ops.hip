@@ -160,9 +160,11 @@ extern "C" int hav_fused_bias_act(void* out, const void* x, const void* b, const
 // instead of Cin/4), reduced through LDS.  Workgroup x = 0 also writes s.
 #define SD_OT 16
 #define SD_SL 64
-__device__ __forceinline__ void style_demod_body(float* __restrict__ s_out, float* __restrict__ d_out, const float* __restrict__ st,
-                                                 const float* __restrict__ mod_w, const float* __restrict__ mod_b,
-                                                 const float* __restrict__ wsq, float eps, int D, int Cin, int Cout, int bx, float* s_sq)
+// PF / PCF: pointer types of the outputs / read-only tables -- plain pointers for kernel arguments, address_space(1) pointers for those
+// read from the batched kernel's device table (generic to the compiler otherwise: FLAT loads and stores)
+template <typename PF, typename PCF>
+__device__ __forceinline__ void style_demod_body(PF s_out, PF d_out, const float* __restrict__ st, PCF mod_w, PCF mod_b, PCF wsq, float eps, int D,
+                                                 int Cin, int Cout, int bx, float* s_sq)
 {
     float* s_part = s_sq + Cin;
     const int tid = threadIdx.x;
@@ -221,7 +223,7 @@ __global__ void __launch_bounds__(SD_OT * SD_SL) style_demod_kernel(float* __res
 {
     extern __shared__ float s_sq[];                 // [Cin] s^2, then [SD_SL][SD_OT] partial sums
     const int b = blockIdx.y;
-    style_demod_body(s_out + (size_t)b * Cin, d_out ? d_out + (size_t)b * Cout : nullptr, style + (size_t)b * D, mod_w, mod_b, wsq, eps, D,
+    style_demod_body<float*, const float*>(s_out + (size_t)b * Cin, d_out ? d_out + (size_t)b * Cout : nullptr, style + (size_t)b * D, mod_w, mod_b, wsq, eps, D,
                      Cin, Cout, blockIdx.x, s_sq);
 }
 
@@ -237,8 +239,16 @@ __global__ void __launch_bounds__(SD_OT * SD_SL) style_demod_batched_kernel(cons
         if ((int)blockIdx.x >= layers[q].first_block) l = q;
     const HavStyleDemodLayer L = layers[l];
     const int b = blockIdx.y;
-    style_demod_body(L.s_out + (size_t)b * L.Cin, L.d_out ? L.d_out + (size_t)b * L.Cout : nullptr,
-                     styles + ((size_t)b * n_styles + L.style_index) * D, L.mod_w, L.mod_b, L.wsq, eps, D, L.Cin, L.Cout,
+    // pointers read from the table are generic to the compiler (FLAT loads / stores); they are device-memory pointers by contract
+    typedef __attribute__((address_space(1))) float gfloat;
+    typedef const __attribute__((address_space(1))) float cgfloat;
+    gfloat* s_out = (gfloat*)L.s_out;
+    gfloat* d_out = (gfloat*)L.d_out;
+    cgfloat* mod_w = (cgfloat*)L.mod_w;
+    cgfloat* mod_b = (cgfloat*)L.mod_b;
+    cgfloat* wsq = (cgfloat*)L.wsq;
+    style_demod_body<gfloat*, cgfloat*>(s_out + (size_t)b * L.Cin, d_out ? d_out + (size_t)b * L.Cout : (gfloat*)nullptr,
+                     styles + ((size_t)b * n_styles + L.style_index) * D, mod_w, mod_b, wsq, eps, D, L.Cin, L.Cout,
                      (int)blockIdx.x - L.first_block, s_sq);
 }
 

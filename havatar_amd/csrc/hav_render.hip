@@ -435,6 +435,36 @@ __device__ __forceinline__ float row16_scan_mul(float v)
     return v;
 }
 __device__ __forceinline__ float read_lane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+// value of the partner lane in the other half-wave (lane ^ 32): ds_bpermute_b32 (__shfl_xor).  gfx950 also has a VALU instruction for it,
+// v_permlane32_swap_b32 (measured, tools/ubench/permlane32.hip: lanes 32-63 of the first operand <-> lanes 0-31 of the second), which
+// would take the exchange off the LDS pipe -- but with ROCm 7.2 it is NOT usable here: results are right on small runs and differ
+// from launch to launch on a full frame (8 % of the launches of a 512^2 frame, lanes 16-31 of a tile; explicit s_nop 7 / 15 on both
+// sides of the instruction change the rate, they do not remove it: profiles/r03_stress_root_cause.txt).  HAV_HALF_SWAP_PERMLANE=1|2
+// keeps the experiment reproducible.
+#ifndef HAV_HALF_SWAP_PERMLANE
+#define HAV_HALF_SWAP_PERMLANE 0
+#endif
+__device__ __forceinline__ float half_swap(float v, int h)
+{
+#if HAV_HALF_SWAP_PERMLANE
+    const unsigned int u = __float_as_uint(v);
+    // measured (tools/ubench/permlane32.hip): the instruction swaps lanes 32-63 of its first operand with lanes 0-31 of its second
+#if HAV_HALF_SWAP_PERMLANE == 2          // experiment: the instruction from inline asm with explicit wait states on both sides
+    unsigned int x = u, y = u;
+    asm volatile("s_nop 7\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 7" : "+v"(x), "+v"(y));
+    return __uint_as_float(h ? x : y);
+#else
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);          // r[0]: lanes 32-63 = v[0-31];  r[1]: lanes 0-31 = v[32-63]
+    return __uint_as_float(h ? r[0] : r[1]);
+#endif
+#else
+    float r = __shfl_xor(v, 32, 64);
+#ifdef HAV_LDS_SETTLE
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7" : "+v"(r));          // experiment: let the returned value settle before its first reader
+#endif
+    return r;
+#endif
+}
 // orders this wave's LDS traffic (the per-wave scratch is private to a wave: no workgroup barrier needed)
 __device__ __forceinline__ void wave_lds_sync()
 {
@@ -661,11 +691,18 @@ __device__ __forceinline__ void split3(float v0, float v1, uint32_t& ph, uint32_
 // requirement) and ties all four tiles to it.
 // (In the variants that also carry the composited-hidden-unit accumulators the in-place form costs more in spills than it
 // saves in moves: they keep the two-operand form, INPLACE = false.)
-template <bool INPLACE>
+#ifndef HAV_RELU_NOPS
+#define HAV_RELU_NOPS "s_nop 15\n\ts_nop 7"
+#endif
+#ifndef HAV_RELU_INPLACE
+#define HAV_RELU_INPLACE 1      // 0: the lean variants use the two-operand form too (experiment)
+#endif
+template <bool INPLACE_>
 __device__ __forceinline__ void relu_tiles(f32x16 (&acc)[4])
 {
+    constexpr bool INPLACE = INPLACE_ && HAV_RELU_INPLACE;
     if (!INPLACE) {
-        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+        asm volatile(HAV_RELU_NOPS : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -676,7 +713,7 @@ __device__ __forceinline__ void relu_tiles(f32x16 (&acc)[4])
             }
         return;
     }
-    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+    asm volatile(HAV_RELU_NOPS : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -853,9 +890,20 @@ struct ProfCtx { unsigned long long t, acc[HAV_NPROF]; };
 
 // PREC = 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  PREC = 1: split-operand bf16 MFMA (3 x bf16 per operand, 6 products).
 // The evaluation ends by calling cont(acc2, hd0, hd1, hd2, hd3): the caller's per-tile epilogue (compositing, parking).
+#ifdef HAV_DEBUG_DUMP3
+// diagnostic build: checksums of this lane's values after the gather, after layer 1, after layer 2 and of the heads (self-check of
+// repeated evaluations, tools/stress_diag.py DUMP=10)
+#define DBG_ARG , float (&dcs)[12]
+#define DBG_PASS(x) , x
+#define DBG_SUM(dst, t4) do { float s_ = 0.f; for (int m_ = 0; m_ < 4; ++m_) for (int r_ = 0; r_ < 16; ++r_) s_ += (t4)[m_][r_]; dst = s_; } while (0)
+#else
+#define DBG_ARG
+#define DBG_PASS(x)
+#define DBG_SUM(dst, t4) do { } while (0)
+#endif
 template <int GQ, int PREC, bool BLK, bool LEAN = false, typename Cont>
 __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L, int b, float ox, float oy, float oz, float dx,
-                                            float dy, float dz, float z, Cont&& cont PROF_ARG)
+                                            float dy, float dz, float z, Cont&& cont PROF_ARG DBG_ARG)
 {
     // the lane id is opaque per tile: what derives from it (half-wave, fragment columns, strip slots) is then re-derived in one or two
     // ALU ops where it is used instead of being hoisted out of the sample loop as dozens of loop invariants, spilled and RELOADED
@@ -869,8 +917,11 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
     const float4* sW4 = L.sW4;
     // the bias reads are loop-invariant; an opaque base per tile keeps the compiler from hoisting 128 values out of the sample
     // loop (and spilling them)
-    const float4* sBt = L.sB;
-    asm volatile("" : "+v"(sBt));
+    // (the OFFSET is made opaque, not the pointer: a pointer that has been through an asm statement loses its LDS address space and
+    // every read through it becomes a FLAT load -- slower, and FLAT accesses complete out of order with the other memory counters)
+    int sb_off = 0;
+    asm volatile("" : "+s"(sb_off));
+    const float4* sBt = L.sB + sb_off;
     const int PR = a.p.plane_res, VR = a.p.vol_res;
     // ---- pts = o + d z; skinning field (model/Skinning_Field.py:77-95): half-wave h evaluates bone h ---------
     const float px = ox + dx * z, py = oy + dy * z, pz = oz + dz * z;
@@ -905,11 +956,18 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
                 }
         wmine = acc;
     }
-    const float wother = __shfl_xor(wmine, 32, 64);
+    const float wother = half_swap(wmine, h);
     const float w0 = h ? wother : wmine, w1 = h ? wmine : wother;
     const float den = (w0 + w1) + 1e-8f;
-    const float n0 = w0 / den, n1 = w1 / den;
+    float n0 = w0 / den, n1 = w1 / den;
+#ifdef HAV_DIV_SETTLE
+    asm volatile(HAV_DIV_SETTLE : "+v"(n0), "+v"(n1));          // experiment: wait states between the division's last instruction and its first reader
+#endif
     const float qx_ = n0 * px + n1 * p1x, qy_ = n0 * py + n1 * p1y, qz_ = n0 * pz + n1 * p1z;   // p'
+#ifdef HAV_DEBUG_DUMP3
+    dcs[4] = z; dcs[5] = wmine; dcs[6] = wother; dcs[7] = (qx_ + qy_) + qz_;
+    dcs[8] = den; dcs[9] = n0; dcs[10] = n1; dcs[11] = (px + py + pz) + (p1x + p1y + p1z);
+#endif
     TICK(1);
 
     // ---- layer 1 (model/nerf_model.py:104-108): bias + 8 projected tri-plane taps + PE columns on the MFMA ----
@@ -1001,6 +1059,9 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
     auto finish = [&](f32x16 (&acc1)[4]) {
         f32x16 acc2[4];
         float hd0, hd1, hd2, hd3;
+#ifdef HAV_DEBUG_DUMP3
+        DBG_SUM(dcs[0], acc1);
+#endif
         TICK(2);
         // ---- PE octaves 4h..4h+3 of this half-wave (model/network/embedder.py:32-61) ---------------------
         float pe[KPE_STEPS];
@@ -1042,6 +1103,9 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
             }
         }
         relu_tiles<LEAN>(acc1);
+#ifdef HAV_DEBUG_DUMP3
+        DBG_SUM(dcs[1], acc1);
+#endif
         TICK(4);
 
         __builtin_amdgcn_sched_barrier(0);
@@ -1086,6 +1150,9 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
             }
         }
         relu_tiles<LEAN>(acc2);
+#ifdef HAV_DEBUG_DUMP3
+        DBG_SUM(dcs[2], acc2);
+#endif
         mfma_unlock(L);
         TICK(5);
 
@@ -1132,13 +1199,16 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
             }
             hd0 = hA.x; hd1 = hA.y; hd2 = hB.x; hd3 = hB.y;
         }
-        hd0 += __shfl_xor(hd0, 32, 64); hd1 += __shfl_xor(hd1, 32, 64);
-        hd2 += __shfl_xor(hd2, 32, 64); hd3 += __shfl_xor(hd3, 32, 64);
+        hd0 += half_swap(hd0, h); hd1 += half_swap(hd1, h);
+        hd2 += half_swap(hd2, h); hd3 += half_swap(hd3, h);
         {
             const auto b4 = __builtin_amdgcn_raw_buffer_load_b128(L.wrs, 0, OFF_B4 * 4, 0);
             hd0 += __uint_as_float(b4[0]); hd1 += __uint_as_float(b4[1]); hd2 += __uint_as_float(b4[2]); hd3 += __uint_as_float(b4[3]);
         }
         TICK(6);
+#ifdef HAV_DEBUG_DUMP3
+        dcs[3] = (hd0 + hd1) + (hd2 + hd3);
+#endif
         cont(acc2, hd0, hd1, hd2, hd3);
     };
     f32x16 acc1[4];
@@ -1267,6 +1337,9 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
 #ifdef HAV_PROFILE
                 ProfCtx P;
 #endif
+#ifdef HAV_DEBUG_DUMP3
+                float dbg_dummy[12];
+#endif
                 sample_eval<16, 0, false>(a, L, b, ox, oy, oz, dx, dy, dz, z, [&](f32x16 (&acc2)[4], float hd0, float hd1, float hd2, float hd3) {
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- volume_render_radiance_field (utils/nerf_util.py:28-73) -------------------------------
@@ -1348,7 +1421,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                         racc[R_WMAX] = fmaxf(racc[R_WMAX], v5);
                     }
                 }
-                } PROF_PASS);
+                } PROF_PASS DBG_PASS(dbg_dummy));
                 wave_lds_sync();
             }   // tiles
 
@@ -1610,6 +1683,16 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
 #endif
         auto park = [&](int e, const f32x16 (&v)[4], float r0, float r1, float r2, float r3) {       // entry e of this block's slot
             float4* H2 = reinterpret_cast<float4*>(slot + (size_t)e * ENTF);
+#ifdef HAV_DEBUG_DUMP3
+            if (a.dbg_zfine && rayok) {          // diagnostic build: a checksum of this lane's 64 hidden units per (ray, entry, half-wave)
+                float cs = 0.f;
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cs += v[m][r];
+                a.dbg_zfine[(4 + h) * ((long long)a.p.B * a.p.R * a.S_fp) + gr * a.S_fp + e] = cs;
+            }
+#endif
             if (FEATPARK) {
                 f32x16 ft[2];
 #pragma unroll
@@ -1720,11 +1803,30 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                 // ---- stage 1: the S_f new samples (same k for all 32 rays), parked behind the even coarse entries ----
                 for (int k = 0; k < S_f; ++k) {
                     TICK(0);
+#ifdef HAV_DEBUG_DUMP3
+                    float cA[12], cB[12];
                     sample_eval<(CACHE == 2 ? HAV_GQ2 : 8), PREC, true, CACHE == 2>(a, L, b, ox, oy, oz, dx, dy, dz, s_n[k * 32 + j],
                                                                  [&](f32x16 (&acc2)[4], float hd0, float hd1, float hd2, float hd3) {
                         __builtin_amdgcn_sched_barrier(0);
+                    } PROF_PASS, cA);
+#endif
+                    float zk = s_n[k * 32 + j];
+#ifdef HAV_LDS_SETTLE
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7" : "+v"(zk));
+#endif
+                    sample_eval<(CACHE == 2 ? HAV_GQ2 : 8), PREC, true, CACHE == 2>(a, L, b, ox, oy, oz, dx, dy, dz, zk,
+                                                                 [&](f32x16 (&acc2)[4], float hd0, float hd1, float hd2, float hd3) {
+                        __builtin_amdgcn_sched_barrier(0);
                         park(S_half + k, acc2, hd0, hd1, hd2, hd3);
-                    } PROF_PASS);
+                    } PROF_PASS DBG_PASS(cB));
+#ifdef HAV_DEBUG_DUMP3
+                    if (a.dbg_zfine && rayok) {          // self-check: the same tile evaluated twice; which stage differs first
+                        const int code = (cA[0] != cB[0] ? 1 : 0) | (cA[1] != cB[1] ? 2 : 0) | (cA[2] != cB[2] ? 4 : 0) | (cA[3] != cB[3] ? 8 : 0) |
+                                         (cA[4] != cB[4] ? 16 : 0) | (cA[5] != cB[5] ? 32 : 0) | (cA[6] != cB[6] ? 64 : 0) | (cA[7] != cB[7] ? 128 : 0) |
+                                         (cA[8] != cB[8] ? 256 : 0) | (cA[9] != cB[9] ? 512 : 0) | (cA[10] != cB[10] ? 1024 : 0) | (cA[11] != cB[11] ? 2048 : 0);
+                        a.dbg_zfine[(6 + h) * ((long long)a.p.B * a.p.R * a.S_fp) + gr * a.S_fp + S_half + k] = (float)code;
+                    }
+#endif
                     TICK(7);
                 }
                 RAY_FENCE();
@@ -1791,6 +1893,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                                 const long long plane = (long long)a.p.B * a.p.R * S_fp;
                                 a.dbg_zfine[plane + gr * S_fp + sidx] = raw.w;
                                 a.dbg_zfine[2 * plane + gr * S_fp + sidx] = raw.x;
+                                a.dbg_zfine[3 * plane + gr * S_fp + sidx] = (float)ec;          // which entry: < S_half = coarse sample 2 e, else new sample e - S_half
                             }
 #endif
                         }
@@ -1832,6 +1935,13 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
 
             for (int s = 0; s < ((CACHE && pass == 1) ? 0 : S); ++s) {
                 TICK(0);
+#ifdef HAV_DEBUG_DUMP3
+                float cA[12], cB[12];
+                sample_eval<(CACHE == 2 ? HAV_GQ2 : 8), PREC, true, CACHE == 2>(a, L, b, ox, oy, oz, dx, dy, dz, z,
+                                                             [&](f32x16 (&acc2)[4], float hd0, float hd1, float hd2, float hd3) {
+                    __builtin_amdgcn_sched_barrier(0);
+                } PROF_PASS, cA);
+#endif
                 sample_eval<(CACHE == 2 ? HAV_GQ2 : 8), PREC, true, CACHE == 2>(a, L, b, ox, oy, oz, dx, dy, dz, z,
                                                              [&](f32x16 (&acc2)[4], float hd0, float hd1, float hd2, float hd3) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -1866,7 +1976,15 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                     znext = pass == 0 ? z_coarse<RM>(a, gr, rkey, s + 2, near, far) : next_fine();
                     dist = znext - z;
                 }
-                } PROF_PASS);
+                } PROF_PASS DBG_PASS(cB));
+#ifdef HAV_DEBUG_DUMP3
+                if (a.dbg_zfine && rayok && pass == 0 && a.S_fp > 0) {          // coarse tiles: even s -> planes 6/7 at entry s/2, odd s -> planes 8/9
+                    const int code = (cA[0] != cB[0] ? 1 : 0) | (cA[1] != cB[1] ? 2 : 0) | (cA[2] != cB[2] ? 4 : 0) | (cA[3] != cB[3] ? 8 : 0) |
+                                     (cA[4] != cB[4] ? 16 : 0) | (cA[5] != cB[5] ? 32 : 0) | (cA[6] != cB[6] ? 64 : 0) | (cA[7] != cB[7] ? 128 : 0) |
+                                     (cA[8] != cB[8] ? 256 : 0) | (cA[9] != cB[9] ? 512 : 0) | (cA[10] != cB[10] ? 1024 : 0) | (cA[11] != cB[11] ? 2048 : 0);
+                    a.dbg_zfine[(6 + 2 * (s & 1) + h) * ((long long)a.p.B * a.p.R * a.S_fp) + gr * a.S_fp + (s >> 1)] = (float)code;
+                }
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 TICK(7);
             }

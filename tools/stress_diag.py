@@ -16,7 +16,7 @@ rm.set_triplane(t(sc["planes"]))
 args = (rays, bg, t(sc["inv_T"]), t(sc["vol"]), 64, 16)
 DUMP = int(os.environ.get("DUMP", "0"))          # 1: also compare the merged fine depths; 3: + the parked density / red heads (-DHAV_DEBUG_DUMP3 build)
 names = ("rgb_c", "d_c", "a_c", "wmax", "rgb_f", "d_f", "a_f") + (("dump",) if DUMP else ())
-for perturb in (True, False):
+for perturb in ((True,) if os.environ.get("ONLY") == "perturb" else (True, False)):
     def go():
         if rm.rng_counter is not None: rm.rng_counter.zero_()
         return rm.render(*args, perturb=perturb, coarse_outputs=False, dbg_zfine=DUMP)
@@ -24,6 +24,20 @@ for perturb in (True, False):
     nbad = 0
     for i in range(N):
         out = go(); torch.cuda.synchronize()
+        if DUMP >= 10:          # self-check planes of the -DHAV_DEBUG_DUMP3 build: every tile was evaluated twice, code != 0 = the two runs differ
+            zf = out[-1]; S_fp = zf.shape[1]
+            pl = zf.reshape(DUMP, -1, S_fp)
+            codes = torch.cat([pl[6], pl[7], pl[8][:, :32], pl[9][:, :32]], 1)
+            bad = torch.nonzero(codes != 0)
+            if bad.numel():
+                nself = locals().get("nself", 0) + 1
+                rays_ = sorted(set(bad[:, 0].tolist()))
+                print("  launch %d SELF-CHECK: %d (ray, tile, half) mismatches in rays %s lanes %s" % (i, bad.shape[0], rays_[:8], sorted(set(r % 32 for r in rays_))))
+                for r, c in bad[:6].tolist():
+                    col = c; plane = 6 + (0 if col < S_fp else 1 if col < 2 * S_fp else 2 if col < 2 * S_fp + 32 else 3)
+                    ent = col if col < S_fp else col - S_fp if col < 2 * S_fp else col - 2 * S_fp if col < 2 * S_fp + 32 else col - 2 * S_fp - 32
+                    print("    ray %d lane %d half %d %s %d: stage mask %d (1 gather, 2 layer 1, 4 layer 2, 8 heads, 16 z, 32 own bone weight, 64 partner bone weight, 128 warped point, 256 den, 512 n0, 1024 n1, 2048 p + p1)" %
+                          (r, r % 32, plane & 1, "entry" if plane < 8 else "odd coarse sample after entry", ent, int(codes[r, c])))
         for nm, a, b in zip(names, ref, out):
             if a is None or torch.equal(a, b): continue
             if nm == "dump":          # [planes * rays, S_fp]: which plane (0 depths, 1 density head, 2 red head), which rays, first differing sample
@@ -36,6 +50,17 @@ for perturb in (True, False):
                         first = [int(torch.nonzero(dd[r]).flatten()[0]) for r in rr[:8].tolist()]
                         print("  launch %d dump plane %d: %d rays differ %s first differing merged sample %s, %d samples differ in ray %d" %
                               (i, k, rr.numel(), rr[:8].tolist(), first, int(dd[rr[0]].sum()), int(rr[0])))
+                        if k == 1 and DUMP >= 4:          # rays whose depths agree: the differing parked values name the entry (plane 3)
+                            same_z = [r for r in rr.tolist() if not (pl[0][r] != pb[0][r]).any()]
+                            for r in same_z[:6]:
+                                ix = torch.nonzero(dd[r]).flatten().tolist()
+                                ents = [int(pl[3][r][q]) for q in ix]
+                                print("    ray %d (lane %d): depths equal; density head differs at merged samples %s = entries %s: %s vs %s" %
+                                      (r, r % 32, ix, ents, [float(pl[1][r][q]) for q in ix], [float(pb[1][r][q]) for q in ix]))
+                                if DUMP >= 6:          # planes 4, 5: checksum of the hidden units of (ray, ENTRY) per half-wave, indexed by entry
+                                    for e_ in ents:
+                                        print("      hidden-unit checksums of entry %d: h=0 %r vs %r   h=1 %r vs %r" %
+                                              (e_, float(pl[4][r][e_]), float(pb[4][r][e_]), float(pl[5][r][e_]), float(pb[5][r][e_])))
                 nbad += 1
                 continue
             d = (a - b).abs().reshape(a.shape[1], -1).amax(1)
