@@ -47,6 +47,19 @@ CFG3_NOTE = ("cfg3: one step = a batch of %d frames dealt round-robin to %d rank
              "finished RGB frame of round r ([3,512,512] fp32 = 3.1 MB per rank) is all-gathered over RCCL while round r+1 renders")
 
 
+
+def emit_line(obj):
+    """The ONE JSON line of the contract, as the LAST line of stdout: RCCL (NCCL_DEBUG=VERSION is exported on the GPU boxes) writes its
+    version banner through C stdio, which sits in libc's buffer until exit and would land behind a plain print().  Flush libc first."""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(obj), flush=True)
+
+
 def cpu_model():
     try:
         for ln in open("/proc/cpuinfo"):
@@ -188,7 +201,7 @@ def run_cfg5(args):
                                 "hav_mlp_bwd_data / hav_mlp_bwd_weights); achieved = 3 x 94848 FLOP x queries / their summed time; at 917 504 "
                                 "queries the contraction is small (261 GFLOP) and the kernels stream X / dX / activations: both fractions "
                                 "are reported"}}
-    print(json.dumps(res))
+    emit_line(res)
 
 
 def main():
@@ -356,7 +369,7 @@ def main():
     if cpu:
         # plumbing mode: no kernels to profile; report the contract fields and what the collective moved
         if rank == 0:
-            print(json.dumps({"metric": "rendered frames/sec @%d^2, 64 samples/ray" % H, "value": round(fps, 4), "unit": "frames/s",
+            emit_line(({"metric": "rendered frames/sec @%d^2, 64 samples/ray" % H, "value": round(fps, 4), "unit": "frames/s",
                               "n_gpus": 0, "ranks": world, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
                               "scaling": "strong" if args.workload == "cfg3" else "weak", "vs_baseline": None, "dtype": "f32",
@@ -573,8 +586,12 @@ def main():
                                              "%.1f s measured, scaled to a full frame" % (rows, H, rows * W, took),
                                    "one_core": {"value": round(1.0 / est1, 6), "unit": "frames/s", "cores": 1,
                                                 "sample": "%d image row(s) (%d rays), 1 thread, %.1f s measured, scaled to a full frame" % (rows1, rows1 * W, took1)}}
-        print(json.dumps(res))
+        if dist.is_initialized():          # first, so that nothing the communicator prints on its way out lands behind the line
+            dist.barrier()
+            dist.destroy_process_group()
+        emit_line(res)
     if dist.is_initialized():
+        dist.barrier()
         dist.destroy_process_group()
 
 
