@@ -444,6 +444,13 @@ __device__ __forceinline__ float read_lane(float v, int l) { return __int_as_flo
 #ifndef HAV_HALF_SWAP_PERMLANE
 #define HAV_HALF_SWAP_PERMLANE 0
 #endif
+// 1: the two bone-weight quotients of sample_eval as one v_rcp_f32 + a Newton step (<= 1 ulp from the IEEE quotient).  0 = the compiler's
+// IEEE expansion (v_div_scale / v_div_fmas / v_div_fixup, two of them interleaved, VCC and SGPR-pair traffic in between): with ROCm 7.2 on
+// gfx950 that sequence is where the rare run-to-run difference of DESIGN.md 3.12 comes from -- identical inputs, a different warped point
+// in lanes 48-63 of one tile; on a box where the IEEE form differed in 22 % of the launches of a 512^2 frame this form gave 0 of 14 000.
+#ifndef HAV_FAST_DIV
+#define HAV_FAST_DIV 1
+#endif
 __device__ __forceinline__ float half_swap(float v, int h)
 {
 #if HAV_HALF_SWAP_PERMLANE
@@ -890,7 +897,16 @@ struct ProfCtx { unsigned long long t, acc[HAV_NPROF]; };
 
 // PREC = 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  PREC = 1: split-operand bf16 MFMA (3 x bf16 per operand, 6 products).
 // The evaluation ends by calling cont(acc2, hd0, hd1, hd2, hd3): the caller's per-tile epilogue (compositing, parking).
-#ifdef HAV_DEBUG_DUMP3
+#ifdef HAV_DEBUG_TRACE
+// diagnostic build (tools/stress_diag.py DUMP=41): twelve per-lane stage values of EVERY tile evaluation go to a trace buffer
+// [12 quantities x 2 half-waves][rays][80 slots] behind the merged-depth dump, to be compared between launches on the host:
+// 0 gather checksum, 1 after layer 1, 2 after layer 2, 3 heads, 4 depth, 5 own bone weight, 6 partner's, 7 warped point, 8 den, 9 n0, 10 n1, 11 p + p1
+struct DbgTrace { float* p; long long plane; };
+#define DBG_ARG , DbgTrace dtr
+#define DBG_PASS(x) , x
+#define DBG_SUM(dst, t4) do { float s_ = 0.f; for (int m_ = 0; m_ < 4; ++m_) for (int r_ = 0; r_ < 16; ++r_) s_ += (t4)[m_][r_]; dst = s_; } while (0)
+#define DBG_PUT(i, v) do { if (dtr.p) dtr.p[(i) * dtr.plane] = (v); } while (0)
+#elif defined(HAV_DEBUG_DUMP3)
 // diagnostic build: checksums of this lane's values after the gather, after layer 1, after layer 2 and of the heads (self-check of
 // repeated evaluations, tools/stress_diag.py DUMP=10)
 #define DBG_ARG , float (&dcs)[12]
@@ -901,10 +917,23 @@ struct ProfCtx { unsigned long long t, acc[HAV_NPROF]; };
 #define DBG_PASS(x)
 #define DBG_SUM(dst, t4) do { } while (0)
 #endif
+#ifndef HAV_ARGS_RELOAD
+#define HAV_ARGS_RELOAD 0
+#endif
 template <int GQ, int PREC, bool BLK, bool LEAN = false, typename Cont>
-__device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L, int b, float ox, float oy, float oz, float dx,
+__device__ __forceinline__ void sample_eval(const MarchArgs& a_in, const LaneCtx& L, int b, float ox, float oy, float oz, float dx,
                                             float dy, float dz, float z, Cont&& cont PROF_ARG DBG_ARG)
 {
+#if HAV_ARGS_RELOAD
+    // experiment: the ~25 scalars of the argument block this function uses are re-read from the kernarg segment per tile (s_load, scalar
+    // cache) instead of living in SGPRs across the tile loop -- where they push the kernel past its SGPR budget and get spilled to VGPR
+    // lanes (v_writelane / v_readlane).  The OFFSET is opaque, not the pointer (address space, see the bias pointer below).
+    int a_off = 0;
+    asm volatile("" : "+s"(a_off));
+    const MarchArgs& a = *reinterpret_cast<const MarchArgs*>(reinterpret_cast<const char*>(&a_in) + a_off);
+#else
+    const MarchArgs& a = a_in;
+#endif
     // the lane id is opaque per tile: what derives from it (half-wave, fragment columns, strip slots) is then re-derived in one or two
     // ALU ops where it is used instead of being hoisted out of the sample loop as dozens of loop invariants, spilled and RELOADED
     int lane = L.lane;
@@ -920,7 +949,11 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
     // (the OFFSET is made opaque, not the pointer: a pointer that has been through an asm statement loses its LDS address space and
     // every read through it becomes a FLAT load -- slower, and FLAT accesses complete out of order with the other memory counters)
     int sb_off = 0;
+#ifdef HAV_SBOFF_SGPR
     asm volatile("" : "+s"(sb_off));
+#else
+    asm volatile("" : "+v"(sb_off));
+#endif
     const float4* sBt = L.sB + sb_off;
     const int PR = a.p.plane_res, VR = a.p.vol_res;
     // ---- pts = o + d z; skinning field (model/Skinning_Field.py:77-95): half-wave h evaluates bone h ---------
@@ -959,12 +992,22 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
     const float wother = half_swap(wmine, h);
     const float w0 = h ? wother : wmine, w1 = h ? wmine : wother;
     const float den = (w0 + w1) + 1e-8f;
+#if HAV_FAST_DIV
+    // one reciprocal + one Newton step (<= 1 ulp from the IEEE quotient) instead of two v_div_scale / v_div_fmas / v_div_fixup sequences
+    float rden = __builtin_amdgcn_rcpf(den);
+    rden = rden * (2.0f - den * rden);
+    float n0 = w0 * rden, n1 = w1 * rden;
+#else
     float n0 = w0 / den, n1 = w1 / den;
+#endif
 #ifdef HAV_DIV_SETTLE
     asm volatile(HAV_DIV_SETTLE : "+v"(n0), "+v"(n1));          // experiment: wait states between the division's last instruction and its first reader
 #endif
     const float qx_ = n0 * px + n1 * p1x, qy_ = n0 * py + n1 * p1y, qz_ = n0 * pz + n1 * p1z;   // p'
-#ifdef HAV_DEBUG_DUMP3
+#ifdef HAV_DEBUG_TRACE
+    DBG_PUT(4, z); DBG_PUT(5, wmine); DBG_PUT(6, wother); DBG_PUT(7, (qx_ + qy_) + qz_);
+    DBG_PUT(8, den); DBG_PUT(9, n0); DBG_PUT(10, n1); DBG_PUT(11, (px + py + pz) + (p1x + p1y + p1z));
+#elif defined(HAV_DEBUG_DUMP3)
     dcs[4] = z; dcs[5] = wmine; dcs[6] = wother; dcs[7] = (qx_ + qy_) + qz_;
     dcs[8] = den; dcs[9] = n0; dcs[10] = n1; dcs[11] = (px + py + pz) + (p1x + p1y + p1z);
 #endif
@@ -1059,7 +1102,9 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
     auto finish = [&](f32x16 (&acc1)[4]) {
         f32x16 acc2[4];
         float hd0, hd1, hd2, hd3;
-#ifdef HAV_DEBUG_DUMP3
+#ifdef HAV_DEBUG_TRACE
+        { float s0_; DBG_SUM(s0_, acc1); DBG_PUT(0, s0_); }
+#elif defined(HAV_DEBUG_DUMP3)
         DBG_SUM(dcs[0], acc1);
 #endif
         TICK(2);
@@ -1103,7 +1148,9 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
             }
         }
         relu_tiles<LEAN>(acc1);
-#ifdef HAV_DEBUG_DUMP3
+#ifdef HAV_DEBUG_TRACE
+        { float s1_; DBG_SUM(s1_, acc1); DBG_PUT(1, s1_); }
+#elif defined(HAV_DEBUG_DUMP3)
         DBG_SUM(dcs[1], acc1);
 #endif
         TICK(4);
@@ -1150,7 +1197,9 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
             }
         }
         relu_tiles<LEAN>(acc2);
-#ifdef HAV_DEBUG_DUMP3
+#ifdef HAV_DEBUG_TRACE
+        { float s2_; DBG_SUM(s2_, acc2); DBG_PUT(2, s2_); }
+#elif defined(HAV_DEBUG_DUMP3)
         DBG_SUM(dcs[2], acc2);
 #endif
         mfma_unlock(L);
@@ -1206,7 +1255,9 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a, const LaneCtx& L
             hd0 += __uint_as_float(b4[0]); hd1 += __uint_as_float(b4[1]); hd2 += __uint_as_float(b4[2]); hd3 += __uint_as_float(b4[3]);
         }
         TICK(6);
-#ifdef HAV_DEBUG_DUMP3
+#ifdef HAV_DEBUG_TRACE
+        DBG_PUT(3, (hd0 + hd1) + (hd2 + hd3));
+#elif defined(HAV_DEBUG_DUMP3)
         dcs[3] = (hd0 + hd1) + (hd2 + hd3);
 #endif
         cont(acc2, hd0, hd1, hd2, hd3);
@@ -1337,7 +1388,9 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
 #ifdef HAV_PROFILE
                 ProfCtx P;
 #endif
-#ifdef HAV_DEBUG_DUMP3
+#ifdef HAV_DEBUG_TRACE
+                DbgTrace dbg_dummy{nullptr, 0};
+#elif defined(HAV_DEBUG_DUMP3)
                 float dbg_dummy[12];
 #endif
                 sample_eval<16, 0, false>(a, L, b, ox, oy, oz, dx, dy, dz, z, [&](f32x16 (&acc2)[4], float hd0, float hd1, float hd2, float hd3) {
@@ -1659,6 +1712,13 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
         const float dn = sqrtf(dx * dx + dy * dy + dz * dz);
         float* wpark = a.out.rgb_fine ? a.out.rgb_fine + gr * 67 : nullptr;   // this ray's parking row for w[0..S_c)
         RKey rkey = RANDOM ? rng_ray_key(a, gr, call_off) : RKey{0u, 0u, 0u, a.step_c};
+#ifdef HAV_DEBUG_TRACE
+        // trace slot of (this lane's ray, tile): behind the [rays][S_fp] depth dump; 80 slots per ray = S_c coarse tiles + S_f new samples
+        const long long dbg_plane_ = (long long)a.p.B * a.p.R * 80;
+#define DBG_TILE(slot_) DbgTrace{(a.dbg_zfine && rayok && CACHE == 2 && a.p.S_c + a.p.S_f <= 80) ? a.dbg_zfine + (long long)a.p.B * a.p.R * a.S_fp + (12 * h) * dbg_plane_ + gr * 80 + (slot_) : nullptr, dbg_plane_}
+#elif defined(HAV_DEBUG_DUMP3)
+#define DBG_TILE(slot_) cB
+#endif
         // Register hygiene: the phases of a block (sample loop | resampling | stage 1 | A | B | stores) all start from these four
         // per-ray values.  Left transparent, the compiler shares sub-expressions BETWEEN phases (coarse depths of fixed indices,
         // output addresses, hash pieces): dozens of values that then live -- spilled -- through the sample loops.  An opaque fence
@@ -1818,7 +1878,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                                                                  [&](f32x16 (&acc2)[4], float hd0, float hd1, float hd2, float hd3) {
                         __builtin_amdgcn_sched_barrier(0);
                         park(S_half + k, acc2, hd0, hd1, hd2, hd3);
-                    } PROF_PASS DBG_PASS(cB));
+                    } PROF_PASS DBG_PASS(DBG_TILE(S_c + k)));
 #ifdef HAV_DEBUG_DUMP3
                     if (a.dbg_zfine && rayok) {          // self-check: the same tile evaluated twice; which stage differs first
                         const int code = (cA[0] != cB[0] ? 1 : 0) | (cA[1] != cB[1] ? 2 : 0) | (cA[2] != cB[2] ? 4 : 0) | (cA[3] != cB[3] ? 8 : 0) |
@@ -1976,7 +2036,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                     znext = pass == 0 ? z_coarse<RM>(a, gr, rkey, s + 2, near, far) : next_fine();
                     dist = znext - z;
                 }
-                } PROF_PASS DBG_PASS(cB));
+                } PROF_PASS DBG_PASS(DBG_TILE(s)));
 #ifdef HAV_DEBUG_DUMP3
                 if (a.dbg_zfine && rayok && pass == 0 && a.S_fp > 0) {          // coarse tiles: even s -> planes 6/7 at entry s/2, odd s -> planes 8/9
                     const int code = (cA[0] != cB[0] ? 1 : 0) | (cA[1] != cB[1] ? 2 : 0) | (cA[2] != cB[2] ? 4 : 0) | (cA[3] != cB[3] ? 8 : 0) |

@@ -40,6 +40,23 @@ for perturb in ((True,) if os.environ.get("ONLY") == "perturb" else (True, False
                           (r, r % 32, plane & 1, "entry" if plane < 8 else "odd coarse sample after entry", ent, int(codes[r, c])))
         for nm, a, b in zip(names, ref, out):
             if a is None or torch.equal(a, b): continue
+            if nm == "dump" and DUMP == 41:          # -DHAV_DEBUG_TRACE build: [depth dump][12 quantities x 2 halves][rays][80 slots]
+                S_fp = a.shape[1]; nr = a.numel() // (41 * S_fp)
+                ta = a.flatten()[nr * S_fp:].reshape(2, 12, nr, 80); tb = b.flatten()[nr * S_fp:].reshape(2, 12, nr, 80)
+                dd = (ta != tb)
+                tiles = torch.nonzero(dd.any(0).any(0))          # (ray, slot)
+                order = [4, 11, 5, 6, 8, 9, 10, 7, 0, 1, 2, 3]
+                qn = {0: "gather", 1: "layer1", 2: "layer2", 3: "heads", 4: "z", 5: "own_w", 6: "partner_w", 7: "q", 8: "den", 9: "n0", 10: "n1", 11: "p+p1"}
+                slots = sorted(set(tiles[:, 1].tolist())); rays_ = sorted(set(tiles[:, 0].tolist()))
+                print("  launch %d TRACE: %d (ray, tile) differ; slots %s (coarse s < 64, new sample 64 + k); lanes %s" %
+                      (i, tiles.shape[0], slots[:10], sorted(set(r % 32 for r in rays_))))
+                s0 = slots[0]
+                for r in [x for x in rays_ if dd[:, :, x, s0].any()][:4]:
+                    for hh in (0, 1):
+                        w = [qn[q] for q in order if bool(dd[hh, q, r, s0])]
+                        print("    ray %d lane %d half %d slot %d: differing quantities in order of computation: %s" % (r, r % 32, hh, s0, w))
+                nbad += 1
+                continue
             if nm == "dump":          # [planes * rays, S_fp]: which plane (0 depths, 1 density head, 2 red head), which rays, first differing sample
                 S_fp = a.shape[1]
                 pl = a.reshape(DUMP, -1, S_fp); pb = b.reshape(DUMP, -1, S_fp)
