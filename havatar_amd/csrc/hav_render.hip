@@ -1733,7 +1733,8 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
         // coarse weights w[0..S_c) of the block's rays for the inverse CDF: with a workspace, one coalesced 128-byte row per sample
         // in this wave's own slot; without, the ray's (not yet written) rgb_fine row.  Either way they are read back with L1-bypassing
         // loads: rgb_fine rows of neighbouring rays share cache lines ACROSS waves, and an L1 line fetched by the neighbour before
-        // this wave's stores is never refreshed (the rare 16-rays-of-a-block differences of tools/stress_diag.py).
+        // this wave's stores is never refreshed.  (The rare 16-rays-of-a-block differences of tools/stress_diag.py were NOT this: they
+        // came from the IEEE division sequence in sample_eval)
         float* wrow = CACHE ? slot + (size_t)a.S_fp * ENTF : nullptr;
 #if HAV_BLOCK_FENCE
         if (CACHE) {        // the slot is re-used block after block: everything the previous block did to it has landed, and no L1 line of it survives

@@ -98,7 +98,12 @@ __global__ void __launch_bounds__(256) field_inputs_kernel(FieldArgs a)
         float part = vin ? tw * a.vol[vidx] : 0.f;
         part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 4, 64);
         const float w0 = __shfl(part, 0, 64), w1 = __shfl(part, 8, 64);
-        const float s = (w0 + w1) + 1e-8f, h0 = w0 / s, h1 = w1 / s;                       // :87
+        // :87.  The two quotients as one reciprocal + Newton step (<= 1 ulp from w / s), exactly as the inference kernel forms them
+        // (hav_render.hip HAV_FAST_DIV, DESIGN.md 3.12: the compiler's interleaved IEEE division sequences are not trusted on gfx950)
+        const float s = (w0 + w1) + 1e-8f;
+        float rs = __builtin_amdgcn_rcpf(s);
+        rs = rs * (2.0f - s * rs);
+        const float h0 = w0 * rs, h1 = w1 * rs;
         const float rx = h0 * px + h1 * p1x, ry = h0 * py + h1 * p1y, rz = h0 * pz + h1 * p1z;   // :90,95
         // ---- UniformBoxWarp_new of the NeRF box, then the two plane look-ups (nerf_model.py:88-99)
         const float qx = rx * a.bs[0] + a.bt[0], qy = ry * a.bs[1] + a.bt[1], qz = rz * a.bs[2] + a.bt[2];
@@ -172,7 +177,7 @@ __global__ void __launch_bounds__(256) field_inputs_kernel(FieldArgs a)
             // p' = h0 p0 + h1 p1, h_i = w_i / s: d/dw_i = (d/dh_i - sum_j d/dh_j h_j) / s
             const float dh0 = dx * px + dy * py + dz * pz, dh1 = dx * p1x + dy * p1y + dz * p1z;
             const float mix = dh0 * h0 + dh1 * h1;
-            const float dw = ((bone ? dh1 : dh0) - mix) / s;
+            const float dw = ((bone ? dh1 : dh0) - mix) * rs;
             if (vin && tw * dw != 0.f) atomicAdd(a.dvol + vidx, tw * dw);   // clamped (border) coordinates: half the taps weigh 0
         }
     }
