@@ -1,0 +1,52 @@
+"""Static checks on the compiler's output for gfx950 (no GPU needed: hipcc cross-compiles here) -- the code-generation accidents that cost
+this project real time in round 3, as regression tests:
+  * no FLAT instruction in any kernel: a pointer that has been through an empty asm statement loses its address space, its accesses become
+    flat_load / flat_store, which are slower and complete out of order with the other memory counters;
+  * the production march kernels keep their register budget without scratch;
+  * no instruction writes an A / B operand of a v_mfma before the next matrix instruction issues, none touches a matrix result inside
+    11 wait states (tools/mfma_war_check.py: the gfx950 hazard of DESIGN.md 3.5 that the compiler does not model)."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = "/opt/rocm/bin/hipcc"
+SOURCES = [("hav_ops", []), ("hav_train", []), ("hav_mlp_train", []), ("hav_conv", []), ("hav_render", ["-DHAV_FAST_BUILD"])]
+
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+
+
+@pytest.fixture(scope="module")
+def asm(tmp_path_factory):
+    out = {}
+    d = tmp_path_factory.mktemp("isa")
+    for name, extra in SOURCES:
+        dst = str(d / (name + ".s"))
+        subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", dst,
+                        os.path.join(ROOT, "havatar_amd", "csrc", name + ".hip")] + extra, check=True, stderr=subprocess.DEVNULL, timeout=600)
+        out[name] = dst
+    return out
+
+
+def test_no_flat_instructions_in_any_kernel(asm):
+    for name, path in asm.items():
+        bad = [l.strip() for l in open(path) if re.match(r"\s+flat_(load|store|atomic)", l)]
+        assert not bad, "%s: %d FLAT instructions, e.g. %s" % (name, len(bad), bad[:3])
+
+
+def test_production_march_kernels_have_no_scratch_and_pass_the_static_hazard_check(asm):
+    text = open(asm["hav_render"]).read()
+    for sym in ("_Z20hav_march_blk_kernelILi0ELi2ELi2EEv9MarchArgs", "_Z20hav_march_blk_kernelILi1ELi2ELi2EEv9MarchArgs"):
+        m = re.search(r"\.name:\s+" + sym + r"\b", text)
+        assert m, sym
+        meta = text[text.rfind("- .agpr_count", 0, m.start()):m.start() + 600]
+        assert re.search(r"\.vgpr_spill_count:\s+0\b", meta), (sym, re.findall(r"\.vgpr_spill_count:\s+\d+", meta))
+        assert re.search(r"\.private_segment_fixed_size:\s+0\b", meta), (sym, re.findall(r"\.private_segment_fixed_size:\s+\d+", meta))
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mfma_war_check.py"), asm["hav_render"], sym, "8", "11"],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert re.search(r"\b[1-9]\d* v_mfma instructions, 0 early writes of an A/B operand", r.stdout), r.stdout[-500:]
+        assert "0 touches of a matrix result inside 11 wait states" in r.stdout, r.stdout[-500:]
