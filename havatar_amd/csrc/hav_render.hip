@@ -465,11 +465,7 @@ __device__ __forceinline__ float half_swap(float v, int h)
     return __uint_as_float(h ? r[0] : r[1]);
 #endif
 #else
-    float r = __shfl_xor(v, 32, 64);
-#ifdef HAV_LDS_SETTLE
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7" : "+v"(r));          // experiment: let the returned value settle before its first reader
-#endif
-    return r;
+    return __shfl_xor(v, 32, 64);
 #endif
 }
 // orders this wave's LDS traffic (the per-wave scratch is private to a wave: no workgroup barrier needed)
@@ -917,23 +913,11 @@ struct DbgTrace { float* p; long long plane; };
 #define DBG_PASS(x)
 #define DBG_SUM(dst, t4) do { } while (0)
 #endif
-#ifndef HAV_ARGS_RELOAD
-#define HAV_ARGS_RELOAD 0
-#endif
 template <int GQ, int PREC, bool BLK, bool LEAN = false, typename Cont>
 __device__ __forceinline__ void sample_eval(const MarchArgs& a_in, const LaneCtx& L, int b, float ox, float oy, float oz, float dx,
                                             float dy, float dz, float z, Cont&& cont PROF_ARG DBG_ARG)
 {
-#if HAV_ARGS_RELOAD
-    // experiment: the ~25 scalars of the argument block this function uses are re-read from the kernarg segment per tile (s_load, scalar
-    // cache) instead of living in SGPRs across the tile loop -- where they push the kernel past its SGPR budget and get spilled to VGPR
-    // lanes (v_writelane / v_readlane).  The OFFSET is opaque, not the pointer (address space, see the bias pointer below).
-    int a_off = 0;
-    asm volatile("" : "+s"(a_off));
-    const MarchArgs& a = *reinterpret_cast<const MarchArgs*>(reinterpret_cast<const char*>(&a_in) + a_off);
-#else
     const MarchArgs& a = a_in;
-#endif
     // the lane id is opaque per tile: what derives from it (half-wave, fragment columns, strip slots) is then re-derived in one or two
     // ALU ops where it is used instead of being hoisted out of the sample loop as dozens of loop invariants, spilled and RELOADED
     int lane = L.lane;
@@ -949,11 +933,7 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a_in, const LaneCtx
     // (the OFFSET is made opaque, not the pointer: a pointer that has been through an asm statement loses its LDS address space and
     // every read through it becomes a FLAT load -- slower, and FLAT accesses complete out of order with the other memory counters)
     int sb_off = 0;
-#ifdef HAV_SBOFF_SGPR
-    asm volatile("" : "+s"(sb_off));
-#else
-    asm volatile("" : "+v"(sb_off));
-#endif
+    asm volatile("" : "+v"(sb_off));          // (in an SGPR instead, the surrounding code was allocated differently and the hazard of DESIGN.md 3.12 was 100x more frequent)
     const float4* sBt = L.sB + sb_off;
     const int PR = a.p.plane_res, VR = a.p.vol_res;
     // ---- pts = o + d z; skinning field (model/Skinning_Field.py:77-95): half-wave h evaluates bone h ---------
@@ -999,9 +979,6 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a_in, const LaneCtx
     float n0 = w0 * rden, n1 = w1 * rden;
 #else
     float n0 = w0 / den, n1 = w1 / den;
-#endif
-#ifdef HAV_DIV_SETTLE
-    asm volatile(HAV_DIV_SETTLE : "+v"(n0), "+v"(n1));          // experiment: wait states between the division's last instruction and its first reader
 #endif
     const float qx_ = n0 * px + n1 * p1x, qy_ = n0 * py + n1 * p1y, qz_ = n0 * pz + n1 * p1z;   // p'
 #ifdef HAV_DEBUG_TRACE
@@ -1871,10 +1848,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                         __builtin_amdgcn_sched_barrier(0);
                     } PROF_PASS, cA);
 #endif
-                    float zk = s_n[k * 32 + j];
-#ifdef HAV_LDS_SETTLE
-                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7" : "+v"(zk));
-#endif
+                    const float zk = s_n[k * 32 + j];
                     sample_eval<(CACHE == 2 ? HAV_GQ2 : 8), PREC, true, CACHE == 2>(a, L, b, ox, oy, oz, dx, dy, dz, zk,
                                                                  [&](f32x16 (&acc2)[4], float hd0, float hd1, float hd2, float hd3) {
                         __builtin_amdgcn_sched_barrier(0);
@@ -2059,11 +2033,6 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
             // ---- inverse-CDF resampling (utils/nerf_util.py:76-117): one ray per lane, one sequential sweep over the CDF ----
             if (pass == 0 && S_fp > 0) {
                 const int nw = S_c - 2, nb = S_c - 1;
-#ifdef HAV_WROW_FENCE
-                // the coarse weights were stored moments ago by this wave and are read back here
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#endif
                 float sum = 0.f;
                 for (int i = 0; i < nw; ++i) sum += (HAV_SELF_LOAD(CACHE ? &wrow[(1 + i) * 32 + j] : &wpark[1 + i]) + 1e-5f);
                 float run = 0.f, cdf_lo = 0.f;
