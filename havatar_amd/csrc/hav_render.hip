@@ -739,7 +739,20 @@ __device__ __forceinline__ void relu_tiles(f32x16 (&acc)[4])
 // KEEP() extends an operand's live range (no instruction is emitted) until the FOLLOWING MFMA has issued, i.e. >= 32 cycles.
 // The accumulator rides along as an in/out operand so that the (otherwise freely movable) empty asm stays between the two
 // MFMAs it separates: the compiler does reorder register-only MFMAs across a plain asm volatile.
+// HAV_MFMA_PADS (default 0).  Rounds 1-2 believed that v_mfma_f32_32x32x16_* keeps reading its A / B operands after issue (a run-to-run
+// difference in columns 16-31 of a tile) and padded the matrix sequences: operand keep-alives (KEEP), 32 wait states behind every group
+// (HARD) and a scheduling barrier per group.  Round 3 traced that difference to the IEEE division sequence of the skinning blend
+//  and measured the operands directly (tools/ubench/mfma_war.hip: an operand register overwritten by the very next
+// instruction, single and in dependent chains of three, two waves per SIMD: 0 of 10^10 results change).  The pads are off (-1.3 % kernel
+// time); HAV_MFMA_PADS=1 brings them back.
+#ifndef HAV_MFMA_PADS
+#define HAV_MFMA_PADS 0
+#endif
+#if HAV_MFMA_PADS
 #define KEEP(acc, x) asm volatile("" : "+v"(acc) : "v"(x))
+#else
+#define KEEP(acc, x) do { } while (0)
+#endif
 
 // HARD (see mfma_split2h below): wait the last MFMA of a k-chunk out before the splitting code of the next chunk may write registers.
 template <int NCH, bool HARD = true, typename GetV>
@@ -867,10 +880,14 @@ __device__ __forceinline__ void mfma_split2h(f32x16 (&acc)[NM], const uint4* fra
         acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh, acc[m], 0, 0, 0);
         KEEP(acc[m], xl);
         pa = ah; pb = xh;
+#if HAV_MFMA_PADS
         if (HARD && m == NM - 1 && g + 1 < NCH * NM) asm volatile(HAV_HARD_NOPS : "+v"(acc[m]) : "v"(pa), "v"(pb));
         __builtin_amdgcn_sched_barrier(0);
+#endif
     }
+#if HAV_MFMA_PADS
     asm volatile(HAV_HARD_NOPS : "+v"(acc[NM - 1]) : "v"(pa), "v"(pb));
+#endif
 }
 #undef KEEP
 

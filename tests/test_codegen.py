@@ -3,8 +3,9 @@ this project real time in round 3, as regression tests:
   * no FLAT instruction in any kernel: a pointer that has been through an empty asm statement loses its address space, its accesses become
     flat_load / flat_store, which are slower and complete out of order with the other memory counters;
   * the production march kernels keep their register budget without scratch;
-  * no instruction writes an A / B operand of a v_mfma before the next matrix instruction issues, none touches a matrix result inside
-    11 wait states (tools/mfma_war_check.py: the gfx950 hazard of DESIGN.md 3.5 that the compiler does not model)."""
+  * no instruction touches a matrix-instruction RESULT inside 11 wait states (tools/mfma_war_check.py): the compiler pads that for its own
+    instructions but not for inline asm (the in-place relu), DESIGN.md 3.5.  (The script's other check -- early writes of an A / B OPERAND --
+    is informational since round 3: tools/ubench/mfma_war.hip shows that gfx950 does not read operands after issue.)"""
 import os
 import re
 import subprocess
@@ -48,5 +49,5 @@ def test_production_march_kernels_have_no_scratch_and_pass_the_static_hazard_che
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mfma_war_check.py"), asm["hav_render"], sym, "8", "11"],
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr
-        assert re.search(r"\b[1-9]\d* v_mfma instructions, 0 early writes of an A/B operand", r.stdout), r.stdout[-500:]
+        assert re.search(r"\b[1-9]\d* v_mfma instructions, \d+ early writes of an A/B operand", r.stdout), r.stdout[-500:]
         assert "0 touches of a matrix result inside 11 wait states" in r.stdout, r.stdout[-500:]
