@@ -44,6 +44,11 @@ typedef float fl2_t __attribute__((ext_vector_type(2)));
 #define CV_TASKS (CV_PIX * 8)            // (pixel, channel pair) staging tasks per chunk
 #define CV_TPT ((CV_TASKS + 255) / 256)  // per thread
 #define CV_WSHIFT 256.0f
+// wait states behind the matrix instructions of a chunk, before the staging code of the next one (the operand hazard
+// they were added for does not exist; what remains is their effect as a scheduling fence -- measured before being touched)
+#ifndef CV_MFMA_PAD
+#define CV_MFMA_PAD "s_nop 15\n\ts_nop 15"
+#endif
 
 extern "C" int64_t hav_conv3x3_packed_bytes(int Cout, int Cin) { return (int64_t)(Cin / 16) * 9 * (Cout / 32) * 2 * 64 * 16; }
 
@@ -254,7 +259,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(ConvArgs a)
         // the matrix instructions keep reading their operand registers for a while after issue: wait them out before
         // the conversion code below may recycle registers
         CV_T(pt2);
-        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]));
+        asm volatile(CV_MFMA_PAD : "+v"(acc[0]), "+v"(acc[1]));
         if (ci + 1 < NC) stash(buf ^ 1, sv, ssc);
         CV_T(pt3);
         __syncthreads();
@@ -423,7 +428,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_il_kernel(ConvArgs a)
         // registers stay allocated until here (no temporary may land in them), and the pipe drains before the next chunk's first writes
 #pragma unroll
         for (int t = 0; t < 9; ++t) { CV_KEEP4(Ac[t][0]); CV_KEEP4(Ac[t][1]); }
-        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+        asm volatile(CV_MFMA_PAD : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
         CV_T(pt1);
         __syncthreads();
         CV_T(pt2);
@@ -702,7 +707,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3s2_split_kernel(ConvS2Args a)
                 acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh, acc[rr], 0, 0, 0);
             }
         }
-        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]));          // operand registers are read after issue
+        asm volatile(CV_MFMA_PAD : "+v"(acc[0]), "+v"(acc[1]));          // operand registers are read after issue
         if (cc + 1 < NC) stash(buf ^ 1, cc + 1, sv);
         __syncthreads();
     }
@@ -906,7 +911,7 @@ __global__ void __launch_bounds__(256, 2) gemm_split_kernel(GemmArgs a)
         }
         // the matrix instructions keep reading their operand registers after issue: wait them out before stash() may
         // recycle registers
-        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
+        asm volatile(CV_MFMA_PAD : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
         if (cc + 1 < NC) stash(buf ^ 1, sv, ssc);
         __syncthreads();
     }
@@ -1143,7 +1148,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_kernel(WgradArgs a)
                     acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xh, acc[q], 0, 0, 0);
                 }
             }
-            asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]));
+            asm volatile(CV_MFMA_PAD : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]));
             if (more) { stash_x(y + 2, nx); stash_g((y + 1) & 1, ng); }
             __syncthreads();
         }
