@@ -468,6 +468,9 @@ __device__ __forceinline__ float half_swap(float v, int h)
     return __shfl_xor(v, 32, 64);
 #endif
 }
+// sigmoid with the reciprocal instruction (1 ulp) instead of the compiler's IEEE division sequence -- three of those interleaved per
+// sample is the pattern DESIGN.md 3.12 is about; rcp(inf) = 0 covers exp overflow (no Newton step: inf * 0 would poison it)
+__device__ __forceinline__ float sigmoid_rcp(float x) { return __builtin_amdgcn_rcpf(1.0f + expf(-x)); }
 // orders this wave's LDS traffic (the per-wave scratch is private to a wave: no workgroup barrier needed)
 __device__ __forceinline__ void wave_lds_sync()
 {
@@ -1451,9 +1454,9 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                     const bool writer = (col == 0) && (!same || rowt == 0);
                     float e0, e1, e2, e3, e4;
                     if (h == 0) {
-                        e0 = 1.0f / (1.0f + expf(-hd0));              // sigmoid on rgb only (:45-46)
-                        e1 = 1.0f / (1.0f + expf(-hd1));
-                        e2 = 1.0f / (1.0f + expf(-hd2));
+                        e0 = sigmoid_rcp(hd0);              // sigmoid on rgb only (:45-46)
+                        e1 = sigmoid_rcp(hd1);
+                        e2 = sigmoid_rcp(hd2);
                         e3 = z; e4 = 1.0f;
                     } else { e0 = e1 = e2 = e3 = e4 = 0.f; }
                     const float v0 = row16_sum(e0 * wgt), v1 = row16_sum(e1 * wgt), v2 = row16_sum(e2 * wgt);
@@ -1934,9 +1937,9 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                             const float alpha = 1.0f - expf(-sg * (dist * dn));
                             const float wgt = alpha * T;
                             T = T * ((1.0f - alpha) + 1e-10f);
-                            c0 = fmaf(wgt, 1.0f / (1.0f + expf(-raw.x)), c0);
-                            c1 = fmaf(wgt, 1.0f / (1.0f + expf(-raw.y)), c1);
-                            c2 = fmaf(wgt, 1.0f / (1.0f + expf(-raw.z)), c2);
+                            c0 = fmaf(wgt, sigmoid_rcp(raw.x), c0);
+                            c1 = fmaf(wgt, sigmoid_rcp(raw.y), c1);
+                            c2 = fmaf(wgt, sigmoid_rcp(raw.z), c2);
                             dep = fmaf(wgt, zc, dep);
                             accw += wgt;
                             wmax = fmaxf(wmax, wgt);
@@ -2016,9 +2019,9 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
 #pragma unroll
                     for (int m = 0; m < 4; ++m) hsum[m] = __builtin_elementwise_fma(wv, acc2[m], hsum[m]);   // v_pk_fma_f32
                 }
-                c0 = fmaf(wgt, 1.0f / (1.0f + expf(-hd0)), c0);               // sigmoid on rgb only (:45-46)
-                c1 = fmaf(wgt, 1.0f / (1.0f + expf(-hd1)), c1);
-                c2 = fmaf(wgt, 1.0f / (1.0f + expf(-hd2)), c2);
+                c0 = fmaf(wgt, sigmoid_rcp(hd0), c0);               // sigmoid on rgb only (:45-46)
+                c1 = fmaf(wgt, sigmoid_rcp(hd1), c1);
+                c2 = fmaf(wgt, sigmoid_rcp(hd2), c2);
                 dep = fmaf(wgt, z, dep);
                 accw += wgt;
                 wmax = fmaxf(wmax, wgt);
