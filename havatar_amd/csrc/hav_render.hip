@@ -758,9 +758,18 @@ __device__ __forceinline__ void relu_tiles(f32x16 (&acc)[4])
 #endif
 
 // HARD (see mfma_split2h below): wait the last MFMA of a k-chunk out before the splitting code of the next chunk may write registers.
+#ifndef HAV_MFMA_IL
+#define HAV_MFMA_IL 0     // 1: the interleaved, hand-placed sequences further down (parity-tested; measured neutral: DESIGN.md 3.13)
+#endif
+template <int NCH, typename GetV>
+__device__ __forceinline__ void mfma_split3_il(f32x16 (&acc)[4], const uint4* frag, int lane, GetV getv);
 template <int NCH, bool HARD = true, typename GetV>
 __device__ __forceinline__ void mfma_split3(f32x16 (&acc)[4], const uint4* frag /* [NCH][4 m][3 parts][64 lanes] */, int lane, GetV getv)
 {
+#if HAV_MFMA_IL
+    mfma_split3_il<NCH>(acc, frag, lane, getv);
+    return;
+#endif
     uint4 A[2][3];
     uint4 bh, bm, bl;
     bf16x8_t pa, pb;                  // operands of the previous group's last MFMA
@@ -849,9 +858,15 @@ __device__ __forceinline__ void split2h(float v0, float v1, uint32_t& ph, uint32
 #ifndef HAV_HARD_NOPS
 #define HAV_HARD_NOPS "s_nop 15\n\ts_nop 15"
 #endif
+template <int NCH, int NM, typename GetV>
+__device__ __forceinline__ void mfma_split2h_il(f32x16 (&acc)[NM], const uint4* frag, int lane, GetV getv);
 template <int NCH, int NM, bool HARD = true, typename GetV>
 __device__ __forceinline__ void mfma_split2h(f32x16 (&acc)[NM], const uint4* frag /* [NCH][NM row tiles][2 parts][64 lanes] */, int lane, GetV getv)
 {
+#if HAV_MFMA_IL
+    mfma_split2h_il<NCH, NM>(acc, frag, lane, getv);
+    return;
+#endif
 #ifndef HAV_FRAG_DIST
 #define HAV_FRAG_DIST 1     // groups of MFMAs a fragment read runs ahead of its use (1: 64-96 cycles; 2 and 3 measured the same: the loops do not wait on the LDS)
 #endif
@@ -896,6 +911,150 @@ __device__ __forceinline__ void mfma_split2h(f32x16 (&acc)[NM], const uint4* fra
 #endif
 }
 #undef KEEP
+
+// ---- Interleaved, hand-placed matrix sequences (round 4; HAV_MFMA_IL, default 1) ------------------------------------------------
+// What the compiler made of the two routines below (hipcc 7.2, -O3): it sinks every fragment read next to the MFMA that consumes it
+// (ds_read_b128 -> s_waitcnt lgkmcnt(0) -> v_mfma: a full LDS round trip per group, whatever prefetch distance the source spells out),
+// it puts the 12-36 VALU instructions of a chunk's operand split in FRONT of the chunk's first MFMA, and the three (six) products of
+// a group accumulate back to back into one register tuple.  The layer phases ran at about half the matrix pipe's pace.
+// Measured (tools/ubench/mfma_overlap2.hip, profiles/r04_ubench_overlap2.txt): plain VALU / LDS instructions issue in the shadow of a
+// matrix instruction -- up to ~6 per v_mfma_f32_32x32x16 at 1-2 cycles each, from the same wave; a partner wave's plain VALU stream runs
+// at 95 % of its solo pace beside a saturating MFMA stream -- and only PACKED fp32 VALU (v_pk_fma/mul/add_f32) excludes the matrix pipe.
+// (Rounds 1-3 concluded "VALU does not overlap with MFMA" from microbenchmarks whose C fillers hipcc had SLP-packed into v_pk_fma_f32.)
+// So: two row tiles per group, their products interleaved (consecutive MFMAs never share an accumulator); the fragments of group g+1
+// are read behind the first two MFMAs of group g; the NEXT chunk's operand split (non-packed instructions only) is dealt out over
+// the gaps of the current chunk; a scheduling barrier behind every slot pins the order.
+#define HAV_SB() __builtin_amdgcn_sched_barrier(0)
+template <int NCH, int NM, typename GetV>
+__device__ __forceinline__ void mfma_split2h_il(f32x16 (&acc)[NM], const uint4* frag /* [NCH][NM row tiles][2 parts][64 lanes] */, int lane, GetV getv)
+{
+    static_assert(NM % 2 == 0, "row tiles are processed in pairs");
+    constexpr int NP = NM / 2, NPG = NCH * NP;
+    uint4 A[2][4];                  // [ring slot][tile 0 hi, tile 0 lo, tile 1 hi, tile 1 lo]
+    uint4 bh[2], bl[2];             // B operand of chunk ch (slot ch & 1) and of the next one
+    auto load_pair = [&](uint4 (&dst)[4], int pg) {
+        const int base = ((pg / NP) * NM + 2 * (pg % NP)) * 2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[q] = frag[(base + q) * 64 + lane];
+    };
+    auto split_dword = [&](int ch, int q) {       // dword q of chunk ch's operand: 3 VALU instructions
+        float v[8];
+        getv(ch, v);
+        uint32_t ph, pl;
+        split2h(v[2 * q], v[2 * q + 1], ph, pl);
+        uint4& H = bh[ch & 1]; uint4& Lo = bl[ch & 1];
+        if (q == 0) { H.x = ph; Lo.x = pl; } else if (q == 1) { H.y = ph; Lo.y = pl; } else if (q == 2) { H.z = ph; Lo.z = pl; } else { H.w = ph; Lo.w = pl; }
+    };
+    load_pair(A[0], 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) split_dword(0, q);
+    HAV_SB();
+#pragma unroll
+    for (int pg = 0; pg < NPG; ++pg) {
+        const int ch = pg / NP, p = pg % NP, m0 = 2 * p, m1 = 2 * p + 1;
+        const f16x8_t xh = __builtin_bit_cast(f16x8_t, bh[ch & 1]), xl = __builtin_bit_cast(f16x8_t, bl[ch & 1]);
+        const f16x8_t ah0 = __builtin_bit_cast(f16x8_t, A[pg & 1][0]), al0 = __builtin_bit_cast(f16x8_t, A[pg & 1][1]);
+        const f16x8_t ah1 = __builtin_bit_cast(f16x8_t, A[pg & 1][2]), al1 = __builtin_bit_cast(f16x8_t, A[pg & 1][3]);
+        // the four split steps of the next chunk go into gaps 2..5 of this chunk's groups
+        auto next_split = [&](int slot) {         // slot 0..3 of this group
+            if (ch + 1 >= NCH) return;
+            if (NP == 1) split_dword(ch + 1, slot);
+            else if (NP == 2) { if (slot == 0 || slot == 2) split_dword(ch + 1, 2 * p + (slot >> 1)); }
+            else if (p < 4 && slot == 0) split_dword(ch + 1, p);
+        };
+        acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, xh, acc[m0], 0, 0, 0);
+        HAV_SB();
+        if (pg + 1 < NPG) {
+            const int base = (((pg + 1) / NP) * NM + 2 * ((pg + 1) % NP)) * 2;
+            A[(pg + 1) & 1][0] = frag[(base + 0) * 64 + lane];
+            A[(pg + 1) & 1][1] = frag[(base + 1) * 64 + lane];
+        }
+        HAV_SB();
+        acc[m1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, xh, acc[m1], 0, 0, 0);
+        HAV_SB();
+        if (pg + 1 < NPG) {
+            const int base = (((pg + 1) / NP) * NM + 2 * ((pg + 1) % NP)) * 2;
+            A[(pg + 1) & 1][2] = frag[(base + 2) * 64 + lane];
+            A[(pg + 1) & 1][3] = frag[(base + 3) * 64 + lane];
+        }
+        HAV_SB();
+        acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, xl, acc[m0], 0, 0, 0);
+        HAV_SB();
+        next_split(0);
+        HAV_SB();
+        acc[m1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, xl, acc[m1], 0, 0, 0);
+        HAV_SB();
+        next_split(1);
+        HAV_SB();
+        acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, xh, acc[m0], 0, 0, 0);
+        HAV_SB();
+        next_split(2);
+        HAV_SB();
+        acc[m1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, xh, acc[m1], 0, 0, 0);
+        HAV_SB();
+        next_split(3);
+        HAV_SB();
+    }
+}
+// the bf16 triple split without packed-fp32 instructions (they exclude the matrix pipe): v = hi + mid + lo exactly, 11 plain VALU per pair
+__device__ __forceinline__ void split3_a(float v0, float v1, uint32_t& ph, float& r0, float& r1)
+{
+    const uint32_t u0 = __float_as_uint(v0), u1 = __float_as_uint(v1);
+    ph = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    r0 = v0 - __uint_as_float(u0 & 0xFFFF0000u);
+    r1 = v1 - __uint_as_float(u1 & 0xFFFF0000u);
+}
+__device__ __forceinline__ void split3_b(float r0, float r1, uint32_t& pm, uint32_t& pl)
+{
+    const uint32_t a0 = __float_as_uint(r0), a1 = __float_as_uint(r1);
+    pm = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
+    const float q0 = r0 - __uint_as_float(a0 & 0xFFFF0000u), q1 = r1 - __uint_as_float(a1 & 0xFFFF0000u);
+    pl = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+}
+template <int NCH, typename GetV>
+__device__ __forceinline__ void mfma_split3_il(f32x16 (&acc)[4], const uint4* frag /* [NCH][4 m][3 parts][64 lanes] */, int lane, GetV getv)
+{
+    constexpr int NM = 4, NP = 2, NPG = NCH * NP;
+    uint4 A[2][6];                  // [ring slot][tile 0 hi, mid, lo, tile 1 hi, mid, lo]
+    uint4 bh[2], bm[2], bl[2];
+    float rr[2];                    // residuals between the two halves of a split step
+    auto setw = [](uint4& t, int q, uint32_t w) { if (q == 0) t.x = w; else if (q == 1) t.y = w; else if (q == 2) t.z = w; else t.w = w; };
+    auto split_a = [&](int ch, int q) { float v[8]; getv(ch, v); uint32_t ph; split3_a(v[2 * q], v[2 * q + 1], ph, rr[0], rr[1]); setw(bh[ch & 1], q, ph); };
+    auto split_b = [&](int ch, int q) { uint32_t pm, pl; split3_b(rr[0], rr[1], pm, pl); setw(bm[ch & 1], q, pm); setw(bl[ch & 1], q, pl); };
+#pragma unroll
+    for (int q = 0; q < 6; ++q) A[0][q] = frag[q * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { split_a(0, q); split_b(0, q); }
+    HAV_SB();
+#pragma unroll
+    for (int pg = 0; pg < NPG; ++pg) {
+        const int ch = pg / NP, p = pg % NP, m0 = 2 * p, m1 = 2 * p + 1;
+        const bf16x8_t xh = __builtin_bit_cast(bf16x8_t, bh[ch & 1]), xm = __builtin_bit_cast(bf16x8_t, bm[ch & 1]), xl = __builtin_bit_cast(bf16x8_t, bl[ch & 1]);
+        const bf16x8_t ah0 = __builtin_bit_cast(bf16x8_t, A[pg & 1][0]), am0 = __builtin_bit_cast(bf16x8_t, A[pg & 1][1]), al0 = __builtin_bit_cast(bf16x8_t, A[pg & 1][2]);
+        const bf16x8_t ah1 = __builtin_bit_cast(bf16x8_t, A[pg & 1][3]), am1 = __builtin_bit_cast(bf16x8_t, A[pg & 1][4]), al1 = __builtin_bit_cast(bf16x8_t, A[pg & 1][5]);
+        const int nbase = (((pg + 1) / NP) * NM + 2 * ((pg + 1) % NP)) * 3;
+        auto nload = [&](int q) { if (pg + 1 < NPG) { A[(pg + 1) & 1][2 * q] = frag[(nbase + 2 * q) * 64 + lane]; A[(pg + 1) & 1][2 * q + 1] = frag[(nbase + 2 * q + 1) * 64 + lane]; } };
+        // next chunk's split: dwords 2p, 2p+1 in this group, each in two halves (5 + 6 instructions)
+        auto nsplit = [&](int half) {
+            if (ch + 1 >= NCH) return;
+            const int q = 2 * p + (half >> 1);
+            if (half & 1) split_b(ch + 1, q); else split_a(ch + 1, q);
+        };
+        // the six products >= 2^-16 of the leading one, smallest first per accumulator: l.h, h.l, m.m, m.h, h.m, h.h
+        acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, xh, acc[m0], 0, 0, 0); HAV_SB(); nload(0); HAV_SB();
+        acc[m1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, xh, acc[m1], 0, 0, 0); HAV_SB(); nload(1); HAV_SB();
+        acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, xl, acc[m0], 0, 0, 0); HAV_SB(); nload(2); HAV_SB();
+        acc[m1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, xl, acc[m1], 0, 0, 0); HAV_SB();
+        acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am0, xm, acc[m0], 0, 0, 0); HAV_SB(); nsplit(0); HAV_SB();
+        acc[m1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am1, xm, acc[m1], 0, 0, 0); HAV_SB();
+        acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am0, xh, acc[m0], 0, 0, 0); HAV_SB(); nsplit(1); HAV_SB();
+        acc[m1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am1, xh, acc[m1], 0, 0, 0); HAV_SB();
+        acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, xm, acc[m0], 0, 0, 0); HAV_SB(); nsplit(2); HAV_SB();
+        acc[m1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, xm, acc[m1], 0, 0, 0); HAV_SB();
+        acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, xh, acc[m0], 0, 0, 0); HAV_SB(); nsplit(3); HAV_SB();
+        acc[m1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, xh, acc[m1], 0, 0, 0); HAV_SB();
+    }
+}
 
 // Phase timing (tools/phase_profile.sh builds an alternative library with -DHAV_PROFILE): wave-uniform s_memtime deltas summed
 // per phase and added to g_prof at kernel exit.  Waits are attributed to the phase in which the s_waitcnt / s_nop sits.
@@ -1110,6 +1269,10 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a_in, const LaneCtx
         TICK(2);
         // ---- PE octaves 4h..4h+3 of this half-wave (model/network/embedder.py:32-61) ---------------------
         float pe[KPE_STEPS];
+        if (a.ablate & 2) {          // timing experiment: no sin / cos
+#pragma unroll
+            for (int kk = 0; kk < KPE_STEPS; ++kk) pe[kk] = qx_ * (float)(kk + 1);
+        } else
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const float f = h ? (float)(16 << kk) : (float)(1 << kk);
@@ -1122,6 +1285,7 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a_in, const LaneCtx
         mfma_lock(L);
 
         if (PREC == 2) {
+            if (!(a.ablate & 16))
             mfma_split2h<3, 4>(acc1, L.sA1, lane, [&](int c, float (&v)[8]) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = pe[8 * c + e];
@@ -1132,7 +1296,8 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a_in, const LaneCtx
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = pe[8 * c + e];
             });
-        } else if (!(a.ablate & 16)) {
+        }
+        else if (!(a.ablate & 16)) {
             float af[2][4];               // explicit double buffer: the A fragments of k-step t+1 are requested before the MFMAs of step t
 #pragma unroll
             for (int m = 0; m < 4; ++m) af[0][m] = sW1[m * 64 + lane];
@@ -1171,6 +1336,7 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a_in, const LaneCtx
                 acc2[m][4 * q + 2] = __uint_as_float(bb[2]); acc2[m][4 * q + 3] = __uint_as_float(bb[3]);
             }
         if (PREC == 2) {
+            if (!(a.ablate & 32))
             mfma_split2h<8, 4>(acc2, L.sA2, lane, [&](int ch, float (&v)[8]) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = acc1[ch >> 1][8 * (ch & 1) + e];
@@ -1250,7 +1416,10 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a_in, const LaneCtx
         }
         hd0 += half_swap(hd0, h); hd1 += half_swap(hd1, h);
         hd2 += half_swap(hd2, h); hd3 += half_swap(hd3, h);
-        {
+        if (BLK) {          // block kernel: LDS copy (a global load here queued behind the other waves' tap loads in every tile: ~1 K cycles)
+            const float4 b4 = sBt[64];
+            hd0 += b4.x; hd1 += b4.y; hd2 += b4.z; hd3 += b4.w;
+        } else {
             const auto b4 = __builtin_amdgcn_raw_buffer_load_b128(L.wrs, 0, OFF_B4 * 4, 0);
             hd0 += __uint_as_float(b4[0]); hd1 += __uint_as_float(b4[1]); hd2 += __uint_as_float(b4[2]); hd3 += __uint_as_float(b4[3]);
         }
@@ -1604,7 +1773,17 @@ __device__ __forceinline__ float4 nt_load4(const float4* p)
 #ifndef HAV_GQ2
 #define HAV_GQ2 16         // float4 loads per gather stage in the fine-maps-only variant (its register budget allows a whole tap: -2 %)
 #endif
+#ifndef HAV_WSUM_INLOOP
+#define HAV_WSUM_INLOOP 0
+#endif
+#ifndef HAV_STAGEB_PF
+#define HAV_STAGEB_PF 1        // parked entries in flight in stage B (measured: 2 = +2 %, 3 = +8 %, 4 = +12 % kernel time; profiles/r04_ab_lat.txt)
+#endif
+#define HAV_LDS_BIAS 264          // LDS copy of b1 | b2 | b4 (folded rgb biases, alpha bias) | pad, behind the weight image
 #define WS_H2_FLOATS 4096
+#ifndef HAV_FEATPARK
+#define HAV_FEATPARK 1      // fp16 mode: park the 64 features of a sample (48 more MFMAs per parked tile) instead of its 128 hidden units
+#endif
 #define WS_ENTRY_FLOATS (WS_H2_FLOATS + 128 + 32)
 // CACHE = 2: additionally, the caller does not want the coarse pass's composited outputs (Trainer.forward with a fine pass only
 // uses the fine ones): the coarse pass then carries no composited-hidden-unit accumulators at all (64 VGPRs less in its loop).
@@ -1615,7 +1794,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
     constexpr bool COUT = CACHE != 2;
     // fp16 mode: the fc_rgbFeat fragments fit in LDS next to the layer weights, so what is parked per sample is its 64 FEATURES
     // (8 rows of 1 KB per wave) instead of its 128 hidden units (16 rows): half the parking traffic for 48 more MFMAs per parked tile
-    constexpr bool FEATPARK = (PREC == 2) && (CACHE != 0);
+    constexpr bool FEATPARK = (PREC == 2) && (CACHE != 0) && HAV_FEATPARK;
     constexpr int H2F = FEATPARK ? WS_H2_FLOATS / 2 : WS_H2_FLOATS, ENTF = H2F + 128 + 32;      // floats of one parked entry
     if (a.guard) {          // fp16 range guard: the fp16 kernel and its bf16 fallback are both launched, one of them proceeds
         const unsigned int unsafe = __builtin_amdgcn_readfirstlane(*a.guard);
@@ -1629,7 +1808,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* s_n = smem + WLDS + 256 + wave * a.scr_floats;      // [S_f][32] importance samples of this wave's rays (after the b1|b2 copy)
+    float* s_n = smem + WLDS + HAV_LDS_BIAS + wave * a.scr_floats;      // [S_f][32] importance samples of this wave's rays (after the b1|b2|b4 copy)
     if (PREC >= 1) {
         const float4* src = reinterpret_cast<const float4*>(a.blob + (PREC == 2 ? OFF_A1H : OFF_A1S));
         float4* dst = reinterpret_cast<float4*>(smem);
@@ -1642,7 +1821,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
         float4* dstf = reinterpret_cast<float4*>(smem + OFF_WFT);
         for (int i = tid; i < K2_STEPS * 2 * 64 / 4; i += MARCH_THREADS) dstf[i] = srcf[i];
     }
-    if (tid < 64) reinterpret_cast<float4*>(smem + WLDS)[tid] = reinterpret_cast<const float4*>(a.blob + OFF_B1)[tid];   // b1 | b2
+    if (tid < 65) reinterpret_cast<float4*>(smem + WLDS)[tid] = reinterpret_cast<const float4*>(a.blob + OFF_B1)[tid];   // b1 | b2 | b4 (contiguous in the blob)
     __syncthreads();
 
 #ifdef HAV_PROFILE
@@ -1662,7 +1841,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
     L.wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.blob), 0, BLOB_FLOATS * 4, 0x00020000);
     L.lane = lane; L.h = h; L.hoff = h * 16;
     {   // one lock word per SIMD behind the per-wave scratch, indexed by the SIMD this wave really runs on (HW_REG_HW_ID bits 5:4)
-        int* locks = reinterpret_cast<int*>(smem + WLDS + 256 + MARCH_WAVES * a.scr_floats);
+        int* locks = reinterpret_cast<int*>(smem + WLDS + HAV_LDS_BIAS + MARCH_WAVES * a.scr_floats);
 #ifdef HAV_LOCK_BY_WAVE
         const unsigned simd = wave & 3;
 #else
@@ -1730,11 +1909,12 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
 #endif
         RAY_FENCE();
         float* slot = CACHE ? a.ws + ((a.ablate & 1024) ? 0 : a.ws_slot * ((long long)blockIdx.x * MARCH_WAVES + wave)) : nullptr;   // 1024: timing experiment, all waves share one L2-resident slot
-        // coarse weights w[0..S_c) of the block's rays for the inverse CDF: with a workspace, one coalesced 128-byte row per sample
-        // in this wave's own slot; without, the ray's (not yet written) rgb_fine row.  Either way they are read back with L1-bypassing
-        // loads: rgb_fine rows of neighbouring rays share cache lines ACROSS waves, and an L1 line fetched by the neighbour before
-        // this wave's stores is never refreshed.  (The rare 16-rays-of-a-block differences of tools/stress_diag.py were NOT this: they
-        // came from the IEEE division sequence in sample_eval)
+        // coarse weights w[0..S_c) of the block's rays for the inverse CDF: with a workspace, one coalesced 128-byte row per sample in
+        // this wave's own slot (wrow: written and read by the same wave, plain cached loads -- a wave's stores are coherent with its own
+        // CU's L1); without (CACHE == 0, not the production path), the ray's (not yet written) rgb_fine row (wpark).  rgb_fine rows of
+        // neighbouring rays share cache lines ACROSS waves, and an L1 line fetched by a neighbour before this wave's stores could be
+        // stale on another CU only -- the row is private to the ray, so it is the same-CU case too, but the wpark reads stay
+        // L1-bypassing (non-temporal): that path is outside the determinism stress runs.
         float* wrow = CACHE ? slot + (size_t)a.S_fp * ENTF : nullptr;
 #if HAV_BLOCK_FENCE
         if (CACHE) {        // the slot is re-used block after block: everything the previous block did to it has landed, and no L1 line of it survives
@@ -1761,6 +1941,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
 #pragma unroll
                     for (int r = 0; r < 16; ++r) ft[m][r] = 0.f;
                 mfma_lock(L);
+                if (!(a.ablate & 4))
                 mfma_split2h<8, 2>(ft, L.sAF, lane, [&](int ch, float (&x)[8]) {
 #pragma unroll
                     for (int el = 0; el < 8; ++el) x[el] = v[ch >> 1][8 * (ch & 1) + el];
@@ -1849,6 +2030,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
 #pragma unroll
                 for (int r = 0; r < 16; ++r) hsum[m][r] = 0.f;
             float T = 1.0f, c0 = 0.f, c1 = 0.f, c2 = 0.f, dep = 0.f, accw = 0.f, wmax = 0.f;
+            float wsum = 0.f;           // sum_{i=1}^{S_c-2} (w_i + 1e-5), accumulated in the resampling's own (sequential) order while the weights are produced
             // merged fine depths are produced on the fly: even coarse depths and the LDS-resident importance samples
             int ie = 0, ik = 0;
             float ze = 0.f, nk = 0.f;
@@ -1968,16 +2150,35 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
 #pragma unroll
                     for (int r = 0; r < 16; ++r) hsumB[m][r] = 0.f;
                 constexpr int NROW = FEATPARK ? 8 : 16;
-                for (int e = 0; e < S; ++e) {
-                    const float4* H2 = reinterpret_cast<const float4*>(slot + (size_t)e * ENTF);
-                    const float wgt = HAV_SELF_LOAD(&slot[(size_t)e * ENTF + H2F + 128 + j]);
+                constexpr int PF = HAV_STAGEB_PF < 1 ? 1 : (FEATPARK ? HAV_STAGEB_PF : (HAV_STAGEB_PF + 1) / 2);      // entries in flight (32 / 64 registers each)
+                float4 vb[PF][NROW];
+                float wb[PF];
+                auto ldB = [&](int u, int e) {
+                    if (e < S) {
+                        const float4* H2 = reinterpret_cast<const float4*>(slot + (size_t)e * ENTF);
+                        wb[u] = HAV_SELF_LOAD(&slot[(size_t)e * ENTF + H2F + 128 + j]);
 #pragma unroll
-                    for (int q = 0; q < NROW; ++q) {
-                        const float4 v = nt_load4(&H2[q * 64 + lane]);
-                        hsumB[q >> 2][4 * (q & 3) + 0] = fmaf(wgt, v.x, hsumB[q >> 2][4 * (q & 3) + 0]);
-                        hsumB[q >> 2][4 * (q & 3) + 1] = fmaf(wgt, v.y, hsumB[q >> 2][4 * (q & 3) + 1]);
-                        hsumB[q >> 2][4 * (q & 3) + 2] = fmaf(wgt, v.z, hsumB[q >> 2][4 * (q & 3) + 2]);
-                        hsumB[q >> 2][4 * (q & 3) + 3] = fmaf(wgt, v.w, hsumB[q >> 2][4 * (q & 3) + 3]);
+                        for (int q = 0; q < NROW; ++q) vb[u][q] = nt_load4(&H2[q * 64 + lane]);
+                    }
+                };
+#pragma unroll
+                for (int u = 0; u < PF; ++u) ldB(u, u);
+                for (int e0 = 0; e0 < S; e0 += PF) {
+#pragma unroll
+                    for (int u = 0; u < PF; ++u) {
+                        if (e0 + u < S) {
+                            const float wgt = wb[u];
+#pragma unroll
+                            for (int q = 0; q < NROW; ++q) {
+                                const float4 v = vb[u][q];
+                                hsumB[q >> 2][4 * (q & 3) + 0] = fmaf(wgt, v.x, hsumB[q >> 2][4 * (q & 3) + 0]);
+                                hsumB[q >> 2][4 * (q & 3) + 1] = fmaf(wgt, v.y, hsumB[q >> 2][4 * (q & 3) + 1]);
+                                hsumB[q >> 2][4 * (q & 3) + 2] = fmaf(wgt, v.z, hsumB[q >> 2][4 * (q & 3) + 2]);
+                                hsumB[q >> 2][4 * (q & 3) + 3] = fmaf(wgt, v.w, hsumB[q >> 2][4 * (q & 3) + 3]);
+                            }
+                        }
+                        asm volatile("" ::: "memory");          // the refill stays behind the FMAs that free its registers
+                        ldB(u, e0 + u + PF);
                     }
                 }
                 TICK(3);
@@ -2026,6 +2227,9 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                 accw += wgt;
                 wmax = fmaxf(wmax, wgt);
                 if (pass == 0 && S_fp > 0 && h == 0) { if (CACHE) wrow[s * 32 + j] = wgt; else if (rayok) wpark[s] = wgt; }
+#if HAV_WSUM_INLOOP
+                if (pass == 0 && s >= 1 && s <= S_c - 2) wsum += (wgt + 1e-5f);
+#endif
                 if (CACHE && pass == 0 && S_fp > 0 && !(s & 1)) park(s >> 1, acc2, hd0, hd1, hd2, hd3);
                 if (pass == 1 && a.dbg_zfine && h == 0 && rayok) a.dbg_zfine[gr * S_fp + s] = z;
                 // advance: dists[-1] repeats dists[-2] (:36-37)
@@ -2056,8 +2260,22 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
             // ---- inverse-CDF resampling (utils/nerf_util.py:76-117): one ray per lane, one sequential sweep over the CDF ----
             if (pass == 0 && S_fp > 0) {
                 const int nw = S_c - 2, nb = S_c - 1;
+#if HAV_WSUM_INLOOP
+                const float sum = wsum;
+#else
                 float sum = 0.f;
-                for (int i = 0; i < nw; ++i) sum += (HAV_SELF_LOAD(CACHE ? &wrow[(1 + i) * 32 + j] : &wpark[1 + i]) + 1e-5f);
+                for (int i0 = 0; i0 < nw; i0 += 8) {          // eight loads in flight per round trip, summed in index order
+                    float t8[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) t8[q] = (i0 + q < nw) ? (CACHE ? HAV_SELF_LOAD(&wrow[(1 + i0 + q) * 32 + j]) : __builtin_nontemporal_load(&wpark[1 + i0 + q])) : 0.f;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) if (i0 + q < nw) sum += (t8[q] + 1e-5f);
+                }
+#endif
+                // the weights come back through an 8-deep rotation of registers: a lone load in this phase queues behind the other waves' tap
+                // loads in the texture path (~1 K cycles each, measured: the two passes over 62 weights were 170 K cycles per block)
+                auto wload = [&](int i) -> float { return (i < nw) ? (CACHE ? HAV_SELF_LOAD(&wrow[(1 + i) * 32 + j]) : __builtin_nontemporal_load(&wpark[1 + i])) : 0.f; };
+                float wq0 = wload(0), wq1 = wload(1), wq2 = wload(2), wq3 = wload(3), wq4 = wload(4), wq5 = wload(5), wq6 = wload(6), wq7 = wload(7);
                 float run = 0.f, cdf_lo = 0.f;
                 int k = 0;
                 auto u_of = [&](int kk) -> float {
@@ -2074,7 +2292,9 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                 float zi = z_coarse<RM>(a, gr, rkey, 0, near, far), zi1 = z_coarse<RM>(a, gr, rkey, 1, near, far);
                 float zi2 = z_coarse<RM>(a, gr, rkey, 2, near, far);
                 for (int i = 0; i < nw; ++i) {
-                    run += (HAV_SELF_LOAD(CACHE ? &wrow[(1 + i) * 32 + j] : &wpark[1 + i]) + 1e-5f) / sum;
+                    const float wi = wq0;
+                    wq0 = wq1; wq1 = wq2; wq2 = wq3; wq3 = wq4; wq4 = wq5; wq5 = wq6; wq6 = wq7; wq7 = wload(i + 8);
+                    run += (wi + 1e-5f) / sum;
                     const float cdf_hi = run;
                     const float bl = 0.5f * (zi1 + zi), ba = 0.5f * (zi2 + zi1);
                     float dnm = cdf_hi - cdf_lo;
@@ -2155,7 +2375,7 @@ static int mlp_prec(const HavRenderParams* p) { return p->mlp_mode == HAV_MLP_F3
 static long long fine_cache_slot_floats(const HavRenderParams* p)
 {
     const long long S_fp = (p->S_c + 1) / 2 + p->S_f;
-    return S_fp * ((mlp_prec(p) == 2 ? WS_H2_FLOATS / 2 : WS_H2_FLOATS) + 128 + 32)       // features (fp16 mode) or hidden units
+    return S_fp * (((mlp_prec(p) == 2 && HAV_FEATPARK) ? WS_H2_FLOATS / 2 : WS_H2_FLOATS) + 128 + 32)       // features (fp16 mode) or hidden units
            + (long long)((p->S_c + 3) & ~3) * 32;                                                // + the coarse weights of the block, [S_c][32]
 }
 // Would a workspace be used at all?  Measured on MI355X: with stratified jitter on (the production setting)
@@ -2222,7 +2442,8 @@ struct BlkEntry { int rm, prec, cm; const void* fn; void (*launch)(int, size_t, 
 #define BLK(R_, P_, C_) {R_, P_, C_, (const void*)hav_march_blk_kernel<R_, P_, C_>, launch_blk<R_, P_, C_>}
 static const BlkEntry kBlk[] = {
 #ifdef HAV_FAST_BUILD      // development builds: the production kernel only (seconds instead of a minute per compile)
-    BLK(0, 2, 2), BLK(1, 2, 2), BLK(0, 1, 0), BLK(1, 1, 0)};      // + the fp16 guard's bf16 stand-ins
+    BLK(0, 2, 2), BLK(1, 2, 2), BLK(0, 1, 0), BLK(1, 1, 0),       // + the fp16 guard's bf16 stand-ins
+    BLK(0, 1, 2), BLK(1, 1, 2)};                                  // + the bf16 production pair
 #else
     BLK(0, 0, 0), BLK(2, 0, 0),
     BLK(0, 1, 0), BLK(1, 1, 0), BLK(2, 1, 0), BLK(0, 1, 1), BLK(1, 1, 1), BLK(2, 1, 1), BLK(0, 1, 2), BLK(1, 1, 2), BLK(2, 1, 2),
@@ -2307,7 +2528,7 @@ extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, cons
     if (v.blk) {
         a.scr_floats = ((p->S_f > 0 ? p->S_f : 1) * 32 + 3) & ~3;
         auto lds_of = [&](int prec) {
-            return ((size_t)(prec == 2 ? LDSH_FLOATS : (prec == 1 ? LDS3_FLOATS : LDS_FLOATS)) + 256 + (size_t)MARCH_WAVES * a.scr_floats + 4) * sizeof(float);
+            return ((size_t)(prec == 2 ? LDSH_FLOATS : (prec == 1 ? LDS3_FLOATS : LDS_FLOATS)) + HAV_LDS_BIAS + (size_t)MARCH_WAVES * a.scr_floats + 4) * sizeof(float);
         };
         if (lds_of(v.prec) > 160 * 1024 || (v.guard && lds_of(1) > 160 * 1024)) return HAV_EUNSUP;
         const int gridb = march_grid_blocks(p);
@@ -2342,6 +2563,9 @@ extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, cons
 #ifndef HAV_FAST_BUILD
         if (random) hipLaunchKernelGGL(hav_march_f32_kernel<true>, dim3(grid), dim3(MARCH_THREADS), lds, st, a);
         else hipLaunchKernelGGL(hav_march_f32_kernel<false>, dim3(grid), dim3(MARCH_THREADS), lds, st, a);
+#else
+        (void)grid; (void)lds;
+        return HAV_EUNSUP;          // development build (tools/build_variant.sh): the ray-pair kernel is not compiled in
 #endif
         HAV_LAUNCH_CHECK();
     }

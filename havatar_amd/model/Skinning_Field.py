@@ -87,9 +87,9 @@ class Deformation_Field_new(nn.Module):
             inside = torch.ones(pts.shape[0], dtype=torch.bool, device=dev)
             for a in range(3):
                 inside &= (pts[:, a] > vol_thr[a][0]) & (pts[:, a] < vol_thr[a][1])
-            gt = inside.float().unsqueeze(-1)
             vol = self.canonical_Wvolume()
             w = voxel_feature(xyz=self.gridwarper(pts.unsqueeze(0)), volume_feat=vol[:, 0:1] if pose_space else vol[:, 1:])
+            gt = inside.to(w.dtype).unsqueeze(-1)          # (the reference's torch.zeros(...): the default dtype)
             loss = torch.nn.functional.binary_cross_entropy(torch.clamp(w, 0.0, 1.0)[0], gt)
             loss.backward()
             opt.step()

@@ -235,7 +235,8 @@ class _FusedConvBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, W, s, d, noise, nw, bias, scale, slope, gain, act):
-        x, W = x.contiguous(), W.contiguous()
+        # (x and W arrive contiguous: fused_block() makes them so OUTSIDE the node -- a .contiguous() in here, where grad mode is off, would
+        # save a detached copy of a channels-last / sliced input and cut the second-order graph of the create_graph branch below)
         y = conv3x3(x, pack(W, scale), W.shape[0], s=s, d=d, noise=noise, noise_weight=nw, bias=bias, slope=slope, gain=gain, act=act)
         ctx.save_for_backward(x, W, s, d, noise, nw, bias, y)
         ctx.cfg = (float(scale), float(slope), float(gain), bool(act))
@@ -263,7 +264,7 @@ class _FusedConvBlock(torch.autograd.Function):
                 slots = {0: x, 1: W, 2: s, 3: d, 5: nw, 6: bias}
                 if conv2d_gradfix.weight_gradients_disabled:
                     slots.pop(1)
-                idx = [k for k, t in slots.items() if t is not None and need[k] and t.requires_grad]
+                idx = [k for k, t in slots.items() if t is not None and need[k]]          # by ctx.needs_input_grad alone
                 got = torch.autograd.grad(v, [slots[k] for k in idx], g, create_graph=True, allow_unused=True) if idx else ()
             out = [None] * 11
             for k, gk in zip(idx, got):
@@ -305,7 +306,7 @@ def fused_block(x, W, scale, s=None, d=None, noise=None, noise_weight=None, bias
     f = lambda t: None if t is None else t.contiguous()
     if noise is not None and noise_weight is None:
         noise = None
-    return _FusedConvBlock.apply(x, W, f(s), f(d), f(noise), f(noise_weight), f(bias), scale, slope, gain, act)
+    return _FusedConvBlock.apply(x.contiguous(), W.contiguous(), f(s), f(d), f(noise), f(noise_weight), f(bias), scale, slope, gain, act)
 
 
 def upconv_eligible(x, weight):

@@ -50,9 +50,11 @@ class RayMarcher:
         self.rng_counter = None
         self.rng_offset = 0
         self.seed = 0x9E3779B97F4A7C15
-        # arithmetic of the two dense layers (include/havatar.h): fp16 double split (default), bf16 triple split, exact fp32 MFMA
-        self.mlp_mode = {"f32": _lib.HAV_MLP_F32, "split": _lib.HAV_MLP_SPLIT_BF16, "bf16": _lib.HAV_MLP_SPLIT_BF16}.get(
-            os.environ.get("HAVATAR_MLP", "half"), _lib.HAV_MLP_SPLIT_F16)
+        # arithmetic of the two dense layers (include/havatar.h).  Default: the bf16 triple split -- every operand = hi + mid + lo bf16
+        # exactly (24 bits, as wide as the reference's fp32), six partial products.  HAVATAR_MLP=half selects the fp16 double split
+        # (22-bit operands: narrower than fp32, ~25 % faster), HAVATAR_MLP=f32 the exact fp32 MFMA (an fmaf chain).
+        self.mlp_mode = {"f32": _lib.HAV_MLP_F32, "half": _lib.HAV_MLP_SPLIT_F16, "fp16": _lib.HAV_MLP_SPLIT_F16}.get(
+            os.environ.get("HAVATAR_MLP", "split"), _lib.HAV_MLP_SPLIT_BF16)
         # fine-pass cache: re-use the coarse pass's field values for the even coarse samples the merged list repeats
         self.fine_cache = os.environ.get("HAVATAR_FINE_CACHE", "1") != "0"
         self._workspace = None

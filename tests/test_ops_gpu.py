@@ -880,6 +880,68 @@ def test_fused_training_nodes_support_double_backward_and_no_weight_gradients():
         gv.pow(2).sum().backward()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["contiguous", "channels_last", "sliced"])
+def test_fused_conv_block_double_backward_and_no_weight_gradients(layout):
+    """_FusedConvBlock (the node StyledConv / ConvLayer training goes through) under create_graph=True and inside
+    conv2d_gradfix.no_weight_gradients(): second-order gradients equal the ATen statement's in fp64 -- also for an input that is NOT
+    contiguous (channels-last, or a slice of a wider tensor): the contiguous copy is made outside the node, so the graph back to the
+    caller's tensor stays whole."""
+    from havatar_amd.native import conv
+    from havatar_amd.model.op import conv2d_gradfix
+    g = torch.Generator(device=DEV).manual_seed(77)
+    B, Cin, Cout, H = 2, 64, 64, 32          # (W % 32 == 0: conv.eligible)
+    r = lambda *sh: torch.randn(*sh, device=DEV, generator=g)
+    xw0 = r(B, Cin + 8, H, H)                       # the "sliced" layout takes channels 4 .. Cin+4 of this
+    W0, s0, d0, b0 = r(Cout, Cin, 3, 3), 1.0 + 0.3 * r(B, Cin), 0.5 + torch.rand(B, Cout, device=DEV, generator=g), 0.2 * r(Cout)
+    noise, nw0 = r(B, 1, H, H), torch.full((1,), 0.37, device=DEV)
+    scale = 1.0 / (Cin * 9) ** 0.5
+
+    def leaf_and_view(dt):
+        if layout == "sliced":
+            leaf = xw0.to(dt).clone().requires_grad_(True)
+            return leaf, leaf[:, 4:4 + Cin]
+        leaf = xw0[:, 4:4 + Cin].to(dt).contiguous().clone()
+        if layout == "channels_last":
+            leaf = leaf.contiguous(memory_format=torch.channels_last)
+        leaf.requires_grad_(True)
+        return leaf, leaf
+
+    def penalty(dt, fused):
+        leaf, x = leaf_and_view(dt)
+        assert (layout == "contiguous") == x.is_contiguous()
+        W, s, d, nw, b = (t.to(dt).clone().requires_grad_(True) for t in (W0, s0, d0, nw0, b0))
+        if fused:
+            assert conv.block_eligible(x, W)
+            y = conv.fused_block(x, W, scale, s=s, d=d, noise=noise, noise_weight=nw, bias=b, act=True)
+        else:
+            v = torch.nn.functional.conv2d(x * s.view(B, Cin, 1, 1), W * scale, padding=1) * d.view(B, Cout, 1, 1) + nw * noise.to(dt) + b.view(1, -1, 1, 1)
+            y = torch.nn.functional.leaky_relu(v, 0.2) * 2 ** 0.5
+        gx, gs = torch.autograd.grad(y.pow(2).sum(), (leaf, s), create_graph=True)     # first order, graph kept
+        assert gx.requires_grad and gs.requires_grad
+        (gx.pow(2).sum() + gs.pow(2).sum()).backward()                                   # second order
+        return [t.grad.double() for t in (leaf, W, s, d, b)]
+
+    want, got = penalty(torch.float64, False), penalty(torch.float32, True)
+    for name, a, b_ in zip(("x", "W", "s", "d", "bias"), got, want):
+        assert (a - b_).abs().max().item() <= 5e-4 * b_.abs().max().item(), (layout, name, (a - b_).abs().max().item(), b_.abs().max().item())
+
+    # no_weight_gradients(): no weight gradient is formed, the data gradient is unchanged -- first order and under create_graph
+    leaf, x = leaf_and_view(torch.float32)
+    W = W0.clone().requires_grad_(True)
+    y = conv.fused_block(x, W, scale, bias=b0, act=True)
+    with conv2d_gradfix.no_weight_gradients():
+        y.sum().backward(retain_graph=True)
+    assert W.grad is None and leaf.grad is not None
+    gx_only = leaf.grad.clone()
+    leaf.grad = None
+    with conv2d_gradfix.no_weight_gradients():
+        gx2, = torch.autograd.grad(y.sum(), leaf, create_graph=True)
+    assert torch.allclose(gx2, gx_only, rtol=1e-4, atol=1e-6)
+    y.sum().backward()
+    assert W.grad is not None and torch.allclose(leaf.grad, gx_only, rtol=1e-5, atol=1e-7)
+
+
 def test_native_install_registers_the_bare_module_names_the_reference_imports():
     """`havatar_amd.native.install()` puts the ctypes-backed modules under the BARE names the reference's
     model/op/*.py import (`import fused`, model/op/fused_act.py:20; `import upfirdn2d as upfirdn2d_op`, model/op/upfirdn2d.py:19).

@@ -21,7 +21,7 @@ rm.set_mlp(t(m["W1"]), t(m["b1"]), t(m["W2"]), t(m["b2"]), t(m["Wa"]), t(m["ba"]
 rm.set_triplane(t(sc["planes"]))
 rays, bg, inv_T, vol = t(sc["rays"]), t(sc["bg"]), t(sc["inv_T"]), t(sc["vol"])
 L = _lib.lib()
-buf = (C.c_ulonglong * 12)()
+buf = (C.c_ulonglong * 24)()          # HAV_NPROF entries
 for _ in range(2):
     rm.render(rays, bg, inv_T, vol, 64, 16, perturb=perturb, coarse_outputs=False)
 L.hav_debug_read_prof(buf)
