@@ -24,9 +24,12 @@
 //      - split-operand bf16 (HAV_MLP_SPLIT_BF16, mode 0 of the ABI and the guard's fallback): hi + mid + lo bf16 exactly, six
 //        partial products on v_mfma_f32_32x32x16_bf16 (mfma_split3) -- fp32-sgemm-class results over fp32's whole range;
 //      - exact fp32: v_mfma_f32_32x32x2_f32 (an fmaf chain).
-//  * Measured on gfx950 (tools/ubench): MFMA does not overlap with VALU work -- neither from the same wave nor from the other
-//    wave of the SIMD.  Kernel time = MFMA cycles + VALU issue cycles + unhidden tap latency, so the matrix work was cut
-//    algebraically:
+//  * Measured on gfx950 (tools/ubench/mfma_overlap2.hip, round 4): plain VALU and LDS instructions DO issue beside the matrix pipe --
+//    a partner wave's v_fma_f32 / v_max / v_cvt stream keeps 95 % of its pace beside a saturating MFMA stream, ~6 fillers fit behind
+//    each v_mfma_f32_32x32x16 of the same wave -- and only PACKED fp32 VALU (v_pk_fma/mul/add_f32) serialises with it.  (Rounds 1-3
+//    read "VALU does not overlap with MFMA" off microbenchmarks whose C fillers hipcc had packed into v_pk_fma_f32.)  What bounds the
+//    kernel is the socket power cap: it runs at 2.0-2.2 of 2.4 GHz, and cycle savings come back as lower clock.  The
+//    matrix work -- the most power-hungry part -- was cut algebraically:
 //      - Layer 1's 128 tri-plane columns are folded into the planes once per frame: bilinear interpolation is linear,
 //        W1f (sum_tap w_tap texel_tap) = sum_tap w_tap (W1f texel_tap).  hav_triplane_prepare projects every texel
 //        through W1f (a 128x64 GEMM over 32768 texels = 0.5 GFLOP per frame, vs 2.8 TFLOP for the march) into
@@ -912,7 +915,7 @@ __device__ __forceinline__ void mfma_split2h(f32x16 (&acc)[NM], const uint4* fra
 }
 #undef KEEP
 
-// ---- Interleaved, hand-placed matrix sequences (round 4; HAV_MFMA_IL, default 1) ------------------------------------------------
+// ---- Interleaved, hand-placed matrix sequences (round 4; HAV_MFMA_IL, default 0: measured neutral under the power cap) ------------------------------------------------
 // What the compiler made of the two routines below (hipcc 7.2, -O3): it sinks every fragment read next to the MFMA that consumes it
 // (ds_read_b128 -> s_waitcnt lgkmcnt(0) -> v_mfma: a full LDS round trip per group, whatever prefetch distance the source spells out),
 // it puts the 12-36 VALU instructions of a chunk's operand split in FRONT of the chunk's first MFMA, and the three (six) products of
@@ -1417,7 +1420,9 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a_in, const LaneCtx
         hd0 += half_swap(hd0, h); hd1 += half_swap(hd1, h);
         hd2 += half_swap(hd2, h); hd3 += half_swap(hd3, h);
         if (BLK) {          // block kernel: LDS copy (a global load here queued behind the other waves' tap loads in every tile: ~1 K cycles)
-            const float4 b4 = sBt[64];
+            int b4_off = 64;          // its own opaque offset: through sBt the base of the bias reads would stay live across both layers
+            asm volatile("" : "+v"(b4_off));
+            const float4 b4 = L.sB[b4_off];
             hd0 += b4.x; hd1 += b4.y; hd2 += b4.z; hd3 += b4.w;
         } else {
             const auto b4 = __builtin_amdgcn_raw_buffer_load_b128(L.wrs, 0, OFF_B4 * 4, 0);
@@ -1772,6 +1777,9 @@ __device__ __forceinline__ float4 nt_load4(const float4* p)
 }
 #ifndef HAV_GQ2
 #define HAV_GQ2 16         // float4 loads per gather stage in the fine-maps-only variant (its register budget allows a whole tap: -2 %)
+#endif
+#ifndef HAV_RESAMPLE_PF
+#define HAV_RESAMPLE_PF 8      // coarse weights in flight in the resampling sweep (8 or 4)
 #endif
 #ifndef HAV_WSUM_INLOOP
 #define HAV_WSUM_INLOOP 0
@@ -2151,6 +2159,20 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                     for (int r = 0; r < 16; ++r) hsumB[m][r] = 0.f;
                 constexpr int NROW = FEATPARK ? 8 : 16;
                 constexpr int PF = HAV_STAGEB_PF < 1 ? 1 : (FEATPARK ? HAV_STAGEB_PF : (HAV_STAGEB_PF + 1) / 2);      // entries in flight (32 / 64 registers each)
+                if constexpr (PF == 1) {          // one entry at a time (the default: more in flight measured slower, and cost registers)
+                for (int e = 0; e < S; ++e) {
+                    const float4* H2 = reinterpret_cast<const float4*>(slot + (size_t)e * ENTF);
+                    const float wgt = HAV_SELF_LOAD(&slot[(size_t)e * ENTF + H2F + 128 + j]);
+#pragma unroll
+                    for (int q = 0; q < NROW; ++q) {
+                        const float4 v = nt_load4(&H2[q * 64 + lane]);
+                        hsumB[q >> 2][4 * (q & 3) + 0] = fmaf(wgt, v.x, hsumB[q >> 2][4 * (q & 3) + 0]);
+                        hsumB[q >> 2][4 * (q & 3) + 1] = fmaf(wgt, v.y, hsumB[q >> 2][4 * (q & 3) + 1]);
+                        hsumB[q >> 2][4 * (q & 3) + 2] = fmaf(wgt, v.z, hsumB[q >> 2][4 * (q & 3) + 2]);
+                        hsumB[q >> 2][4 * (q & 3) + 3] = fmaf(wgt, v.w, hsumB[q >> 2][4 * (q & 3) + 3]);
+                    }
+                }
+                } else {
                 float4 vb[PF][NROW];
                 float wb[PF];
                 auto ldB = [&](int u, int e) {
@@ -2180,6 +2202,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                         asm volatile("" ::: "memory");          // the refill stays behind the FMAs that free its registers
                         ldB(u, e0 + u + PF);
                     }
+                }
                 }
                 TICK(3);
                 emit(1, hsumB, c0, c1, c2, dep, accw, wmax, FEATPARK ? hsumB : nullptr);       // (feature parking: hsumB[0..1] are the features)
@@ -2264,18 +2287,22 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                 const float sum = wsum;
 #else
                 float sum = 0.f;
-                for (int i0 = 0; i0 < nw; i0 += 8) {          // eight loads in flight per round trip, summed in index order
-                    float t8[8];
+                constexpr int SPF = HAV_RESAMPLE_PF;
+                for (int i0 = 0; i0 < nw; i0 += SPF) {          // SPF loads in flight per round trip, summed in index order
+                    float t8[SPF];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) t8[q] = (i0 + q < nw) ? (CACHE ? HAV_SELF_LOAD(&wrow[(1 + i0 + q) * 32 + j]) : __builtin_nontemporal_load(&wpark[1 + i0 + q])) : 0.f;
+                    for (int q = 0; q < SPF; ++q) t8[q] = (i0 + q < nw) ? (CACHE ? HAV_SELF_LOAD(&wrow[(1 + i0 + q) * 32 + j]) : __builtin_nontemporal_load(&wpark[1 + i0 + q])) : 0.f;
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) if (i0 + q < nw) sum += (t8[q] + 1e-5f);
+                    for (int q = 0; q < SPF; ++q) if (i0 + q < nw) sum += (t8[q] + 1e-5f);
                 }
 #endif
                 // the weights come back through an 8-deep rotation of registers: a lone load in this phase queues behind the other waves' tap
                 // loads in the texture path (~1 K cycles each, measured: the two passes over 62 weights were 170 K cycles per block)
                 auto wload = [&](int i) -> float { return (i < nw) ? (CACHE ? HAV_SELF_LOAD(&wrow[(1 + i) * 32 + j]) : __builtin_nontemporal_load(&wpark[1 + i])) : 0.f; };
-                float wq0 = wload(0), wq1 = wload(1), wq2 = wload(2), wq3 = wload(3), wq4 = wload(4), wq5 = wload(5), wq6 = wload(6), wq7 = wload(7);
+                constexpr int WPF = HAV_RESAMPLE_PF;
+                float wq[WPF];
+#pragma unroll
+                for (int q = 0; q < WPF; ++q) wq[q] = wload(q);
                 float run = 0.f, cdf_lo = 0.f;
                 int k = 0;
                 auto u_of = [&](int kk) -> float {
@@ -2292,8 +2319,10 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                 float zi = z_coarse<RM>(a, gr, rkey, 0, near, far), zi1 = z_coarse<RM>(a, gr, rkey, 1, near, far);
                 float zi2 = z_coarse<RM>(a, gr, rkey, 2, near, far);
                 for (int i = 0; i < nw; ++i) {
-                    const float wi = wq0;
-                    wq0 = wq1; wq1 = wq2; wq2 = wq3; wq3 = wq4; wq4 = wq5; wq5 = wq6; wq6 = wq7; wq7 = wload(i + 8);
+                    const float wi = wq[0];
+#pragma unroll
+                    for (int q = 0; q + 1 < WPF; ++q) wq[q] = wq[q + 1];
+                    wq[WPF - 1] = wload(i + WPF);
                     run += (wi + 1e-5f) / sum;
                     const float cdf_hi = run;
                     const float bl = 0.5f * (zi1 + zi), ba = 0.5f * (zi2 + zi1);

@@ -497,7 +497,7 @@ def test_shipping_device_rng_kernels_vs_oracle_on_their_own_random_numbers(mlp):
     assert rm.last_variant == "hav_march_blk_kernel<2, %d, 2>" % prec
     for a_, b_ in zip(dev_out[3:7], inj_out[3:7]):                            # (b) its sibling on the same numbers
         d = (a_ - b_).abs().reshape(H * W, -1).amax(1)
-        assert d.median().item() <= 2e-6 and (d > 1e-4).float().mean().item() <= 2e-3 and d.max().item() <= 2e-2, (d.median().item(), (d > 1e-4).float().mean().item(), d.max().item())
+        assert d.median().item() <= 2e-6 and (d > 1e-4).float().mean().item() <= 2e-3 and d.max().item() <= 5e-2, (d.median().item(), (d > 1e-4).float().mean().item(), d.max().item())
 
 
 @pytest.mark.parametrize("mlp", ["split", "half"])

@@ -7,7 +7,7 @@ cd "$GRAFT_REPO_ROOT"
 TAG=${1:-run}; shift || true
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-BENCH="python bench.py --steps 8 --warmup 2 --no-cpu-baseline --live-pmc 0 $*"
+BENCH="python bench.py --steps 8 --warmup 2 --no-cpu-baseline --live-pmc 0 --extras 0 $*"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $BENCH > $OUT/bench_kt.log 2>&1
 grep -m1 "^{\"metric\"" $OUT/bench_kt.log > $OUT/bench_line.json
 for pass in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" \
