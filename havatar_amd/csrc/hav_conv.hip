@@ -44,10 +44,12 @@ typedef float fl2_t __attribute__((ext_vector_type(2)));
 #define CV_TASKS (CV_PIX * 8)            // (pixel, channel pair) staging tasks per chunk
 #define CV_TPT ((CV_TASKS + 255) / 256)  // per thread
 #define CV_WSHIFT 256.0f
-// wait states behind the matrix instructions of a chunk, before the staging code of the next one (the operand hazard
-// they were added for does not exist; what remains is their effect as a scheduling fence -- measured before being touched)
+// Rounds 1-3 put 32 wait states behind the matrix instructions of a chunk, before the staging code of the next one, against an operand
+// hazard that does not exist (tools/ubench/mfma_war.hip).  Round 4 re-validated the kernels without them (every parity test
+// of tests/test_ops_gpu.py incl. test_conv3x3_full_occupancy_runs_are_bitwise_identical: profiles/r04_conv_nopad.txt) and dropped them; the
+// asm statement stays as a scheduling fence (it ties the accumulators), empty.  -DCV_MFMA_PAD='"s_nop 15\n\ts_nop 15"' brings them back.
 #ifndef CV_MFMA_PAD
-#define CV_MFMA_PAD "s_nop 15\n\ts_nop 15"
+#define CV_MFMA_PAD ""
 #endif
 
 extern "C" int64_t hav_conv3x3_packed_bytes(int Cout, int Cin) { return (int64_t)(Cin / 16) * 9 * (Cout / 32) * 2 * 64 * 16; }
@@ -707,7 +709,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3s2_split_kernel(ConvS2Args a)
                 acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh, acc[rr], 0, 0, 0);
             }
         }
-        asm volatile(CV_MFMA_PAD : "+v"(acc[0]), "+v"(acc[1]));          // operand registers are read after issue
+        asm volatile(CV_MFMA_PAD : "+v"(acc[0]), "+v"(acc[1]));
         if (cc + 1 < NC) stash(buf ^ 1, cc + 1, sv);
         __syncthreads();
     }
