@@ -85,6 +85,8 @@ def lib():
     L.hav_style_demod_batched.restype = i32
     L.hav_styled_epilogue.argtypes = [vp, vp, vp, vp, vp, vp, f32, f32, i32, i32, i64, i32, vp]
     L.hav_styled_epilogue.restype = i32
+    L.hav_torgb.argtypes = [vp, vp, vp, vp, vp, vp, f32, i32, i32, i32, i64, vp]
+    L.hav_torgb.restype = i32
     L.hav_demod_fwd.argtypes = [vp, vp, vp, vp, f32, f32, i32, i32, i32, i32, vp]
     L.hav_demod_fwd.restype = i32
     L.hav_demod_bwd.argtypes = [vp] * 8 + [f32, i32, i32, i32, i32, vp]

@@ -1246,3 +1246,144 @@ extern "C" int hav_demod_bwd(float* gs, float* gW, float* gq_scratch, const floa
     HAV_LAUNCH_CHECK();
     return 0;
 }
+
+// ================================================================================================
+// ToRGB: the modulated 1x1 convolution (demodulate=False) + bias + skip add of a StyleGAN2 generator level
+// (reference model/styleUnet.py:602-628, ModulatedConv2d :165-297 with kernel_size 1) as ONE pass over the activations:
+//   y[b,o,p] = sum_i (scale * W[o,i] * s[b,i]) * x[b,i,p] + bias[o] (+ skip[b,o,p])
+// The reference's route is x * s (a full read + write of x), an fp32 GEMM with 3 or 12 output rows (MIOpen: NHWC transposes around it),
+// a bias add and the skip add: four to five passes over x for 2 * Cout FLOP per element.  Here a workgroup owns 64 pixel quads; its
+// four waves split the input channels, every lane streams float4s of x (1 KB per wave and load, coalesced), the Cout x Cin weight
+// matrix with the modulation folded in sits in LDS ([i][Cout] rows: three broadcast ds_read_b128 per channel), fp32 FMA chains in
+// channel order inside a slice, the four slices added in a fixed order (bit-reproducible).  HBM-bound: 4 B per element of x.
+// ================================================================================================
+typedef float nt_f4v __attribute__((ext_vector_type(4)));
+template <int COUT, int KS>          // KS = waves of a workgroup that split the input channels (4: small maps / many channels; 1: large maps)
+__global__ void __launch_bounds__(256) torgb_kernel(float* __restrict__ out, const float* __restrict__ x, const float* __restrict__ W,
+                                                    const float* __restrict__ s, const float* __restrict__ bias, const float* __restrict__ skip,
+                                                    float scale, int Cin, int64_t HW)
+{
+    constexpr int CP = (COUT + 3) & ~3;                      // row pitch of the LDS weight matrix (floats)
+    constexpr int QB = 256 / KS;                             // pixel quads per workgroup
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* wm = sm;                                          // [Cin][CP]
+    const int b = blockIdx.y, tid = threadIdx.x, q = tid % QB, k = tid / QB;
+    for (int i = tid; i < Cin; i += 256) {                   // one input channel per thread: COUT coalesced weight loads in flight
+        const float sv = s ? s[(size_t)b * Cin + i] : 1.0f;
+        float wv[CP];
+#pragma unroll
+        for (int o = 0; o < CP; ++o) wv[o] = o < COUT ? W[(size_t)o * Cin + i] : 0.f;
+#pragma unroll
+        for (int o = 0; o < CP; ++o) wm[(size_t)i * CP + o] = o < COUT ? (scale * wv[o]) * sv : 0.f;          // (scale * W) * s: ModulatedConv2d's order (:250)
+    }
+    __syncthreads();
+    const int64_t quad = (int64_t)blockIdx.x * QB + q, nquad = HW >> 2;
+    const bool live = quad < nquad;
+    const int per = (Cin + KS - 1) / KS, i0 = k * per, i1 = min(Cin, i0 + per);
+    float4 acc[COUT];
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* xb = reinterpret_cast<const float4*>(x + (size_t)b * Cin * HW) + (live ? quad : 0);
+    const int64_t cs = HW >> 2;                              // float4s between consecutive channels
+    constexpr int U = KS == 1 ? 8 : 4;                       // channel loads in flight per lane
+    int i = i0;
+    for (; i + U <= i1; i += U) {
+        float4 xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const nt_f4v t = __builtin_nontemporal_load(reinterpret_cast<const nt_f4v*>(xb + (int64_t)(i + u) * cs)); xv[u] = make_float4(t.x, t.y, t.z, t.w); }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float4* wr = reinterpret_cast<const float4*>(wm + (size_t)(i + u) * CP);
+#pragma unroll
+            for (int o4 = 0; o4 < CP / 4; ++o4) {
+                const float4 w4 = wr[o4];
+                const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int o = 4 * o4 + e;
+                    if (o < COUT) {
+                        acc[o].x = fmaf(wv[e], xv[u].x, acc[o].x); acc[o].y = fmaf(wv[e], xv[u].y, acc[o].y);
+                        acc[o].z = fmaf(wv[e], xv[u].z, acc[o].z); acc[o].w = fmaf(wv[e], xv[u].w, acc[o].w);
+                    }
+                }
+            }
+        }
+    }
+    for (; i < i1; ++i) {
+        const float4 xv = xb[(int64_t)i * cs];
+        const float* wr = wm + (size_t)i * CP;
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) {
+            const float w = wr[o];
+            acc[o].x = fmaf(w, xv.x, acc[o].x); acc[o].y = fmaf(w, xv.y, acc[o].y);
+            acc[o].z = fmaf(w, xv.z, acc[o].z); acc[o].w = fmaf(w, xv.w, acc[o].w);
+        }
+    }
+    if (KS > 1) {
+        float4* r4 = reinterpret_cast<float4*>(sm + (size_t)Cin * CP);          // [KS - 1][COUT][QB]
+        if (k > 0) {
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) r4[((k - 1) * COUT + o) * QB + q] = acc[o];
+        }
+        __syncthreads();
+        if (k == 0) {
+#pragma unroll
+            for (int o = 0; o < COUT; ++o)
+#pragma unroll
+                for (int kk = 0; kk < KS - 1; ++kk) {                              // slices 1, 2, ... in this order
+                    const float4 u = r4[(kk * COUT + o) * QB + q];
+                    acc[o].x += u.x; acc[o].y += u.y; acc[o].z += u.z; acc[o].w += u.w;
+                }
+        }
+    }
+    if (k == 0 && live) {
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) {
+            float4 t = acc[o];
+            const float bb = bias ? bias[o] : 0.f;
+            t.x += bb; t.y += bb; t.z += bb; t.w += bb;
+            const size_t off = ((size_t)b * COUT + o) * HW + (size_t)quad * 4;
+            if (skip) {
+                const float4 sk = *reinterpret_cast<const float4*>(skip + off);
+                t.x += sk.x; t.y += sk.y; t.z += sk.z; t.w += sk.w;
+            }
+            *reinterpret_cast<float4*>(out + off) = t;
+        }
+    }
+}
+
+template <int COUT, int KS>
+static int torgb_launch(float* out, const float* x, const float* W, const float* s, const float* bias, const float* skip, float scale,
+                        int B, int Cin, int64_t HW, hipStream_t st)
+{
+    constexpr int CP = (COUT + 3) & ~3, QB = 256 / KS;
+    const size_t lds = ((size_t)Cin * CP + (size_t)(KS - 1) * COUT * QB * 4) * sizeof(float);
+    if (lds > 160 * 1024) return HAV_EUNSUP;
+    static bool attr_done = false;                           // (a race here only repeats an idempotent call)
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)torgb_kernel<COUT, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    const dim3 grid((unsigned)(((HW >> 2) + QB - 1) / QB), (unsigned)B);
+    hipLaunchKernelGGL((torgb_kernel<COUT, KS>), grid, dim3(256), lds, st, out, x, W, s, bias, skip, scale, Cin, HW);
+    HAV_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int hav_torgb(float* out, const float* x, const float* W, const float* s, const float* bias, const float* skip, float scale,
+                         int B, int Cout, int Cin, int64_t HW, void* stream)
+{
+    if (!out || !x || !W || B < 1 || Cin < 1 || HW < 4) return HAV_EINVAL;
+    if ((Cout != 3 && Cout != 12) || Cin > 1024 || (HW & 3)) return HAV_EUNSUP;
+    // large maps: one lane per pixel quad walks all channels (no reduction); smaller maps: 4 or 16 channel slices per pixel quad, so that the
+    // chain of dependent load rounds stays short (a 16^2 map with 512 channels is 8 rounds of 4 loads per lane instead of 128)
+    const int64_t work = (HW >> 2) * B;
+    const int ks = work >= 64 * 1024 && Cin <= 128 ? 1 : (work >= 4 * 1024 ? 4 : 16);
+    hipStream_t st = (hipStream_t)stream;
+#define HAV_TORGB(CO) (ks == 1 ? torgb_launch<CO, 1>(out, x, W, s, bias, skip, scale, B, Cin, HW, st) \
+                               : (ks == 4 ? torgb_launch<CO, 4>(out, x, W, s, bias, skip, scale, B, Cin, HW, st) \
+                                          : torgb_launch<CO, 16>(out, x, W, s, bias, skip, scale, B, Cin, HW, st)))
+    return Cout == 3 ? HAV_TORGB(3) : HAV_TORGB(12);
+#undef HAV_TORGB
+}

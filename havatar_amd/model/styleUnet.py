@@ -446,11 +446,18 @@ class ToRGB(nn.Module):
         self.bias = nn.Parameter(torch.zeros(1, self.out_channel, 1, 1))
 
     def forward(self, input, style, skip=None):
-        out = self.conv(input, style) + self.bias
         if skip is not None:
             skip = self.dwt(self.upsample(self.iwt(skip))) if self.use_wt else self.upsample(skip)
-            out = out + skip
-        return out
+        if self.conv._hip_inference(input) and os.environ.get("HAVATAR_FUSED_TORGB", "1") != "0":
+            # HIP inference: modulation, the 1x1 convolution, bias and skip add in one pass over the activations (hav_torgb) instead of
+            # x * s, MIOpen's GEMM between NHWC transposes, and two adds
+            from ..native import fused
+            s, _ = self.conv.style_vectors(style)
+            out = fused.torgb(input, self.conv.weight[0], s, self.bias, skip, self.conv.scale)
+            if out is not None:
+                return out
+        out = self.conv(input, style) + self.bias
+        return out if skip is None else out + skip
 
 
 def _prefetch_styles(owner, pairs, latent):

@@ -144,6 +144,32 @@ def styled_epilogue(x, demod, noise, noise_weight, bias, negative_slope=0.2, sca
     return out
 
 
+def torgb(x, weight, s, bias, skip, scale):
+    """ToRGB's modulated 1x1 convolution + bias + skip add as one pass (hav_torgb; reference model/styleUnet.py:602-628).
+    x [B,Cin,H,W], weight [Cout,Cin] (or [Cout,Cin,1,1]), s [B,Cin] | None, bias [Cout] (any shape with Cout elements) | None,
+    skip [B,Cout,H,W] | None.  Returns None when the shape is not taken (the caller keeps its ATen route)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+        return None
+    B, Cin, H, W = x.shape
+    Cout = weight.shape[0]
+    if Cout not in (3, 12) or Cin > 1024 or (H * W) % 4 or weight.numel() != Cout * Cin:
+        return None
+    x = _f32c(x, "x")
+    out = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    w2 = _f32c(weight.reshape(Cout, Cin), "weight")
+    s = _f32c(s, "s") if s is not None else None
+    bias = _f32c(bias.reshape(-1), "bias") if bias is not None else None
+    skip = _f32c(skip, "skip") if skip is not None else None
+    if skip is not None and tuple(skip.shape) != (B, Cout, H, W):
+        raise RuntimeError("torgb: skip must be [B,Cout,H,W]")
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().hav_torgb(p(out), p(x), p(w2), p(s), p(bias), p(skip), float(scale), B, Cout, Cin, H * W,
+                                  C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, "hav_torgb")
+    return out
+
+
 def haar(x, k4, inverse=False):
     """HaarTransform / InverseHaarTransform of model/styleUnet.py as one launch (hav_haar_dwt / hav_haar_idwt), bit-identical to the
     four upfirdn2d calls.  k4 [4,2,2]: the kernels of the four calls.  Returns None when the shape is not taken (caller falls back)."""

@@ -102,6 +102,15 @@ int hav_styled_epilogue(float* out, const float* x /*[B,C,HW]*/, const float* d 
                         const float* noise_weight /*device scalar or NULL*/, const float* bias /*[C] or NULL*/, float slope,
                         float gain, int B, int C, int64_t HW, int noise_batched, void* stream);
 
+/* ToRGB of a StyleGAN2 generator level (reference model/styleUnet.py:602-628: ModulatedConv2d(kernel_size=1, demodulate=False) :165-297,
+ * + bias + skip) in one pass over the activations:
+ *   out[b,o,p] = sum_i ((scale * W[o,i]) * s[b,i]) * x[b,i,p] + bias[o] + skip[b,o,p]
+ * x [B,Cin,HW], W [Cout,Cin] (the 1x1 parameter), s [B,Cin] or NULL (no modulation), bias [Cout] or NULL, skip [B,Cout,HW] or NULL (the
+ * caller's dwt(upsample(iwt(skip))) or upsample(skip)); out [B,Cout,HW] may not alias x.  fp32 FMA chains; Cout in {3, 12} (the two ToRGB
+ * widths), Cin <= 1024, HW % 4 == 0; anything else returns HAV_EUNSUP (the caller keeps its ATen route). */
+int hav_torgb(float* out, const float* x, const float* W, const float* s, const float* bias, const float* skip, float scale,
+              int B, int Cout, int Cin, int64_t HW, void* stream);
+
 /* Demodulation factors of a modulated convolution under autograd (training path):
  *   q[i,o] = scale^2 sum_k W[o,i,k]^2 (written to `q`, [Cin,Cout], kept for the backward);  d[b,o] = rsqrt(sum_i s[b,i]^2 q[i,o] + eps)
  * (model/styleUnet.py:214-227, factored form) and its backward: gs [B,Cin] = d loss / d s through d only (the caller adds the direct

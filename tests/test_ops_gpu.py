@@ -942,6 +942,56 @@ def test_fused_conv_block_double_backward_and_no_weight_gradients(layout):
     assert W.grad is not None and torch.allclose(leaf.grad, gx_only, rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,with_s,with_bias,with_skip", [
+    (1, 512, 12, 32, True, True, False), (1, 64, 12, 512, True, True, True), (2, 128, 3, 64, True, True, True),
+    (1, 33, 12, 16, False, False, True), (1, 256, 12, 128, True, False, True)])
+def test_torgb_fused_kernel_matches_the_unfused_statement(B, Cin, Cout, H, with_s, with_bias, with_skip):
+    """hav_torgb (the modulated 1x1 ToRGB convolution + bias + skip add, reference model/styleUnet.py:602-628 with
+    ModulatedConv2d(kernel_size=1, demodulate=False) :165-297) against the unfused statement in fp64; yardstick = the same statement in
+    fp32 through ATen / MIOpen.  Also: the call is bit-reproducible (the four channel slices are added in a fixed order)."""
+    from havatar_amd.native import fused
+    g = torch.Generator(device=DEV).manual_seed(B * 1000 + Cin + H)
+    r = lambda *sh: torch.randn(*sh, device=DEV, generator=g)
+    x, W = r(B, Cin, H, H), r(Cout, Cin, 1, 1)
+    s = 1.0 + 0.3 * r(B, Cin) if with_s else None
+    bias = 0.2 * r(1, Cout, 1, 1) if with_bias else None
+    skip = r(B, Cout, H, H) if with_skip else None
+    scale = 1.0 / Cin ** 0.5
+
+    def statement(dt):
+        xx = x.to(dt) * s.to(dt).view(B, Cin, 1, 1) if s is not None else x.to(dt)
+        y = torch.nn.functional.conv2d(xx, W.to(dt) * scale)
+        if bias is not None:
+            y = y + bias.to(dt)
+        return y if skip is None else y + skip.to(dt)
+
+    got = fused.torgb(x, W[:, :, 0, 0], s, bias, skip, scale)
+    assert got is not None and got.shape == (B, Cout, H, H)
+    truth, f32 = statement(torch.float64), statement(torch.float32).double()
+    floor = (f32 - truth).abs().max().item()
+    err = (got.double() - truth).abs().max().item()
+    assert err <= 3 * floor + 1e-6 * truth.abs().max().item(), (err, floor)
+    assert torch.equal(got, fused.torgb(x, W[:, :, 0, 0], s, bias, skip, scale))
+    assert fused.torgb(x, r(5, Cin), s, None, None, scale) is None          # a width the kernel does not take: the caller keeps ATen
+
+
+def test_torgb_module_takes_the_fused_kernel_and_equals_its_aten_route(monkeypatch):
+    """model/styleUnet.py::ToRGB on HIP tensors without autograd goes through hav_torgb (with the wavelet-domain skip path in front of
+    it) and gives what its ATen route gives."""
+    from havatar_amd.model.styleUnet import ToRGB
+    torch.manual_seed(3)
+    m = ToRGB(64, 64).to(DEV).eval()
+    with torch.no_grad():
+        m.bias.normal_(0, 0.1)
+    x, style, skip = torch.randn(1, 64, 64, 64, device=DEV), torch.randn(1, 64, device=DEV), torch.randn(1, 12, 32, 32, device=DEV)
+    with torch.no_grad():
+        fused_out = m(x, style, skip)
+        monkeypatch.setenv("HAVATAR_FUSED_TORGB", "0")
+        aten_out = m(x, style, skip)
+    assert fused_out.shape == aten_out.shape == (1, 12, 64, 64)
+    assert (fused_out - aten_out).abs().max().item() <= 2e-5 * aten_out.abs().max().item()
+
+
 def test_native_install_registers_the_bare_module_names_the_reference_imports():
     """`havatar_amd.native.install()` puts the ctypes-backed modules under the BARE names the reference's
     model/op/*.py import (`import fused`, model/op/fused_act.py:20; `import upfirdn2d as upfirdn2d_op`, model/op/upfirdn2d.py:19).
