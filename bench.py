@@ -744,7 +744,7 @@ def main():
                                         "config": r5["config"], "what": "BASELINE configs[4]: train_avatar.py's optimisation step (train_avatar.py:106-158), one hipGraph launch"}
             except Exception as e:
                 res["extra"]["cfg5"] = {"error": repr(e)[:300]}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # (rank 0 at N = 1 only: at N > 1 the other ranks would sit in the final barrier)
             threads = os.cpu_count() or 1
             rows = args.cpu_rows or 8
             est, took = cpu_march(sc, rows, threads)
