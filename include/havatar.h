@@ -338,16 +338,18 @@ typedef struct HavRenderParams {
 /* HavRenderParams.status bits */
 #define HAV_STATUS_FP16_FALLBACK 1u  /* the fp16-split kernel declined (range guard) and the bf16-split kernel rendered the call  */
 
-/* How the two dense layers run on the matrix cores.  All three produce fp32-sgemm-class results (parity tests run all):
- *  HAV_MLP_SPLIT_BF16: each fp32 operand is split exactly into 3 bf16 parts and the 6 leading bf16 x bf16 products are
- *                      accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (error ~2^-23 relative per product);
+/* How the two dense layers run on the matrix cores.  All three pass every parity test at the path's tolerance:
+ *  HAV_MLP_SPLIT_BF16: each fp32 operand is split EXACTLY into 3 bf16 parts (24 significant bits: not narrower than the reference's
+ *                      fp32) and the 6 leading bf16 x bf16 products are accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (error
+ *                      ~2^-23 relative per product); the Python layer's default since round 4, and what bench.py's headline times;
  *  HAV_MLP_F32:        v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fmaf chain. */
 #define HAV_MLP_SPLIT_BF16 0
 #define HAV_MLP_F32        1
 #define HAV_MLP_SPLIT_F16  2     /* each fp32 operand = hi + lo fp16 (both rounded to nearest: <= 2^-22 relative -- the size of the
                                   * fp32 accumulation error of a 128-term dot product), 3 products on v_mfma_f32_32x32x16_f16:
-                                  * half the matrix time and two thirds of the LDS of the bf16 triple split; the Python layer's
-                                  * default.  RANGE: fp16 tops out at 65504.  hav_triplane_prepare derives a rigorous bound on
+                                  * half the matrix time and two thirds of the LDS of the bf16 triple split -- 22-bit operands, i.e.
+                                  * NARROWER than fp32: opt-in (HAVATAR_MLP=half in the Python layer), ~25 % faster.
+                                  * RANGE: fp16 tops out at 65504.  hav_triplane_prepare derives a rigorous bound on
                                   * every value this mode converts to fp16 (weights, relu(h1), relu(h2)) from the weights and the
                                   * projected planes -- |h1_u| <= |b1_u| + sum_k |W1pe_uk| + max_texel |P0_u| + max_texel |P1_u|,
                                   * |h2_v| <= |b2_v| + sum_u |W2_vu| bound(h1_u) -- and stores the verdict next to the planes; when
