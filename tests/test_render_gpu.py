@@ -421,6 +421,40 @@ def test_production_variants_512_frame_24_launches(perturb, mlp):
     assert not report, (want, "launches that differ from the first (launch, rays, ray blocks):", report)
 
 
+def _pdf_floor_sensitive(sub, jitter, okw, nth=8):
+    """bool [n]: rays whose inverse-CDF resampling sits ON sample_pdf's one true discontinuity (or, with deterministic depths, on its end
+    point: below) -- `denom[denom < 1e-5] = 1`
+    (utils/nerf_util.py:112-113).  A bin of an empty stretch holds (0 + 1e-5) / sum(w + 1e-5) of the CDF: on a ray whose coarse opacity is
+    ~1 that increment IS 1e-5, and whether it compares below the floor is decided by the last bit of a cumulative sum -- the importance
+    sample then lands at the bin's start (denominator replaced by 1) or anywhere inside it.  No fp32 evaluation of the path is stable there,
+    the reference's included; which rays are affected follows from the fp64 oracle's coarse weights alone (independent of the kernel under
+    test): a ray is flagged when a denominator it uses lies within 1e-7 of the floor (fp32 CDF values near 1 carry 6e-8 of rounding)."""
+    from oracle import oracle
+    d = oracle.render_rays(sub, 64, 16, perturb=jitter, nthreads=nth, f64=True, debug=True, **okw)
+    w = d["w_coarse"][:, 1:-1] + 1e-5                                            # [n, 62]
+    cdf = np.concatenate([np.zeros((w.shape[0], 1)), np.cumsum(w / w.sum(-1, keepdims=True), -1)], -1)      # [n, 63]
+    ns = 16
+    if jitter:
+        u = np.arange(ns)[None, :] * (1.0 / ns) + okw["u_rand"].astype(np.float64) * (1.0 / ns - 1e-6)
+    else:
+        u = np.broadcast_to(np.linspace(0.0, 1.0, ns)[None, :], (w.shape[0], ns))
+    inds = (cdf[:, None, :] <= u[:, :, None]).sum(-1)                            # searchsorted(right=True)
+    below, above = np.maximum(inds - 1, 0), np.minimum(inds, cdf.shape[1] - 1)
+    den = np.take_along_axis(cdf, above, 1) - np.take_along_axis(cdf, below, 1)
+    flagged = (np.abs(den - 1e-5) <= 1e-7).any(-1)
+    slack = np.zeros(w.shape[0])
+    if not jitter:
+        # Deterministic sampling puts its last sample at u = 1 exactly: where the CDF ends at 1 -- give or take the rounding of a 62-term
+        # fp32 cumulative sum (<= 62 * 2^-24 = 3.7e-6).  In exact arithmetic that sample is the last bin's centre; with cdf[-1] = 1 + eps
+        # it is bins[-2] + (1 - eps / den) (bins[-1] - bins[-2]), den = the last bin's CDF increment (6e-5 when the bin is empty): the
+        # sample moves by eps / den of the distance to its neighbour -- and dists[-1] repeats dists[-2] (utils/nerf_util.py:36-37), so
+        # the opacities of the last TWO samples move by that fraction.  The slack a ray gets is what that does to its outputs: the fp64
+        # oracle's weight of those two samples x min(1, 3.7e-6 / den) -- zero on every ray that is empty at the far end.
+        den_last = cdf[:, -1] - cdf[:, -2]
+        slack = d["w_fine"][:, -2:].sum(-1) * np.minimum(1.0, 3.7e-6 / np.maximum(den_last, 1e-12))
+    return flagged, slack
+
+
 def _sampled_rays_vs_oracle(out, rays, sc, H, W, jitter, kw):
     """4096 pixels of a rendered H x W frame (`out` = RayMarcher.render's tuple, fine maps) against the oracle on the same inputs and the
     same random numbers (kw: t_rand [1,H*W,S_c], u_rand [H*W,S_f] as CPU tensors, or {}): 32 random columns in each of 128 image rows.
@@ -442,6 +476,7 @@ def _sampled_rays_vs_oracle(out, rays, sc, H, W, jitter, kw):
     nth = min(16, os.cpu_count() or 4)
     r = oracle.render_rays(sub, 64, 16, perturb=jitter, nthreads=nth, **okw)
     r64 = oracle.render_rays(sub, 64, 16, perturb=jitter, nthreads=nth, f64=True, **okw)
+    floor_rays, slack = _pdf_floor_sensitive(sub, jitter, okw, nth)
     nudged = []
     for direction in (np.float32(np.inf), np.float32(-np.inf)):              # ray origins one ulp up / down
         s2 = dict(sub)
@@ -455,8 +490,9 @@ def _sampled_rays_vs_oracle(out, rays, sc, H, W, jitter, kw):
         cond = np.abs(r32 - r64[k].reshape(n, -1)).max(-1)
         for q in nudged:
             cond = np.maximum(cond, np.abs(q[k].astype(np.float64).reshape(n, -1) - r32).max(-1))
-        viol = err > 1e-3 + 3.0 * cond
+        viol = (err > 1e-3 + 3.0 * cond + slack) & ~floor_rays                   # rays on sample_pdf's denominator floor: the loose bar below
         assert not viol.any(), (k, int(viol.sum()), "rays beyond their bar; worst:", err[viol][:4], "conditioning there:", cond[viol][:4])
+        assert (err[floor_rays] <= 1e-2).all() and floor_rays.mean() <= 0.02, (k, floor_rays.mean())
         assert np.median(err) <= 1e-4, (k, np.median(err))
 
 
@@ -496,8 +532,8 @@ def test_shipping_device_rng_kernels_vs_oracle_on_their_own_random_numbers(mlp):
     torch.cuda.synchronize()
     assert rm.last_variant == "hav_march_blk_kernel<2, %d, 2>" % prec
     for a_, b_ in zip(dev_out[3:7], inj_out[3:7]):                            # (b) its sibling on the same numbers
-        d = (a_ - b_).abs().reshape(H * W, -1).amax(1)
-        assert d.median().item() <= 2e-6 and (d > 1e-4).float().mean().item() <= 2e-3 and d.max().item() <= 5e-2, (d.median().item(), (d > 1e-4).float().mean().item(), d.max().item())
+        d = (a_ - b_).abs().reshape(H * W, -1).amax(1)          # (the stress recipe: 2 % of its rays move by > 1e-4 for an ulp in a coarse depth)
+        assert d.median().item() <= 1e-5 and (d > 1e-3).float().mean().item() <= 1e-2, (d.median().item(), (d > 1e-3).float().mean().item(), d.max().item())
 
 
 @pytest.mark.parametrize("mlp", ["split", "half"])
@@ -537,6 +573,69 @@ def test_full_frame_512_fine_maps_only_cache_kernels_vs_oracle(jitter, mlp):
     assert rm.last_variant == "hav_march_blk_kernel<%d, %d, 2>" % (2 if jitter else 0, {"split": 1, "half": 2}[mlp])
     assert out[0] is None and all(torch.isfinite(o).all() for o in out[3:7])
     _sampled_rays_vs_oracle(out, rays, sc, H, W, jitter, kw)
+
+
+@pytest.mark.parametrize("recipe", ["primary", "stress"])
+@pytest.mark.parametrize("jitter", [False, True])
+@pytest.mark.parametrize("mlp", ["split", "half"])
+def test_full_frame_512_production_kernels_vs_the_reference(mlp, jitter, recipe):
+    """BASELINE config 2 at its real size against the REFERENCE ITSELF (not the oracle): the whole 512 x 512 frame is rendered by the
+    production kernels (<0|2, 1|2, 2>: fine-pass cache, coarse maps declined; then once more with the coarse maps) and 2 064 of its rays --
+    16 random columns in every fourth image row and the last row, plus the frame's last ray -- are compared with what the reference's
+    predict_and_render_radiance gave for exactly those rays (tests/golden/frame512.npz, oracle/gen_golden_frame512.py; rays are
+    independent in the reference, so these are rows of its full-frame result).  With jitter, the reference's t_rand / u_rand for these rays
+    are injected at their positions of full-frame random tensors.  Per-ray bar = the path tolerance + 3 x that ray's conditioning as the REFERENCE shows it: its own
+    fp32-vs-fp64 deviation and the move of its fp32 result under a one-ulp shift of the ray origin (the stress recipe holds ill-conditioned
+    rays, SURVEY B-11); rays on sample_pdf's denominator floor (_pdf_floor_sensitive) are held to 10 x the tolerance instead."""
+    import torch
+    from havatar_amd import _lib
+    from havatar_amd.render import RayMarcher
+    g = np.load(os.path.join(GOLDEN, "frame512.npz"))
+    H, W, idx = int(g["H"]), int(g["W"]), g["idx"]
+    n = idx.size
+    sc = synth.scene(8, 8, recipe)
+    dev = torch.device("cuda:0")
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
+    rm = RayMarcher(sc["nerf_scale"], sc["nerf_trans"], sc["skin_scale"], sc["skin_trans"])
+    rm.mlp_mode = {"split": _lib.HAV_MLP_SPLIT_BF16, "half": _lib.HAV_MLP_SPLIT_F16}[mlp]
+    rm.flags |= _lib.HAV_FLAG_FINE_CACHE
+    rm.set_mlp(*[t(sc["mlp"][k]) for k in ("W1", "b1", "W2", "b2", "Wa", "ba", "Wf", "bf", "Wc", "bc")])
+    rm.set_triplane(t(sc["planes"]))
+    rays = t(synth.camera_rays(H, W))[None]
+    bg = torch.ones(1, H * W, 3, device=dev)
+    kw = {}
+    if jitter:
+        gen = torch.Generator(device="cpu").manual_seed(33)
+        t_rand, u_rand = torch.rand(1, H * W, 64, generator=gen), torch.rand(H * W, 16, generator=gen)
+        t_rand[0, idx] = torch.from_numpy(synth.uniform((1, n, 64), int(g["seed_t"])))[0]
+        u_rand[idx] = torch.from_numpy(synth.uniform((n, 16), int(g["seed_u"])))
+        kw = dict(t_rand=t_rand.to(dev), u_rand=u_rand.to(dev))
+    key = "%s_%s_" % (recipe, "jit" if jitter else "det")
+    prec = {"split": 1, "half": 2}[mlp]
+    sub = dict(sc)
+    sub["rays"], sub["bg"] = rays[:, idx].cpu().numpy(), np.ones((1, n, 3), np.float32)
+    okw = {"t_rand": synth.uniform((1, n, 64), int(g["seed_t"])), "u_rand": synth.uniform((n, 16), int(g["seed_u"]))} if jitter else {}
+    floor_rays, slack = _pdf_floor_sensitive(sub, jitter, okw)   # rays on sample_pdf's denominator floor / end-point slack (from the fp64 oracle alone)
+    assert floor_rays.mean() <= 0.02, floor_rays.mean()
+    for coarse_outputs in (False, True):
+        out = rm.render(rays, bg, t(sc["inv_T"]), t(sc["vol"]), 64, 16, perturb=jitter, coarse_outputs=coarse_outputs, **kw)
+        torch.cuda.synchronize()
+        want_cm = 2 if not coarse_outputs else (0 if prec == 2 else 1)
+        assert rm.last_variant == "hav_march_blk_kernel<%d, %d, %d>" % (2 if jitter else 0, prec, want_cm), rm.last_variant
+        got = {k: (None if o is None else o[0, idx].cpu().numpy().astype(np.float64).reshape(n, -1)) for k, o in zip(OUT_KEYS, out)}
+        for k in ("rgb_fine", "depth_fine", "acc_fine"):
+            err = np.abs(got[k] - g[key + k].astype(np.float64)).max(-1)
+            bar = TOL[k] + 3.0 * g[key + "cond_" + k].astype(np.float64) + slack * (6.0 if k == "depth_fine" else 1.0)     # (depths are ~6 at the far end)
+            bar[floor_rays] = 10.0 * TOL[k]
+            assert (err <= bar).all(), (k, coarse_outputs, int((err > bar).sum()), "rays beyond their bar; worst:", err[err > bar][:4], bar[err > bar][:4])
+            assert np.median(err) <= 0.05 * TOL[k], (k, np.median(err))
+        assert linf(got["weights_max"], g[key + "weights_max"]) <= TOL["weights_max"] + 3.0 * float(g[key + "cond_acc_fine"].max()) + float(slack.max())
+        if coarse_outputs:          # the coarse maps are well conditioned: the fixtures' tight bars
+            assert linf(got["rgb_coarse"][:, :3], g[key + "rgb_coarse"]) <= TOL["rgb_coarse"]
+            assert linf(got["depth_coarse"], g[key + "depth_coarse"]) <= TOL["depth_coarse"]
+            assert linf(got["acc_coarse"], g[key + "acc_coarse"]) <= TOL["acc_coarse"]
+        else:
+            assert out[0] is None and out[1] is None and out[2] is None
 
 
 def _homogeneous_rescale(mlp, s):
