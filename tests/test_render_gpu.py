@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, OUT_KEYS, hip_render, linf, load_render_fixture
+from helpers import GOLDEN, OUT_KEYS, hip_render, linf, load_render_fixture, pdf_floor_sensitive as _pdf_floor_sensitive
 from havatar_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -419,40 +419,6 @@ def test_production_variants_512_frame_24_launches(perturb, mlp):
         if rays_off:
             report.append((i + 1, len(rays_off), len({r // 32 for r in rays_off})))
     assert not report, (want, "launches that differ from the first (launch, rays, ray blocks):", report)
-
-
-def _pdf_floor_sensitive(sub, jitter, okw, nth=8):
-    """bool [n]: rays whose inverse-CDF resampling sits ON sample_pdf's one true discontinuity (or, with deterministic depths, on its end
-    point: below) -- `denom[denom < 1e-5] = 1`
-    (utils/nerf_util.py:112-113).  A bin of an empty stretch holds (0 + 1e-5) / sum(w + 1e-5) of the CDF: on a ray whose coarse opacity is
-    ~1 that increment IS 1e-5, and whether it compares below the floor is decided by the last bit of a cumulative sum -- the importance
-    sample then lands at the bin's start (denominator replaced by 1) or anywhere inside it.  No fp32 evaluation of the path is stable there,
-    the reference's included; which rays are affected follows from the fp64 oracle's coarse weights alone (independent of the kernel under
-    test): a ray is flagged when a denominator it uses lies within 1e-7 of the floor (fp32 CDF values near 1 carry 6e-8 of rounding)."""
-    from oracle import oracle
-    d = oracle.render_rays(sub, 64, 16, perturb=jitter, nthreads=nth, f64=True, debug=True, **okw)
-    w = d["w_coarse"][:, 1:-1] + 1e-5                                            # [n, 62]
-    cdf = np.concatenate([np.zeros((w.shape[0], 1)), np.cumsum(w / w.sum(-1, keepdims=True), -1)], -1)      # [n, 63]
-    ns = 16
-    if jitter:
-        u = np.arange(ns)[None, :] * (1.0 / ns) + okw["u_rand"].astype(np.float64) * (1.0 / ns - 1e-6)
-    else:
-        u = np.broadcast_to(np.linspace(0.0, 1.0, ns)[None, :], (w.shape[0], ns))
-    inds = (cdf[:, None, :] <= u[:, :, None]).sum(-1)                            # searchsorted(right=True)
-    below, above = np.maximum(inds - 1, 0), np.minimum(inds, cdf.shape[1] - 1)
-    den = np.take_along_axis(cdf, above, 1) - np.take_along_axis(cdf, below, 1)
-    flagged = (np.abs(den - 1e-5) <= 1e-7).any(-1)
-    slack = np.zeros(w.shape[0])
-    if not jitter:
-        # Deterministic sampling puts its last sample at u = 1 exactly: where the CDF ends at 1 -- give or take the rounding of a 62-term
-        # fp32 cumulative sum (<= 62 * 2^-24 = 3.7e-6).  In exact arithmetic that sample is the last bin's centre; with cdf[-1] = 1 + eps
-        # it is bins[-2] + (1 - eps / den) (bins[-1] - bins[-2]), den = the last bin's CDF increment (6e-5 when the bin is empty): the
-        # sample moves by eps / den of the distance to its neighbour -- and dists[-1] repeats dists[-2] (utils/nerf_util.py:36-37), so
-        # the opacities of the last TWO samples move by that fraction.  The slack a ray gets is what that does to its outputs: the fp64
-        # oracle's weight of those two samples x min(1, 3.7e-6 / den) -- zero on every ray that is empty at the far end.
-        den_last = cdf[:, -1] - cdf[:, -2]
-        slack = d["w_fine"][:, -2:].sum(-1) * np.minimum(1.0, 3.7e-6 / np.maximum(den_last, 1e-12))
-    return flagged, slack
 
 
 def _sampled_rays_vs_oracle(out, rays, sc, H, W, jitter, kw):
