@@ -87,21 +87,32 @@ class PowerSampler:
     """Socket power (W) and shader clock (GHz) while a loop runs: amdgpu's hwmon / sysfs files, read every few ms from a thread."""
 
     def __init__(self, index=0):
+        """index: the torch device index.  The sysfs node is found through the device's PCI address (a box shows every GPU of the node in
+        sysfs, also the ones this process cannot see); failing that, every amdgpu node is sampled and the busiest one is reported."""
         import glob
-        self.power_f = self.clk_f = self.cap_f = None
-        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
-        cards = [c for c in cards if os.path.exists(os.path.join(c, "pp_dpm_sclk"))]
-        if index < len(cards):
-            dev = cards[index]
+        self.nodes = []                       # [(power file, clock file, cap file)]
+        want = None
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(index)
+            want = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            pass
+        cand = []
+        for dev in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+            if not os.path.exists(os.path.join(dev, "pp_dpm_sclk")):
+                continue
+            bdf = os.path.basename(os.path.realpath(dev))
             for hw in glob.glob(os.path.join(dev, "hwmon", "hwmon*")):
-                for nm in ("power1_average", "power1_input"):
-                    if self.power_f is None and os.path.exists(os.path.join(hw, nm)):
-                        self.power_f = os.path.join(hw, nm)
-                if os.path.exists(os.path.join(hw, "freq1_input")):
-                    self.clk_f = os.path.join(hw, "freq1_input")
-                if os.path.exists(os.path.join(hw, "power1_cap")):
-                    self.cap_f = os.path.join(hw, "power1_cap")
-        self.samples, self._stop, self._th = [], False, None
+                pf = next((os.path.join(hw, nm) for nm in ("power1_average", "power1_input") if os.path.exists(os.path.join(hw, nm))), None)
+                cf = os.path.join(hw, "freq1_input") if os.path.exists(os.path.join(hw, "freq1_input")) else None
+                kf = os.path.join(hw, "power1_cap") if os.path.exists(os.path.join(hw, "power1_cap")) else None
+                if pf or cf:
+                    cand.append((bdf, pf, cf, kf))
+        exact = [c for c in cand if want and c[0].lower() == want.lower()]
+        self.matched = bool(exact)
+        self.nodes = [c[1:] for c in (exact or cand)]
+        self.samples, self._stop, self._th = [[] for _ in self.nodes], False, None
 
     @staticmethod
     def _read(f):
@@ -113,10 +124,11 @@ class PowerSampler:
     def __enter__(self):
         def run():
             while not self._stop:
-                pw = self._read(self.power_f) if self.power_f else None
-                ck = self._read(self.clk_f) if self.clk_f else None
-                if pw is not None or ck is not None:
-                    self.samples.append((pw, ck))
+                for i, (pf, cf, _) in enumerate(self.nodes):
+                    pw = self._read(pf) if pf else None
+                    ck = self._read(cf) if cf else None
+                    if pw is not None or ck is not None:
+                        self.samples[i].append((pw, ck))
                 time.sleep(0.004)
         self._th = threading.Thread(target=run, daemon=True)
         self._th.start()
@@ -127,16 +139,25 @@ class PowerSampler:
         self._th.join(timeout=1.0)
 
     def summary(self):
-        pw = [p * 1e-6 for p, _ in self.samples if p]
-        ck = [c * 1e-9 for _, c in self.samples if c]
-        if not pw and not ck:
+        best = None
+        for (pf, cf, kf), smp in zip(self.nodes, self.samples):
+            pw = [p * 1e-6 for p, _ in smp if p]
+            ck = [c * 1e-9 for _, c in smp if c]
+            if not pw and not ck:
+                continue
+            pw, ck = pw[len(pw) // 3:], ck[len(ck) // 3:]          # the first third of the window is the ramp
+            mean_pw = sum(pw) / len(pw) if pw else 0.0
+            if best is None or mean_pw > best[0]:
+                best = (mean_pw, pw, ck, kf, len(smp))
+        if best is None:
             return None
-        cap = self._read(self.cap_f) if self.cap_f else None
-        # the first third of the window is the ramp
-        pw, ck = pw[len(pw) // 3:], ck[len(ck) // 3:]
+        _, pw, ck, kf, n = best
+        cap = self._read(kf) if kf else None
         return {"socket_power_W": round(sum(pw) / len(pw), 1) if pw else None, "socket_power_max_W": round(max(pw), 1) if pw else None,
                 "power_cap_W": round(cap * 1e-6, 1) if cap else None, "sclk_GHz": round(sum(ck) / len(ck), 3) if ck else None,
-                "sclk_max_GHz": 2.4, "samples": len(self.samples), "source": "amdgpu hwmon (power1_average, freq1_input) during a sustained replay"}
+                "sclk_max_GHz": 2.4, "samples": n,
+                "source": "amdgpu hwmon (power1_average, freq1_input) during a sustained replay; node %s" % (
+                    "matched by PCI address" if self.matched else "= the busiest of the %d amdgpu nodes in sysfs" % len(self.nodes))}
 
 
 def live_pmc_traffic(mlp_env):
@@ -688,8 +709,9 @@ def main():
                                     if (args.workload == "cfg3" and gather is not None and gather.collective) else None),
                        "kernel": kname},
             "roofline": {"bound": "mfma",
-                         "limited_by": ("socket power cap: under this kernel's load the shader clock sits below its 2.4 GHz maximum (roofline.power; "
-                                        "DESIGN.md 3.13: cycle savings come back as lower clock)" if power_bound else busiest),
+                         "limited_by": ("package power (PPT): under this kernel's load the firmware holds the shader clock below its 2.4 GHz maximum "
+                                        "(roofline.power; profiles/r04_throttle_status.txt: PPT violation active, thermal limiters idle; DESIGN.md "
+                                        "3.13: cycle savings come back as lower clock)" if power_bound else busiest),
                          "busiest_unit": names.get(busiest), "unit_busy": busy, "ta": ta_roof, "power": power,
                          "achieved": rf["achieved"], "peak": rf["peak"], "unit": "TFLOP/s", "frac": rf["frac"],
                          "traffic": traffic["bytes"] if traffic else None, "traffic_detail": traffic,
