@@ -8,6 +8,7 @@
 //   model/op/fused_bias_act_kernel.cu:18-105, model/op/fused_bias_act.cpp:18-31
 //   model/op/upfirdn2d_kernel.cu:49-369,      model/op/upfirdn2d.cpp:17-31
 #include "hav_common.h"
+#include <atomic>
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
@@ -1359,11 +1360,15 @@ static int torgb_launch(float* out, const float* x, const float* W, const float*
     constexpr int CP = (COUT + 3) & ~3, QB = 256 / KS;
     const size_t lds = ((size_t)Cin * CP + (size_t)(KS - 1) * COUT * QB * 4) * sizeof(float);
     if (lds > 160 * 1024) return HAV_EUNSUP;
-    static bool attr_done = false;                           // (a race here only repeats an idempotent call)
-    if (!attr_done) {
+    // the dynamic-LDS attribute is per device: one bit per device id (a second GPU driven from the same process needs its own call;
+    // a race here only repeats an idempotent call)
+    static std::atomic<unsigned long long> attr_mask{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
+    if (!((attr_mask.load(std::memory_order_acquire) >> dev) & 1ull)) {
         hipError_t e = hipFuncSetAttribute((const void*)torgb_kernel<COUT, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
+        attr_mask.fetch_or(1ull << dev, std::memory_order_release);
     }
     const dim3 grid((unsigned)(((HW >> 2) + QB - 1) / QB), (unsigned)B);
     hipLaunchKernelGGL((torgb_kernel<COUT, KS>), grid, dim3(256), lds, st, out, x, W, s, bias, skip, scale, Cin, HW);
