@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernel-only A/B of march-kernel builds on ONE box: python tools/ab_march.py libA.so libB.so ...  ('' = the in-tree library).
-Each library is loaded in a fresh subprocess; prints median kernel ms over N launches for perturb on/off."""
+Each library is loaded in a fresh subprocess; prints median kernel ms over N launches for perturb on/off and a digest of the deterministic outputs."""
 import os
 import subprocess
 import sys
@@ -28,6 +28,13 @@ for perturb in (True, False):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(); rm.render(*args, perturb=perturb, coarse_outputs=False); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
     out.append("%s %.3f ms (min %.3f)" % ("perturb" if perturb else "det    ", float(np.median(ts)), min(ts)))
+import hashlib
+o = rm.render(*args, perturb=False, coarse_outputs=False)          # digest of the deterministic outputs: equal digests = bit-identical builds
+o = o if isinstance(o, dict) else dict(enumerate(o))
+hsh = hashlib.sha1()
+for k in sorted(o, key=str):
+    if torch.is_tensor(o[k]): hsh.update(o[k].detach().cpu().numpy().tobytes())
+out.append("det sha1 " + hsh.hexdigest()[:12])
 print(" | ".join(out))
 '''
 for rnd in range(2):
