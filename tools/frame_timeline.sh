@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/timeline
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --output-format csv -d $OUT/kt -o kt -- python bench.py --steps 4 --warmup 4 --graph ${GRAPH:-0} --no-cpu-baseline > $OUT/bench.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/kt -o kt -- python bench.py --steps 4 --warmup 4 --graph ${GRAPH:-0} --no-cpu-baseline --extras 0 --live-pmc 0 > $OUT/bench.log 2>&1
 python - <<'PY' > $OUT/frame_timeline.txt
 import csv, glob, collections
 f = glob.glob("gpurun_out/timeline/kt/**/*kernel_trace.csv", recursive=True)[0]
