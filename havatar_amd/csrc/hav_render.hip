@@ -2416,8 +2416,11 @@ static bool fine_cache_applies(const HavRenderParams* p)
 {
     if (p->S_f <= 0 || p->S_c < 2 || !use_block_kernel(p) || mlp_prec(p) == 0) return false;
     if (p->flags & HAV_FLAG_FINE_RECOMPUTE) return false;
-    if (p->flags & HAV_FLAG_FINE_CACHE) return true;
-    return p->perturb || mlp_prec(p) == 2;
+    // With a workspace the cache is the default in both split modes, with and without jitter.  (Round 1 had it off for deterministic
+    // depths in the bf16 mode, where it was neutral at the time; on the present kernels it is worth 7 % with all seven maps and 14 %
+    // with the fine maps only -- 9.0 -> 7.75 ms at 512 x 512, profiles/r04_ab_cache_det.txt.)  HAV_FLAG_FINE_CACHE is kept for callers
+    // that set it; HAV_FLAG_FINE_RECOMPUTE is the way to get every merged sample evaluated.
+    return true;
 }
 static bool use_fine_cache(const HavRenderParams* p)
 {

@@ -321,8 +321,9 @@ typedef struct HavRenderParams {
     void*    workspace;    /* optional DEVICE scratch, hav_render_workspace_bytes() bytes: the fine pass then re-uses the
                             * radiance-field values of the even coarse samples that the merged list repeats
                             * (model/nerf_trainer.py:170) instead of evaluating them again: 80 evaluations per ray, not 112.
-                            * NULL / too small: every merged sample is evaluated, like the reference does.  In the fp16
-                            * mode the workspace is used by calls that decline the coarse outputs (HavRenderOut) only.    */
+                            * NULL / too small: every merged sample is evaluated, like the reference does (so does
+                            * HAV_FLAG_FINE_RECOMPUTE).  Used by both split modes, with and without jitter; in the fp16
+                            * mode by calls that decline the coarse outputs (HavRenderOut) only.                          */
     uint64_t workspace_bytes;
     float*   dbg_zfine;    /* optional DEVICE [B*R, S_fp] (tests): the call also dumps the merged, sorted fine depths here  */
     uint32_t* status;      /* optional DEVICE word; the call ORs HAV_STATUS_* bits into it on the stream (the caller zeroes it) */
@@ -330,7 +331,7 @@ typedef struct HavRenderParams {
 
 /* HavRenderParams.flags */
 #define HAV_FLAG_PAIR_KERNEL     1   /* force the ray-pair kernel (otherwise only used when num_coarse > 67); A/B runs and tests */
-#define HAV_FLAG_FINE_CACHE      2   /* force the fine-pass cache on where a workspace is offered (default: see workspace above)   */
+#define HAV_FLAG_FINE_CACHE      2   /* the fine-pass cache where a workspace is offered: now the default, kept for callers that set it */
 #define HAV_FLAG_FINE_RECOMPUTE  4   /* never use the fine-pass cache                                                               */
 #define HAV_FLAG_NO_FP16_GUARD   8   /* HAV_MLP_SPLIT_F16 only: skip the range guard below (the caller vouches for the range)       */
 #define HAV_FLAGS_ALL           15

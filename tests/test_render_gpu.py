@@ -25,12 +25,12 @@ FINE_KEYS = ("weights_max", "rgb_fine", "depth_fine", "acc_fine")
 
 def expected_variant(cfg, kw, mlp, coarse_outputs, cache=None):
     """The instantiation hav_render_rays must pick (include/havatar.h + pick_variant in hav_render.hip), spelled out independently:
-    <RNG mode, arithmetic, cache mode>.  cache=None: the library default (fp16: always, bf16: iff jitter, f32: never)."""
+    <RNG mode, arithmetic, cache mode>.  cache=None: the library default (fp16, bf16: whenever a workspace is offered; f32: never)."""
     random = cfg["perturb"] or cfg["noise_std"] > 0
     prec = PREC[mlp]
     rm = 0 if not random else (2 if (kw or prec == 0) else 1)
     if cache is None:
-        cache = prec == 2 or (prec == 1 and cfg["perturb"])
+        cache = prec in (1, 2)
     cache = cache and prec != 0 and cfg["S_f"] > 0
     cm = 0 if not cache else (2 if not coarse_outputs else (0 if prec == 2 else 1))
     return "hav_march_blk_kernel<%d, %d, %d>" % (rm, prec, cm)
@@ -50,7 +50,7 @@ def test_hip_vs_reference_golden(name, mlp, coarse_outputs):
     assert o["variant"] == expected_variant(cfg, kw, mlp, coarse_outputs), o["variant"]
     assert not o["fp16_fallback"], "the fixtures are far inside the fp16 range: the guard must not trip"
     declined = o["variant"].endswith(", 2>")          # (without a cache kernel the library hands the coarse maps out anyway)
-    assert declined == (not coarse_outputs and (mlp == "half" or (mlp == "split" and cfg["perturb"])))
+    assert declined == (not coarse_outputs and mlp in ("half", "split"))
     for k in OUT_KEYS:
         if declined and k not in FINE_KEYS:
             assert o[k] is None, k
@@ -325,14 +325,15 @@ def test_fine_pass_cache_is_the_default_with_jitter_and_needs_a_workspace(monkey
     rm.mlp_mode = _lib.HAV_MLP_SPLIT_F16
     # fp16 mode (HAVATAR_MLP=half): the cache serves the fine-maps-only calls (with or without jitter); a call that also wants the coarse
     # maps evaluates every merged sample (the fp16 kernels that would do both are not dispatched).
-    # bf16 mode: cache iff jitter
+    # bf16 mode: the cache serves every call with a fine pass, with the coarse maps (<., 1, 1>) or without (<., 1, 2>)
     assert rm.variant(64, 16, perturb=True).endswith("2, 0>") and rm.variant(64, 16, perturb=False).endswith("2, 0>")
     assert rm.variant(64, 16, perturb=True, coarse_outputs=False).endswith("<1, 2, 2>")      # production: jitter, cache, fine maps only
     assert rm.variant(64, 16, perturb=False, coarse_outputs=False).endswith("<0, 2, 2>")
     assert rm.variant(64, 16, perturb=True, coarse_outputs=False, injected=True).endswith("<2, 2, 2>")   # injected jitter reaches the cache path
     rm.mlp_mode = _lib.HAV_MLP_SPLIT_BF16
     assert rm.variant(64, 16, perturb=True, coarse_outputs=False, injected=True).endswith("<2, 1, 2>")
-    assert rm.variant(64, 16, perturb=True).endswith("1, 1>") and rm.variant(64, 16, perturb=False).endswith("1, 0>")
+    assert rm.variant(64, 16, perturb=True).endswith("<1, 1, 1>") and rm.variant(64, 16, perturb=False).endswith("<0, 1, 1>")
+    assert rm.variant(64, 16, perturb=False, coarse_outputs=False).endswith("<0, 1, 2>")
     rm.mlp_mode = _lib.HAV_MLP_SPLIT_F16
     rm.fine_cache = False                                          # no workspace offered -> every merged sample is evaluated
     assert rm.variant(64, 16, perturb=True).endswith(", 0>")
@@ -386,7 +387,6 @@ def test_production_variants_512_frame_24_launches(perturb, mlp):
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
     rm = RayMarcher(sc["nerf_scale"], sc["nerf_trans"], sc["skin_scale"], sc["skin_trans"])
     rm.mlp_mode = {"split": _lib.HAV_MLP_SPLIT_BF16, "half": _lib.HAV_MLP_SPLIT_F16}[mlp]
-    rm.flags |= _lib.HAV_FLAG_FINE_CACHE                     # (bf16 mode caches only with jitter by default; the production call has jitter)
     rm.set_mlp(*[t(sc["mlp"][k]) for k in ("W1", "b1", "W2", "b2", "Wa", "ba", "Wf", "bf", "Wc", "bc")])
     rm.set_triplane(t(sc["planes"]))
     rays = t(synth.camera_rays(H, W))[None]

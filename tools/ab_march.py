@@ -20,16 +20,17 @@ m = sc["mlp"]
 rm.set_mlp(*[t(m[k]) for k in ("W1", "b1", "W2", "b2", "Wa", "ba", "Wf", "bf", "Wc", "bc")])
 rm.set_triplane(t(sc["planes"]))
 args = (t(sc["rays"]), t(sc["bg"]), t(sc["inv_T"]), t(sc["vol"]), 64, 16)
+CO = os.environ.get('COARSE', '0') == '1'          # COARSE=1: all seven maps (the <., ., 0|1> kernels)
 out = []
 for perturb in (True, False):
-    for _ in range(3): rm.render(*args, perturb=perturb, coarse_outputs=False)
+    for _ in range(3): rm.render(*args, perturb=perturb, coarse_outputs=CO)
     ts = []
     for _ in range(12):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); rm.render(*args, perturb=perturb, coarse_outputs=False); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
+        a.record(); rm.render(*args, perturb=perturb, coarse_outputs=CO); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
     out.append("%s %.3f ms (min %.3f)" % ("perturb" if perturb else "det    ", float(np.median(ts)), min(ts)))
 import hashlib
-o = rm.render(*args, perturb=False, coarse_outputs=False)          # digest of the deterministic outputs: equal digests = bit-identical builds
+o = rm.render(*args, perturb=False, coarse_outputs=CO)          # digest of the deterministic outputs: equal digests = bit-identical builds
 o = o if isinstance(o, dict) else dict(enumerate(o))
 hsh = hashlib.sha1()
 for k in sorted(o, key=str):
