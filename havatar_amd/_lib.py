@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libhavatar_hip.so")
 
 HAV_F32, HAV_F16, HAV_BF16, HAV_F64 = 0, 1, 2, 3
 HAV_MLP_SPLIT_BF16, HAV_MLP_F32, HAV_MLP_SPLIT_F16 = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 HAV_FLAG_PAIR_KERNEL, HAV_FLAG_FINE_CACHE, HAV_FLAG_FINE_RECOMPUTE, HAV_FLAG_NO_FP16_GUARD = 1, 2, 4, 8
 HAV_STATUS_FP16_FALLBACK = 1
 
@@ -128,7 +128,9 @@ def lib():
     L.hav_conv3x3_scratch_bytes.argtypes = [i32] * 5
     L.hav_conv3x3_scratch_bytes.restype = i64
     L.hav_conv3x3_split.argtypes = [vp] * 8 + [f32, f32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]
-    L.hav_conv3x3s2_split.argtypes = [vp] * 8 + [f32, f32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]
+    L.hav_conv3x3s2_split.argtypes = [vp] * 8 + [f32, f32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]
+    L.hav_conv3x3s2_scratch_bytes.argtypes = [i32] * 6
+    L.hav_conv3x3s2_scratch_bytes.restype = C.c_int64
     L.hav_conv3x3s2_split.restype = i32
     L.hav_conv3x3_pack_t.argtypes = [vp, vp, i32, i32, f32, vp]
     L.hav_conv3x3_pack_t.restype = i32

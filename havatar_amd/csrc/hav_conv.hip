@@ -30,6 +30,7 @@
 // to the other LDS buffer after them: one barrier per chunk.
 #include "hav_common.h"
 #include <atomic>
+#include <type_traits>
 
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
@@ -598,18 +599,27 @@ extern "C" int hav_conv3x3_split(float* y, const float* x, const void* packed, c
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // Stride-2 3x3 convolution (the down-sampling ConvLayer / ConvBlock of the encoders: Blur -> EqualConv2d(stride 2, padding 0) ->
-// FusedLeakyReLU, model/styleUnet.py:326-368; MIOpen ran it as Im2d2Col + an fp32 GEMM) on the same split-fp16 path and the same packed
-// weights as the stride-1 kernel.  Workgroup = 64 (Cout) x [4 rows x 32 columns] of OUTPUT, so the chunk's input patch is 9 x 65
-// pixels; it is staged with even and odd columns apart ([row][column parity][column / 2]): tap (ky, kx) of output column j reads patch
-// column 2 j + kx = entry j + (kx >> 1) of parity kx & 1, i.e. consecutive lanes read consecutive 80-byte records as in the stride-1
-// kernel (records two apart would put 16 lanes on 8 bank groups).  Same MFMA work per output as stride 1, three times the staging.
+// FusedLeakyReLU, model/styleUnet.py:326-368; MIOpen runs it as Im2d2Col + an fp32 GEMM + the activation launch) on the same split-fp16
+// path and the same packed weights as the stride-1 kernel.  Workgroup = 64 (Cout) x [4 rows x 32 columns] of OUTPUT, so the chunk's
+// input patch is 9 x 65 pixels; it is staged with even and odd columns apart ([row][column parity][column / 2]): tap (ky, kx) of output
+// column j reads patch column 2 j + kx = entry j + (kx >> 1) of parity kx & 1, i.e. consecutive lanes read consecutive 80-byte records
+// as in the stride-1 kernel (records two apart would put 16 lanes on 8 bank groups).  A stride-2 patch feeds 2.25 taps per staged pixel
+// where a stride-1 patch feeds 9, so the staging is what has to be hidden.  Second version (round 4): 512 threads.  The 18 (tap, output
+// row) pairs of a wave's former work are dealt to TWO waves (9 each: 27 MFMAs per chunk and wave), which halves the staging tasks and the
+// weight-fragment loads per thread and puts two waves on every SIMD -- one stages / waits on LDS while the other one's MFMAs run
+// (the first version had one wave per SIMD: its loads, conversions, LDS round trips and MFMAs simply added up: 96.7 us on the 256 -> 512
+// layer at 129^2 -> 64^2).  The two halves of a sum meet in LDS after the last chunk; the weight fragments of chunk c + 1 and the
+// B operands of pair p + 1 are requested before the MFMAs of chunk c / pair p.  Maps with too few tiles for 256 CUs split the channel range
+// over 2-8 workgroups per tile; conv3x3_finish_kernel adds the slices in slice order and applies the epilogue.
 #define S2_PR (2 * CV_ROWS + 1)            // 9 patch rows
 #define S2_HC (CV_COLS + 1)                // 33 entries per (row, parity)
 #define S2_RECS (S2_PR * 2 * S2_HC)        // 594 records (9 of them -- odd column 65 -- never read)
 #define S2_TASKS (S2_RECS * 8)
-#define S2_TPT ((S2_TASKS + 255) / 256)    // 19
+#define S2_THREADS 512
+#define S2_TPT ((S2_TASKS + S2_THREADS - 1) / S2_THREADS)    // 10
 struct ConvS2Args {
     float* y; const float* x; const uint4* blob;
+    float* partial; int ksplit;          // K-split: [ksplit][B,Cout,Hout,Wout] raw sums, reduced by conv3x3_finish_kernel
     const unsigned int* in_amax;
     const float* s; const float* d; const float* noise; const float* noise_weight; const float* bias;
     float slope, gain;
@@ -618,17 +628,19 @@ struct ConvS2Args {
 };
 
 template <bool HAS_S>
-__global__ void __launch_bounds__(256, 1) conv3x3s2_split_kernel(ConvS2Args a)
+__global__ void __launch_bounds__(S2_THREADS, 1) conv3x3s2_split_kernel(ConvS2Args a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s2_lds[];          // [2][S2_RECS * CV_REC]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
-    const int wm = wave & 1, wn = wave >> 1;
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = (wave >> 1) & 1, kh = wave >> 2;
     const int bw = a.Wout / CV_COLS;
     const int px = blockIdx.x % bw, py = blockIdx.x / bw;
     const int x0 = px * CV_COLS, y0 = py * CV_ROWS;          // output tile origin
     const int mt = blockIdx.y * 2 + wm;
-    const int b = blockIdx.z;
-    const int Hin = a.Hin, Win = a.Win, Cin = a.Cin, NC = Cin / 16, MT = a.Cout / 32;
+    const int b = blockIdx.z / a.ksplit, ks = blockIdx.z - b * a.ksplit;
+    const int Hin = a.Hin, Win = a.Win, Cin = a.Cin, NCT = Cin / 16, MT = a.Cout / 32;
+    const int c_lo = (NCT * ks) / a.ksplit, c_hi = (NCT * (ks + 1)) / a.ksplit;
     const int64_t HWin = (int64_t)Hin * Win;
     const float* xb = a.x + (int64_t)b * Cin * HWin;
     const float* sb = HAS_S ? a.s + (int64_t)b * Cin : nullptr;
@@ -643,7 +655,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3s2_split_kernel(ConvS2Args a)
     bool t_ok[S2_TPT];
 #pragma unroll
     for (int q = 0; q < S2_TPT; ++q) {
-        const int task = tid + 256 * q;
+        const int task = tid + S2_THREADS * q;
         const int cp = task / S2_RECS, rec = task - cp * S2_RECS;
         const int prow = rec / (2 * S2_HC), rem = rec - prow * (2 * S2_HC);
         const int par = rem / S2_HC, half = rem - par * S2_HC;
@@ -669,7 +681,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3s2_split_kernel(ConvS2Args a)
             if (t_lds[q] < 0) continue;
             float m0 = in_sc, m1 = in_sc;
             if (HAS_S) {          // the chunk's 16 modulation factors: L1 hits, issued behind the matrix work
-                const int cp = (tid + 256 * q) / S2_RECS;
+                const int cp = (tid + S2_THREADS * q) / S2_RECS;
                 m0 *= sb[16 * cc + 2 * cp]; m1 *= sb[16 * cc + 2 * cp + 1];
             }
             const fl2_t f = {v[q][0] * m0, v[q][1] * m1};
@@ -682,38 +694,93 @@ __global__ void __launch_bounds__(256, 1) conv3x3s2_split_kernel(ConvS2Args a)
     f32x16 acc[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
-
-    fetch(0, sv);
-    stash(0, 0, sv);
-    __syncthreads();
-    for (int cc = 0; cc < NC; ++cc) {
-        const int buf = cc & 1;
-        const uint4* ab = a.blob + ((int64_t)(cc * 9) * MT + mt) * 128 + lane;
-        uint4 A[9][2];
+    // this wave's nine (tap, row) pairs: pair p = 9 kh + i  ->  tap p >> 1, row p & 1; its five taps are 4 kh .. 4 kh + 4.  kh is a
+    // template value inside `run` (register arrays want compile-time indices), and the chunk loop is unrolled by two so that the
+    // two fragment sets swap roles by name.
+    auto run = [&](auto KH) {
+        constexpr int khc = decltype(KH)::value;
+        uint4 A0[5][2], A1[5][2];
+        auto load_a = [&](int cc, uint4 (&F)[5][2]) {
+            const uint4* ab = a.blob + ((int64_t)(cc * 9 + 4 * khc) * MT + mt) * 128 + lane;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) { A[t][0] = ab[(int64_t)t * MT * 128]; A[t][1] = ab[(int64_t)t * MT * 128 + 64]; }
-        if (cc + 1 < NC) fetch(cc + 1, sv);
-        const uint32_t* L = s2_lds + buf * (S2_RECS * CV_REC);
+            for (int t = 0; t < 5; ++t) { F[t][0] = ab[(int64_t)t * MT * 128]; F[t][1] = ab[(int64_t)t * MT * 128 + 64]; }
+        };
+        int rec_off[9];          // LDS offset (in uint32) of pair i's B operand, lane part included
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int ky = t / 3, kx = t - 3 * ky;
-            const f16x8_t ah = __builtin_bit_cast(f16x8_t, A[t][0]), al = __builtin_bit_cast(f16x8_t, A[t][1]);
+        for (int i = 0; i < 9; ++i) {
+            const int p = 9 * khc + i, t = p >> 1, rr = p & 1, ky = t / 3, kx = t - 3 * ky;
+            rec_off[i] = (((2 * (2 * wn + rr) + ky) * 2 + (kx & 1)) * S2_HC + j + (kx >> 1)) * CV_REC + 4 * h;
+        }
+        // input prefetch runs TWO chunks ahead (the maps come from L2 / HBM: one chunk of 27 MFMAs per wave is shorter than that
+        // round trip), the weight fragments (L2-resident, shared by every workgroup) one chunk ahead
+        auto step = [&](int cc, int buf, const uint4 (&F)[5][2], uint4 (&Fn)[5][2], float (&Sc)[S2_TPT][2], float (&So)[S2_TPT][2]) {
+            if (cc + 2 < c_hi) fetch(cc + 2, So);
+            if (cc + 1 < c_hi) load_a(cc + 1, Fn);
+            const uint32_t* L = s2_lds + buf * (S2_RECS * CV_REC);
+            uint4 bh[2], bl[2];
+            bh[0] = *reinterpret_cast<const uint4*>(L + rec_off[0]);
+            bl[0] = *reinterpret_cast<const uint4*>(L + rec_off[0] + 8);
 #pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                const int rec = ((2 * (2 * wn + rr) + ky) * 2 + (kx & 1)) * S2_HC + j + (kx >> 1);
-                const uint4 bh = *reinterpret_cast<const uint4*>(L + rec * CV_REC + 4 * h);
-                const uint4 bl = *reinterpret_cast<const uint4*>(L + rec * CV_REC + 8 + 4 * h);
-                const f16x8_t xh = __builtin_bit_cast(f16x8_t, bh), xl = __builtin_bit_cast(f16x8_t, bl);
+            for (int i = 0; i < 9; ++i) {
+                if (i + 1 < 9) {
+                    bh[(i + 1) & 1] = *reinterpret_cast<const uint4*>(L + rec_off[i + 1]);
+                    bl[(i + 1) & 1] = *reinterpret_cast<const uint4*>(L + rec_off[i + 1] + 8);
+                }
+                const int tl = ((9 * khc + i) >> 1) - 4 * khc, rr = (9 * khc + i) & 1;          // compile-time after unrolling
+                const f16x8_t ah = __builtin_bit_cast(f16x8_t, F[tl][0]), al = __builtin_bit_cast(f16x8_t, F[tl][1]);
+                const f16x8_t xh = __builtin_bit_cast(f16x8_t, bh[i & 1]), xl = __builtin_bit_cast(f16x8_t, bl[i & 1]);
+#ifdef S2_ABL_NOMFMA
+                acc[rr][0] += (xh[0] + xl[1]) + (ah[0] + al[0]);
+#else
                 acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh, acc[rr], 0, 0, 0);
                 acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl, acc[rr], 0, 0, 0);
                 acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh, acc[rr], 0, 0, 0);
+#endif
             }
-        }
-        asm volatile(CV_MFMA_PAD : "+v"(acc[0]), "+v"(acc[1]));
-        if (cc + 1 < NC) stash(buf ^ 1, cc + 1, sv);
+#ifndef S2_ABL_NOSTASH
+            if (cc + 1 < c_hi) stash(buf ^ 1, cc + 1, Sc);
+#endif
+            __syncthreads();
+        };
+        float sv2[S2_TPT][2];
+        fetch(c_lo, sv);
+        load_a(c_lo, A0);
+        stash(0, c_lo, sv);
+        if (c_lo + 1 < c_hi) fetch(c_lo + 1, sv);
         __syncthreads();
+        for (int cc = c_lo; cc < c_hi; cc += 2) {
+            step(cc, 0, A0, A1, sv, sv2);
+            if (cc + 1 < c_hi) step(cc + 1, 1, A1, A0, sv2, sv);
+        }
+    };
+    if (kh) run(std::integral_constant<int, 1>{}); else run(std::integral_constant<int, 0>{});
+    // the two tap halves of a tile meet in LDS (the staging buffers are free after the loop's last barrier)
+    float* red = reinterpret_cast<float*>(s2_lds);
+    if (kh) {
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(((wave & 3) * 2 + rr) * 16 + r) * 64 + lane] = acc[rr][r];
     }
+    __syncthreads();
+    if (kh) return;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rr][r] += red[((wave * 2 + rr) * 16 + r) * 64 + lane];
+
     const int Ho = a.Hout, Wo = a.Wout;
+    if (a.partial) {            // K-split: raw sums out, the epilogue runs in conv3x3_finish_kernel after the slices are added up
+        float* pp = a.partial + (int64_t)ks * a.B * a.Cout * Ho * Wo;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
+                pp[(((int64_t)b * a.Cout + co) * Ho + y0 + 2 * wn + rr) * Wo + x0 + j] = acc[rr][r] * out_sc;
+            }
+        return;
+    }
     const float nw = (a.noise && a.noise_weight) ? *a.noise_weight : 0.f;
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
@@ -732,9 +799,25 @@ __global__ void __launch_bounds__(256, 1) conv3x3s2_split_kernel(ConvS2Args a)
     }
 }
 
+static int conv_s2_ksplit(int B, int Cin, int Cout, int Hout, int Wout)
+{
+    const int64_t tiles = (int64_t)B * (Cout / 64) * (Hout / CV_ROWS) * (Wout / CV_COLS);
+    int ks = 1;
+    while (tiles * ks < hav_num_cus() && ks < 8 && (Cin / 16) / (ks * 2) >= 2) ks *= 2;
+    return ks;
+}
+extern "C" int64_t hav_conv3x3s2_scratch_bytes(int B, int Cin, int Cout, int Hin, int Win, int pad)
+{
+    if (B < 1 || Cin < 16 || Cout < 64 || Hin < 3 || Win < 3 || pad < 0 || pad > 1 || (Cin % 16) || (Cout % 64)) return 0;
+    const int Hout = (Hin + 2 * pad - 3) / 2 + 1, Wout = (Win + 2 * pad - 3) / 2 + 1;
+    if ((Hout % CV_ROWS) || (Wout % CV_COLS)) return 0;
+    const int ks = conv_s2_ksplit(B, Cin, Cout, Hout, Wout);
+    return ks > 1 ? (int64_t)ks * B * Cout * Hout * Wout * 4 : 0;
+}
+
 extern "C" int hav_conv3x3s2_split(float* y, const float* x, const void* packed, const float* s, const float* d, const float* noise,
                                    const float* noise_weight, const float* bias, float slope, float gain, int act, int noise_batched, int B,
-                                   int Cin, int Cout, int Hin, int Win, int pad, const void* in_amax, void* stream)
+                                   int Cin, int Cout, int Hin, int Win, int pad, void* scratch, const void* in_amax, void* stream)
 {
     if (!y || !x || !packed || B < 1 || Cin < 16 || Cout < 64 || Hin < 3 || Win < 3 || pad < 0 || pad > 1) return HAV_EINVAL;
     const int Hout = (Hin + 2 * pad - 3) / 2 + 1, Wout = (Win + 2 * pad - 3) / 2 + 1;
@@ -742,6 +825,8 @@ extern "C" int hav_conv3x3s2_split(float* y, const float* x, const void* packed,
     if ((int64_t)Cin * Hin * Win > 0x7fffffffLL) return HAV_EUNSUP;          // 32-bit element offsets inside one sample
     ConvS2Args a;
     a.y = y; a.x = x; a.blob = (const uint4*)packed; a.in_amax = (const unsigned int*)in_amax;
+    a.ksplit = scratch ? conv_s2_ksplit(B, Cin, Cout, Hout, Wout) : 1;
+    a.partial = a.ksplit > 1 ? (float*)scratch : nullptr;
     a.s = s; a.d = d; a.noise = noise; a.noise_weight = noise_weight; a.bias = bias;
     a.slope = slope; a.gain = gain; a.act = act; a.noise_batched = noise_batched;
     a.B = B; a.Cin = Cin; a.Cout = Cout; a.Hin = Hin; a.Win = Win; a.Hout = Hout; a.Wout = Wout; a.pad = pad;
@@ -755,10 +840,22 @@ extern "C" int hav_conv3x3s2_split(float* y, const float* x, const void* packed,
         if (e1 != hipSuccess || e2 != hipSuccess) return (int)(e1 != hipSuccess ? e1 : e2);
         attr_mask.fetch_or(1ull << dev, std::memory_order_release);
     }
-    const dim3 grid((unsigned)((Wout / CV_COLS) * (Hout / CV_ROWS)), (unsigned)(Cout / 64), (unsigned)B);
-    if (s) hipLaunchKernelGGL(conv3x3s2_split_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(conv3x3s2_split_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, a);
+    const dim3 grid((unsigned)((Wout / CV_COLS) * (Hout / CV_ROWS)), (unsigned)(Cout / 64), (unsigned)(B * a.ksplit));
+    if (s) hipLaunchKernelGGL(conv3x3s2_split_kernel<true>, grid, dim3(S2_THREADS), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(conv3x3s2_split_kernel<false>, grid, dim3(S2_THREADS), lds, (hipStream_t)stream, a);
     HAV_LAUNCH_CHECK();
+    if (a.partial) {
+        ConvArgs f;
+        f.y = y; f.x = nullptr; f.blob = nullptr; f.partial = a.partial; f.ksplit = a.ksplit; f.in_amax = nullptr;
+        f.s = nullptr; f.d = d; f.noise = noise; f.noise_weight = noise_weight; f.bias = bias;
+        f.slope = slope; f.gain = gain; f.act = act; f.noise_batched = noise_batched;
+        f.B = B; f.Cin = Cin; f.Cout = Cout; f.H = Hout; f.W = Wout;
+        const int64_t total = (int64_t)B * Cout * Hout * Wout;
+        int64_t blocks = (total + 255) / 256;
+        if (blocks > (int64_t)hav_num_cus() * 16) blocks = (int64_t)hav_num_cus() * 16;
+        hipLaunchKernelGGL(conv3x3_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, f, total);
+        HAV_LAUNCH_CHECK();
+    }
     return 0;
 }
 

@@ -267,11 +267,11 @@ class ConvLayer(nn.Sequential):
     def forward(self, input):
         ec = self[0]
         if (len(self) > 1 and isinstance(self[0], Blur) and isinstance(self[1], EqualConv2d) and input.is_cuda and input.dtype == torch.float32
-                and not torch.is_grad_enabled() and _fused_conv_enabled() and os.environ.get("HAVATAR_CONV_S2", "0") == "1"):
-            # HIP inference, down-sampling layer (opt-in): Blur (hav_upfirdn2d) -> EqualConv2d stride 2 + bias + leaky-ReLU as one kernel
-            # (hav_conv3x3s2_split) instead of MIOpen's Im2d2Col + fp32 GEMM + the activation launch.  Measured in the frame graph
-            # (profiles/r03_v2_frame_timeline_stride2.txt): 96.7 us per layer against ~80 us for the three launches it replaces -- the
-            # 9 x 65 patch costs three times the staging of the stride-1 kernel per MFMA -- so MIOpen stays the default
+                and not torch.is_grad_enabled() and _fused_conv_enabled() and os.environ.get("HAVATAR_CONV_S2", "1") != "0"):
+            # HIP inference, down-sampling layer: Blur (hav_upfirdn2d) -> EqualConv2d stride 2 + bias + leaky-ReLU as one kernel
+            # (hav_conv3x3s2_split) instead of MIOpen's Im2d2Col + fp32 GEMM + the activation launch: 78.6 against 110.8 us on the
+            # encoders' 256 -> 512 layer, 49.5 against 69.1 us on the 512 -> 512 one, blur included (tools/bench_s2.py,
+            # profiles/r04_bench_s2.txt; the first version of the kernel was slower than MIOpen and opt-in).  HAVATAR_CONV_S2=0: MIOpen
             ec = self[1]
             xb = self[0](input)
             if xb.shape[-1] * xb.shape[-2] >= 1024 and _conv.s2_eligible(xb, ec.weight, ec.stride, ec.padding):

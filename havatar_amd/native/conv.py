@@ -135,8 +135,10 @@ def conv3x3s2(x, packed, Cout, padding=0, s=None, d=None, noise=None, noise_weig
     with torch.cuda.device(x.device):
         st = _stream(x.device)
         amax = _absmax(x, st) if autoscale else None
+        nbytes = int(L.hav_conv3x3s2_scratch_bytes(B, Cin, Cout, H, W, int(padding)))
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
         rc = L.hav_conv3x3s2_split(_p(y), _p(x), _p(packed), _p(s), _p(d), _p(noise), _p(noise_weight), _p(bias), float(slope), float(gain),
-                                   int(bool(act)), nb, B, Cin, Cout, H, W, int(padding), _p(amax), st)
+                                   int(bool(act)), nb, B, Cin, Cout, H, W, int(padding), _p(scratch), _p(amax), st)
     _lib.check(rc, "hav_conv3x3s2_split")
     return y
 

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define HAV_ABI_VERSION 3
+#define HAV_ABI_VERSION 4
 
 #define HAV_EINVAL   (-1) /* bad size / null pointer / inconsistent arguments            */
 #define HAV_EUNSUP   (-2) /* valid for the reference, not supported by this build        */
@@ -196,10 +196,13 @@ int hav_conv3x3_split(float* y, const float* x, const void* packed, const float*
 /* The same with stride 2 (the down-sampling ConvLayer / ConvBlock of the encoders after its Blur: EqualConv2d(stride 2, padding 0),
  * model/styleUnet.py:326-368): x [B,Cin,Hin,Win] -> y [B,Cout,Hout,Wout], Hout = (Hin + 2 pad - 3) / 2 + 1, pad 0 or 1 (zeros); same packed
  * weights, same fused terms (noise / d / bias indexed by the OUTPUT map), same arithmetic and range control.  Needs Cin % 16 == 0,
- * Cout % 64 == 0, Hout % 4 == 0, Wout % 32 == 0 (HAV_EUNSUP otherwise). */
+ * Cout % 64 == 0, Hout % 4 == 0, Wout % 32 == 0 (HAV_EUNSUP otherwise).  Maps with too few output tiles to fill the GPU split the channel
+ * range over 2-8 workgroups per tile (deterministic second pass): hav_conv3x3s2_scratch_bytes() bytes of caller scratch (0: not needed;
+ * NULL: never split).  ABI 4: the `scratch` argument. */
+int64_t hav_conv3x3s2_scratch_bytes(int B, int Cin, int Cout, int Hin, int Win, int pad);
 int hav_conv3x3s2_split(float* y, const float* x, const void* packed, const float* s, const float* d, const float* noise,
                         const float* noise_weight, const float* bias, float slope, float gain, int act, int noise_batched, int B,
-                        int Cin, int Cout, int Hin, int Win, int pad, const void* in_amax, void* stream);
+                        int Cin, int Cout, int Hin, int Win, int pad, void* scratch, const void* in_amax, void* stream);
 /* Range control for inputs far from 1 (gradients, 1e5-sized activations): hav_absmax leaves HAV_ABSMAX_WORDS partial maxima of |x| (bit patterns of
  * non-negative floats, one per slice of x; no atomics, nothing to initialise) in a caller buffer of HAV_ABSMAX_WORDS * 4 bytes,
  * 16-byte aligned; passed as `in_amax` (NULL: off) the convolution folds them and scales its input by the power of two that brings

@@ -611,7 +611,7 @@ def test_conv3x3_stride2_matches_fp64_and_the_layer_it_replaces(B, Cin, Cout, H,
 
 def test_downsampling_convlayer_takes_the_stride2_kernel_and_matches_the_aten_route():
     """ConvLayer(downsample=True) (Blur -> EqualConv2d stride 2 -> FusedLeakyReLU) at inference on HIP tensors: the fused route
-    (HAVATAR_CONV_S2=1: hav_upfirdn2d + hav_conv3x3s2_split) against the module's default MIOpen route."""
+    (the default: hav_upfirdn2d + hav_conv3x3s2_split) against the module's MIOpen route (HAVATAR_CONV_S2=0)."""
     import os
     from havatar_amd.model.styleUnet import ConvLayer
     torch.manual_seed(5)
@@ -620,10 +620,10 @@ def test_downsampling_convlayer_takes_the_stride2_kernel_and_matches_the_aten_ro
         layer[2].bias.data.normal_(0, 0.1)
         x = torch.randn(2, cin, H, H, device=DEV)
         with torch.no_grad():
-            want = layer(x)
-            os.environ["HAVATAR_CONV_S2"] = "1"
+            got = layer(x)
+            os.environ["HAVATAR_CONV_S2"] = "0"
             try:
-                got = layer(x)
+                want = layer(x)
             finally:
                 del os.environ["HAVATAR_CONV_S2"]
         assert got.shape == want.shape == (2, cout, H // 2, H // 2)

@@ -16,7 +16,10 @@ ends = [i for i, r in enumerate(rows) if r["Kernel_Name"] == last]
 # the final synthesis is the forward's last launch; earlier synthesis launches of the same forward share the name, so step back
 # by the per-forward count (found from the spacing of the last dispatches)
 gaps = [ends[i + 1] - ends[i] for i in range(len(ends) - 1)]
-per = max(gaps[-12:])
+# the launch pattern repeats with the forward: find the period of the gap sequence (e.g. 6 synthesis launches per forward)
+tail = gaps[-48:]
+period = next(p for p in range(1, 25) if all(tail[i] == tail[i - p] for i in range(p, len(tail))))
+per = sum(tail[-period:])
 a = len(rows) - 1 - per
 frame = rows[a + 1:]
 t0 = int(frame[0]["Start_Timestamp"]); t1 = int(frame[-1]["End_Timestamp"])
