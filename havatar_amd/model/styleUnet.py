@@ -282,6 +282,21 @@ class ConvLayer(nn.Sequential):
                 return _conv.conv3x3s2(xb, pk, ec.weight.shape[0], ec.padding, bias=ec.bias, act=False)
             out = ec(xb)
             return self[2](out) if len(self) > 2 else out
+        if (len(self) > 1 and isinstance(self[0], Blur) and isinstance(self[1], EqualConv2d) and input.is_cuda and input.dtype == torch.float32
+                and torch.is_grad_enabled() and _fused_conv_enabled() and os.environ.get("HAVATAR_CONV_S2", "1") != "0"
+                and os.environ.get("HAVATAR_HIP_TRAIN", "1") != "0"):
+            # HIP training, down-sampling layer: the Blur (its own autograd op) -> EqualConv2d stride 2 + bias + leaky-ReLU as one autograd
+            # node whose forward is hav_conv3x3s2_split (native/conv.py::_S2ConvBlock)
+            ec = self[1]
+            xb = self[0](input)
+            if xb.shape[-1] * xb.shape[-2] >= 1024 and _conv.s2_eligible(xb, ec.weight, ec.stride, ec.padding):
+                if len(self) > 2:
+                    return _conv.s2_block(xb, ec.weight, ec.scale, bias=self[2].bias, slope=self[2].negative_slope, gain=self[2].scale,
+                                          act=True, padding=ec.padding)
+                return _conv.s2_block(xb, ec.weight, ec.scale, bias=ec.bias, act=False, padding=ec.padding)
+            out = ec(xb)
+            return self[2](out) if len(self) > 2 else out
+        ec = self[0]
         if (isinstance(ec, EqualConv2d) and input.is_cuda and input.dtype == torch.float32 and torch.is_grad_enabled()
                 and _fused_conv_enabled() and ec.stride == 1 and ec.padding == 1 and input.shape[-1] * input.shape[-2] >= 1024
                 and _conv.block_eligible(input, ec.weight)):

@@ -311,6 +311,69 @@ def fused_block(x, W, scale, s=None, d=None, noise=None, noise_weight=None, bias
     return _FusedConvBlock.apply(x.contiguous(), W.contiguous(), f(s), f(d), f(noise), f(noise_weight), f(bias), scale, slope, gain, act)
 
 
+class _S2ConvBlock(torch.autograd.Function):
+    """y = act(conv3x3(x, scale * W, stride 2, padding) + bias) * gain -- the EqualConv2d + FusedLeakyReLU of a down-sampling ConvLayer
+    (reference model/styleUnet.py:326-368; its Blur stays its own autograd op in front) for training: forward = pack + range control +
+    hav_conv3x3s2_split instead of the weight scaling, MIOpen's Im2d2Col + fp32 GEMM and the activation launch; backward =
+    hav_conv_block_bwd (activation and bias gradients in one pass) + ATen's convolution_backward for the data and weight gradients.
+    Under create_graph=True the backward restates the layer with differentiable ATen ops; inside
+    conv2d_gradfix.no_weight_gradients() no weight gradient is formed."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias, scale, slope, gain, act, padding):
+        y = conv3x3s2(x, pack(W, scale), W.shape[0], padding, bias=bias, slope=slope, gain=gain, act=act)
+        ctx.save_for_backward(x, W, bias, y)
+        ctx.cfg = (float(scale), float(slope), float(gain), bool(act), int(padding))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        from ..model.op import conv2d_gradfix
+        x, W, bias, y = ctx.saved_tensors
+        scale, slope, gain, act, padding = ctx.cfg
+        need = ctx.needs_input_grad
+        if torch.is_grad_enabled():          # create_graph=True: the layer as differentiable ATen ops
+            with torch.enable_grad():
+                v = torch.nn.functional.conv2d(x, W * scale, stride=2, padding=padding)
+                if bias is not None:
+                    v = v + bias.view(1, -1, 1, 1)
+                if act:
+                    v = torch.nn.functional.leaky_relu(v, slope) * gain
+                slots = {0: x, 1: W, 2: bias}
+                if conv2d_gradfix.weight_gradients_disabled:
+                    slots.pop(1)
+                idx = [k for k, t in slots.items() if t is not None and need[k]]
+                got = torch.autograd.grad(v, [slots[k] for k in idx], g, create_graph=True, allow_unused=True) if idx else ()
+            out = [None] * 8
+            for k, gk in zip(idx, got):
+                out[k] = gk
+            return tuple(out)
+        g = g.contiguous()
+        B, Cout, Ho, Wo = y.shape
+        dev = y.device
+        gc = torch.empty_like(y)
+        sums = torch.empty(B * Cout * 3, dtype=torch.float32, device=dev)
+        gb = torch.empty(Cout, dtype=torch.float32, device=dev) if (bias is not None and need[2]) else None
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().hav_conv_block_bwd(_p(gc), None, _p(gb), None, _p(sums), _p(g), _p(y), None, None, None, _p(bias), slope, gain,
+                                                    int(act), 0, B, Cout, Ho * Wo, _stream(dev)), "hav_conv_block_bwd")
+        want_w = need[1] and not conv2d_gradfix.weight_gradients_disabled
+        gx = gW = None
+        if need[0] or want_w:
+            gx, gW, _ = torch.ops.aten.convolution_backward(gc, x, W * scale, None, [2, 2], [padding, padding], [1, 1], False, [0, 0], 1,
+                                                            [bool(need[0]), bool(want_w), False])
+            if gW is not None:
+                gW = gW * scale
+        if gb is not None and bias.shape != gb.shape:
+            gb = gb.view(bias.shape)
+        return (gx if need[0] else None), (gW if want_w else None), gb, None, None, None, None, None
+
+
+def s2_block(x, W, scale, bias=None, slope=0.2, gain=2 ** 0.5, act=True, padding=0):
+    """see _S2ConvBlock; x [B,Cin,Hin,Win] (already blurred), W [Cout,Cin,3,3] raw parameter; callers check s2_eligible(x, W, 2, padding)."""
+    return _S2ConvBlock.apply(x.contiguous(), W.contiguous(), None if bias is None else bias.contiguous(), scale, slope, gain, act, padding)
+
+
 def upconv_eligible(x, weight):
     """weight [Cout,Cin,3,3] (the ModulatedConv2d parameter); x [B,Cin,H,W] float32 on a HIP device: shapes hav_gemm_split +
     hav_upconv_finish take."""

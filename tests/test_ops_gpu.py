@@ -609,6 +609,75 @@ def test_conv3x3_stride2_matches_fp64_and_the_layer_it_replaces(B, Cin, Cout, H,
     assert (y0.double() - t0).abs().max().item() <= 2e-6 * t0.abs().max().item()
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,act", [(2, 64, 128, 129, True), (1, 256, 256, 65, True), (2, 32, 64, 129, False)])
+def test_stride2_training_node_matches_fp64_autograd_first_and_second_order(B, Cin, Cout, H, act):
+    """_S2ConvBlock (a down-sampling ConvLayer's EqualConv2d + FusedLeakyReLU under autograd: forward on hav_conv3x3s2_split, backward =
+    hav_conv_block_bwd + ATen's convolution_backward): output, first-order gradients (x, W, bias) and, under create_graph=True, second-order
+    gradients against the ATen statement in fp64, with the fp32 ATen route as the yardstick; no_weight_gradients() forms none."""
+    from havatar_amd.native import conv
+    from havatar_amd.model.op import conv2d_gradfix
+    g = torch.Generator(device=DEV).manual_seed(B + Cin + H)
+    r = lambda *sh: torch.randn(*sh, device=DEV, generator=g)
+    x0, W0, b0, up = r(B, Cin, H, H), r(Cout, Cin, 3, 3), 0.2 * r(Cout), r(B, Cout, H // 2, H // 2)
+    scale = 1.0 / (Cin * 9) ** 0.5
+
+    def run(dt, fused, second):
+        x, W, b = (t.to(dt).clone().requires_grad_(True) for t in (x0, W0, b0))
+        if fused:
+            assert conv.s2_eligible(x, W, 2, 0)
+            y = conv.s2_block(x, W, scale, bias=b, act=act, padding=0)
+        else:
+            y = torch.nn.functional.conv2d(x, W * scale, stride=2) + b.view(1, -1, 1, 1)
+            if act:
+                y = torch.nn.functional.leaky_relu(y, 0.2) * 2 ** 0.5
+        if not second:
+            (y * up.to(dt)).sum().backward()
+            return [y.detach().double()] + [t.grad.double() for t in (x, W, b)]
+        gx, = torch.autograd.grad((y * up.to(dt)).pow(2).sum(), x, create_graph=True)
+        assert gx.requires_grad
+        gx.pow(2).sum().backward()
+        return [t.grad.double() for t in (x, W, b)]
+
+    for second in (False, True):
+        truth, ref, got = run(torch.float64, False, second), run(torch.float32, False, second), run(torch.float32, True, second)
+        for i, (t, a, o) in enumerate(zip(truth, ref, got)):
+            err, yard = (o - t).abs().max().item(), (a - t).abs().max().item()
+            assert err <= max(4 * yard, 3e-6 * t.abs().max().item()), (second, i, err, yard)
+    x, W = x0.clone().requires_grad_(True), W0.clone().requires_grad_(True)
+    y = conv.s2_block(x, W, scale, bias=b0, act=act, padding=0)
+    with conv2d_gradfix.no_weight_gradients():
+        y.sum().backward(retain_graph=True)
+    assert W.grad is None and x.grad is not None
+    y.sum().backward()
+    assert W.grad is not None
+
+
+def test_downsampling_convlayer_training_takes_the_stride2_node():
+    """ConvLayer(downsample=True) with gradients enabled on HIP tensors: the module goes through _S2ConvBlock (Blur stays its own autograd
+    op) and its output and parameter / input gradients equal the unfused route's (HAVATAR_CONV_S2=0)."""
+    import os
+    from havatar_amd.model.styleUnet import ConvLayer
+    from havatar_amd.native import conv
+    torch.manual_seed(9)
+    layer = ConvLayer(64, 128, 3, downsample=True).to(DEV).train()
+    layer[2].bias.data.normal_(0, 0.1)
+    x0 = torch.randn(2, 64, 128, 128, device=DEV)
+    res = {}
+    for route in ("1", "0"):
+        os.environ["HAVATAR_CONV_S2"] = route
+        try:
+            layer.zero_grad(set_to_none=True)
+            x = x0.clone().requires_grad_(True)
+            y = layer(x)
+            assert (type(y.grad_fn).__name__ == "_S2ConvBlockBackward") == (route == "1"), type(y.grad_fn).__name__
+            y.pow(2).sum().backward()
+            res[route] = [y.detach(), x.grad, layer[1].weight.grad.clone(), layer[2].bias.grad.clone()]
+        finally:
+            del os.environ["HAVATAR_CONV_S2"]
+    for a, b in zip(res["1"], res["0"]):
+        assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item()
+
+
 def test_downsampling_convlayer_takes_the_stride2_kernel_and_matches_the_aten_route():
     """ConvLayer(downsample=True) (Blur -> EqualConv2d stride 2 -> FusedLeakyReLU) at inference on HIP tensors: the fused route
     (the default: hav_upfirdn2d + hav_conv3x3s2_split) against the module's MIOpen route (HAVATAR_CONV_S2=0)."""
