@@ -435,6 +435,16 @@ class StyledConv(nn.Module):
                 noise = input.new_empty(b, 1, h, w).normal_()
             return _conv.fused_block(input, self.conv.weight[0], self.conv.scale, s=s, d=d, noise=noise, noise_weight=self.noise.weight,
                                      bias=self.activate.bias, slope=self.activate.negative_slope, gain=self.activate.scale, act=True)
+        if (input.is_cuda and input.dtype == torch.float32 and torch.is_grad_enabled() and self.conv.fused_upconv_ok(input)
+                and os.environ.get("HAVATAR_HIP_TRAIN", "1") != "0" and _conv.upconv_block_eligible(input, self.conv.weight[0])):
+            # HIP training, up-sampling 3x3: the whole block as one autograd node (native/conv.py::_UpConvBlock)
+            s, d = self.conv.style_vectors(style)
+            if noise is None:
+                b, _, h, w = input.shape
+                noise = input.new_empty(b, 1, 2 * h, 2 * w).normal_()
+            return _conv.upconv_block(input, self.conv.weight[0], self.conv.scale, self.conv.blur.kernel, s=s, d=d, noise=noise,
+                                      noise_weight=self.noise.weight, bias=self.activate.bias, slope=self.activate.negative_slope,
+                                      gain=self.activate.scale, act=True)
         if self.conv._hip_inference(input):
             # HIP inference: demodulation * noise injection + bias + leaky-relu in ONE pass (hav_styled_epilogue) instead of four
             from ..native import fused

@@ -427,3 +427,107 @@ def upconv3x3(x, packed, Cout, fir, s=None, d=None, noise=None, noise_weight=Non
         _lib.check(L.hav_upconv_finish(_p(y), _p(col), _p(fir), _p(d), _p(noise), _p(noise_weight), _p(bias), float(slope), float(gain),
                                        int(bool(act)), nb, B, Cout, H, W, st), "hav_upconv_finish")
     return y
+
+
+def upconv_block_eligible(x, weight):
+    """x [B,Cin,H,W], weight [Cout,Cin,3,3]: shapes for which the forward (hav_gemm_split + hav_upconv_finish) AND the data gradient
+    (a stride-2 3x3 convolution of the blurred output gradient with Cin and Cout in swapped roles: hav_conv3x3s2_split) of
+    upconv_block run on this library's kernels."""
+    if not upconv_eligible(x, weight) or os.environ.get("HAVATAR_FUSED_UPBLOCK", "1") == "0":
+        return False
+    Cout, Cin = weight.shape[:2]
+    B, _, H, W = x.shape
+    return Cout % 16 == 0 and Cin % 64 == 0 and H % 4 == 0 and W % 32 == 0 and Cout * (2 * H + 1) * (2 * W + 1) < 2 ** 31
+
+
+class _UpConvBlock(torch.autograd.Function):
+    """y [B,Cout,2H,2W] = act(d * blur(conv_transpose2d(s * x, scale * W, stride 2)) + nw * noise + bias) * gain -- an up-sampling
+    StyledConv (reference model/styleUnet.py:236-243,565-599) as ONE autograd node.  Forward = hav_gemm_split + hav_upconv_finish (the
+    inference route).  Backward: hav_conv_block_bwd (activation gradient; d / bias / noise-weight gradients) -> the blur's adjoint
+    (hav_upfirdn2d with the flipped FIR and padding (2, 2): [2H] -> [2H + 1]) -> the data gradient, which IS a stride-2 3x3 convolution of
+    that map with the same filters (Cin and Cout swap roles; no flip: the adjoint of conv_transpose2d(., w) is conv2d(., w)) on
+    hav_conv3x3s2_split -> hav_mod_input_bwd (s gradient, input scaling); the weight gradient is ATen's (MIOpen) on the same blurred map.
+    Replaces ~25 ATen / MIOpen launches per layer and step (modulate, scale, transposed convolution + transposes, blur, demodulate,
+    noise, bias, activation, and their gradients) by 9.  Under create_graph=True the backward restates the block with differentiable
+    ATen ops; inside conv2d_gradfix.no_weight_gradients() no weight gradient is formed."""
+
+    @staticmethod
+    def forward(ctx, x, W, s, d, noise, nw, bias, fir, scale, slope, gain, act):
+        y = upconv3x3(x, pack_upconv(W, scale), W.shape[0], fir, s=s, d=d, noise=noise, noise_weight=nw, bias=bias, slope=slope, gain=gain, act=act)
+        ctx.save_for_backward(x, W, s, d, noise, nw, bias, fir, y)
+        ctx.cfg = (float(scale), float(slope), float(gain), bool(act))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        from ..model.op import conv2d_gradfix
+        from ..model.op.upfirdn2d import upfirdn2d as _ufd
+        x, W, s, d, noise, nw, bias, fir, y = ctx.saved_tensors
+        scale, slope, gain, act = ctx.cfg
+        need = ctx.needs_input_grad
+        B, Cout, H2, W2 = y.shape
+        Cin, H, Wd = x.shape[1:]
+        if torch.is_grad_enabled():          # create_graph=True: the block as differentiable ATen ops
+            with torch.enable_grad():
+                xs = x * s.view(B, Cin, 1, 1) if s is not None else x
+                v = torch.nn.functional.conv_transpose2d(xs, (W * scale).transpose(0, 1), stride=2)
+                v = torch.nn.functional.conv2d(torch.nn.functional.pad(v, (1, 1, 1, 1)), fir.flip(0, 1).view(1, 1, 4, 4).expand(Cout, 1, 4, 4), groups=Cout)
+                if d is not None:
+                    v = v * d.view(B, Cout, 1, 1)
+                if noise is not None:
+                    v = v + nw * noise
+                if bias is not None:
+                    v = v + bias.view(1, -1, 1, 1)
+                if act:
+                    v = torch.nn.functional.leaky_relu(v, slope) * gain
+                slots = {0: x, 1: W, 2: s, 3: d, 5: nw, 6: bias}
+                if conv2d_gradfix.weight_gradients_disabled:
+                    slots.pop(1)
+                idx = [k for k, t in slots.items() if t is not None and need[k]]
+                got = torch.autograd.grad(v, [slots[k] for k in idx], g, create_graph=True, allow_unused=True) if idx else ()
+            out = [None] * 12
+            for k, gk in zip(idx, got):
+                out[k] = gk
+            return tuple(out)
+        g = g.contiguous()
+        L = _lib.lib()
+        dev = y.device
+        gc = torch.empty_like(y)
+        sums = torch.empty(B * Cout * 3, dtype=torch.float32, device=dev)
+        gd = torch.empty(B, Cout, dtype=torch.float32, device=dev) if (d is not None and need[3]) else None
+        gb = torch.empty(Cout, dtype=torch.float32, device=dev) if (bias is not None and need[6]) else None
+        gnw = torch.empty(1, dtype=torch.float32, device=dev) if (noise is not None and nw is not None and need[5]) else None
+        nb = 1 if (noise is not None and B > 1 and noise.numel() == B * H2 * W2) else 0
+        with torch.cuda.device(dev):
+            _lib.check(L.hav_conv_block_bwd(_p(gc), _p(gd), _p(gb), _p(gnw), _p(sums), _p(g), _p(y), _p(d), _p(noise), _p(nw), _p(bias), slope, gain,
+                                            int(act), nb, B, Cout, H2 * W2, _stream(dev)), "hav_conv_block_bwd")
+        want_w = need[1] and not conv2d_gradfix.weight_gradients_disabled
+        gx = gs = gW = None
+        if need[0] or (s is not None and need[2]) or want_w:
+            gv = _ufd(gc, fir.flip(0, 1), pad=(2, 2))          # d loss / d conv_transpose2d output  [B,Cout,2H+1,2W+1]
+            wt = W.transpose(0, 1).contiguous()                          # [Cin,Cout,3,3]: conv_transpose2d's weight = the data gradient's conv weight
+            if need[0] or (s is not None and need[2]):
+                gx = conv3x3s2(gv, pack(wt, scale), Cin, 0, act=False, autoscale=True)          # dL/d(s x): gradient-sized, see hav_absmax
+                if s is not None:
+                    gs = torch.empty(B, Cin, dtype=torch.float32, device=dev)
+                    with torch.cuda.device(dev):
+                        _lib.check(L.hav_mod_input_bwd(_p(gx), _p(gs), _p(x), _p(s), B, Cin, H * Wd, _stream(dev)), "hav_mod_input_bwd")
+            if want_w:
+                xs = x * s.view(B, Cin, 1, 1) if s is not None else x
+                _, gwt, _ = torch.ops.aten.convolution_backward(gv, xs, wt, None, [2, 2], [0, 0], [1, 1], True, [0, 0], 1, [False, True, False])
+                gW = gwt.transpose(0, 1) * scale
+        if gnw is not None and nw.shape != gnw.shape:
+            gnw = gnw.view(nw.shape)
+        if gb is not None and bias.shape != gb.shape:
+            gb = gb.view(bias.shape)
+        return (gx if need[0] else None), gW, (gs if need[2] else None), gd, None, gnw, gb, None, None, None, None, None
+
+
+def upconv_block(x, W, scale, fir, s=None, d=None, noise=None, noise_weight=None, bias=None, slope=0.2, gain=2 ** 0.5, act=True):
+    """see _UpConvBlock; x [B,Cin,H,W], W [Cout,Cin,3,3] raw parameter, fir the blur's [4,4] kernel (factor^2 folded in), s [B,Cin], d [B,Cout],
+    noise [1|B,1,2H,2W] (not differentiated), noise_weight [1], bias [Cout]; callers check upconv_block_eligible(x, W)."""
+    f = lambda t: None if t is None else t.contiguous()
+    if noise is not None and noise_weight is None:
+        noise = None
+    return _UpConvBlock.apply(x.contiguous(), W.contiguous(), f(s), f(d), f(noise), f(noise_weight), f(bias), fir.detach().contiguous(), scale, slope,
+                              gain, act)

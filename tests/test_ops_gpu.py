@@ -678,6 +678,86 @@ def test_downsampling_convlayer_training_takes_the_stride2_node():
         assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item()
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W,modulated", [(2, 64, 32, 32, 32, True), (1, 128, 64, 16, 64, True), (2, 64, 64, 32, 32, False)])
+def test_upsampling_block_training_node_matches_fp64_autograd_first_and_second_order(B, Cin, Cout, H, W, modulated):
+    """_UpConvBlock (an up-sampling StyledConv under autograd: forward hav_gemm_split + hav_upconv_finish; backward hav_conv_block_bwd ->
+    the blur's adjoint -> the data gradient as a stride-2 convolution on hav_conv3x3s2_split -> hav_mod_input_bwd, weight gradient on
+    ATen): output, every first-order gradient and, under create_graph=True, second-order gradients against the ATen statement in fp64,
+    with the fp32 ATen route as the yardstick; no_weight_gradients() forms none."""
+    from havatar_amd.native import conv
+    from havatar_amd.model.op import conv2d_gradfix
+    g = torch.Generator(device=DEV).manual_seed(B * 3 + Cin + Cout + H)
+    r = lambda *sh: torch.randn(*sh, device=DEV, generator=g)
+    x0, W0 = r(B, Cin, H, W), r(Cout, Cin, 3, 3)
+    s0, d0 = 1.0 + 0.3 * r(B, Cin), 0.5 + torch.rand(B, Cout, device=DEV, generator=g)
+    noise, nw0, b0 = r(B, 1, 2 * H, 2 * W), torch.full((1,), 0.37, device=DEV), 0.2 * r(Cout)
+    up = r(B, Cout, 2 * H, 2 * W)
+    k1 = torch.tensor([1.0, 3.0, 3.0, 1.0], device=DEV)
+    fir = (k1[:, None] * k1[None, :]) / k1.sum() ** 2 * 4.0
+    scale = 1.0 / (Cin * 9) ** 0.5
+
+    def run(dt, fused, second):
+        x, Wp, s, d, nw, b = (t.to(dt).clone().requires_grad_(True) for t in (x0, W0, s0, d0, nw0, b0))
+        if fused:
+            assert conv.upconv_block_eligible(x, Wp)
+            y = conv.upconv_block(x, Wp, scale, fir, s=s if modulated else None, d=d if modulated else None, noise=noise, noise_weight=nw, bias=b, act=True)
+        else:
+            xs = x * s.view(B, Cin, 1, 1) if modulated else x
+            v = torch.nn.functional.conv_transpose2d(xs, (Wp * scale).transpose(0, 1), stride=2)
+            v = torch.nn.functional.conv2d(torch.nn.functional.pad(v, (1, 1, 1, 1)), fir.to(dt).flip(0, 1).view(1, 1, 4, 4).expand(Cout, 1, 4, 4), groups=Cout)
+            if modulated:
+                v = v * d.view(B, Cout, 1, 1)
+            y = torch.nn.functional.leaky_relu(v + nw * noise.to(dt) + b.view(1, -1, 1, 1), 0.2) * 2 ** 0.5
+        leaves = [x, Wp, nw, b] + ([s, d] if modulated else [])
+        if not second:
+            (y * up.to(dt)).sum().backward()
+            return [y.detach().double()] + [t.grad.double() for t in leaves]
+        first = torch.autograd.grad((y * up.to(dt)).pow(2).sum(), [x] + ([s] if modulated else []), create_graph=True)
+        assert all(t.requires_grad for t in first)
+        sum(t.pow(2).sum() for t in first).backward()
+        return [t.grad.double() for t in leaves]
+
+    for second in (False, True):
+        truth, ref, got = run(torch.float64, False, second), run(torch.float32, False, second), run(torch.float32, True, second)
+        for i, (t, a, o) in enumerate(zip(truth, ref, got)):
+            err, yard = (o - t).abs().max().item(), (a - t).abs().max().item()
+            assert err <= max(4 * yard, 4e-6 * t.abs().max().item()), (second, i, err, yard, t.abs().max().item())
+    x, Wp = x0.clone().requires_grad_(True), W0.clone().requires_grad_(True)
+    y = conv.upconv_block(x, Wp, scale, fir, bias=b0, act=True)
+    with conv2d_gradfix.no_weight_gradients():
+        y.sum().backward(retain_graph=True)
+    assert Wp.grad is None and x.grad is not None
+    y.sum().backward()
+    assert Wp.grad is not None
+
+
+def test_upsampling_styledconv_training_takes_the_fused_node():
+    """StyledConv(upsample=True) with gradients enabled on HIP tensors goes through _UpConvBlock; output and gradients equal the unfused
+    route's (HAVATAR_FUSED_UPBLOCK=0: MIOpen's transposed convolution + the ATen glue)."""
+    import os
+    from havatar_amd.model.styleUnet import StyledConv
+    torch.manual_seed(11)
+    layer = StyledConv(128, 64, 3, 32, upsample=True).to(DEV).train()
+    layer.activate.bias.data.normal_(0, 0.1)
+    layer.noise.weight.data.fill_(0.3)
+    x0, st0, noise = torch.randn(2, 128, 32, 32, device=DEV), torch.randn(2, 32, device=DEV), torch.randn(2, 1, 64, 64, device=DEV)
+    res = {}
+    for route in ("1", "0"):
+        os.environ["HAVATAR_FUSED_UPBLOCK"] = route
+        try:
+            layer.zero_grad(set_to_none=True)
+            x, st = x0.clone().requires_grad_(True), st0.clone().requires_grad_(True)
+            y = layer(x, st, noise=noise)
+            assert (type(y.grad_fn).__name__ == "_UpConvBlockBackward") == (route == "1"), type(y.grad_fn).__name__
+            y.pow(2).sum().backward()
+            res[route] = [y.detach(), x.grad, st.grad, layer.conv.weight.grad.clone(), layer.conv.modulation.weight.grad.clone(),
+                          layer.activate.bias.grad.clone(), layer.noise.weight.grad.clone()]
+        finally:
+            del os.environ["HAVATAR_FUSED_UPBLOCK"]
+    for i, (a, b) in enumerate(zip(res["1"], res["0"])):
+        assert (a - b).abs().max().item() <= 3e-4 * b.abs().max().item(), (i, (a - b).abs().max().item(), b.abs().max().item())
+
+
 def test_downsampling_convlayer_takes_the_stride2_kernel_and_matches_the_aten_route():
     """ConvLayer(downsample=True) (Blur -> EqualConv2d stride 2 -> FusedLeakyReLU) at inference on HIP tensors: the fused route
     (the default: hav_upfirdn2d + hav_conv3x3s2_split) against the module's MIOpen route (HAVATAR_CONV_S2=0)."""
