@@ -287,14 +287,16 @@ class ConvLayer(nn.Sequential):
                 and os.environ.get("HAVATAR_HIP_TRAIN", "1") != "0"):
             # HIP training, down-sampling layer: the Blur (its own autograd op) -> EqualConv2d stride 2 + bias + leaky-ReLU as one autograd
             # node whose forward is hav_conv3x3s2_split (native/conv.py::_S2ConvBlock)
-            ec = self[1]
-            xb = self[0](input)
-            if xb.shape[-1] * xb.shape[-2] >= 1024 and _conv.s2_eligible(xb, ec.weight, ec.stride, ec.padding):
+            ec, bl = self[1], self[0]
+            p = bl.pad if len(bl.pad) == 4 else (bl.pad[0], bl.pad[1], bl.pad[0], bl.pad[1])
+            kh, kw = bl.kernel.shape
+            shape_b = (input.shape[0], input.shape[1], input.shape[2] + p[2] + p[3] - kh + 1, input.shape[3] + p[0] + p[1] - kw + 1)
+            if shape_b[-1] * shape_b[-2] >= 1024 and _conv.s2_eligible(input, ec.weight, ec.stride, ec.padding, shape=shape_b):
                 if len(self) > 2:
-                    return _conv.s2_block(xb, ec.weight, ec.scale, bias=self[2].bias, slope=self[2].negative_slope, gain=self[2].scale,
-                                          act=True, padding=ec.padding)
-                return _conv.s2_block(xb, ec.weight, ec.scale, bias=ec.bias, act=False, padding=ec.padding)
-            out = ec(xb)
+                    return _conv.s2_block(input, ec.weight, ec.scale, bias=self[2].bias, slope=self[2].negative_slope, gain=self[2].scale,
+                                          act=True, padding=ec.padding, fir=bl.kernel, fir_pad=bl.pad)
+                return _conv.s2_block(input, ec.weight, ec.scale, bias=ec.bias, act=False, padding=ec.padding, fir=bl.kernel, fir_pad=bl.pad)
+            out = ec(bl(input))
             return self[2](out) if len(self) > 2 else out
         ec = self[0]
         if (isinstance(ec, EqualConv2d) and input.is_cuda and input.dtype == torch.float32 and torch.is_grad_enabled()

@@ -101,12 +101,13 @@ def conv3x3(x, packed, Cout, s=None, d=None, noise=None, noise_weight=None, bias
     return y
 
 
-def s2_eligible(x, weight, stride=2, padding=0):
-    """weight [Cout,Cin,3,3]; x [B,Cin,Hin,Win] float32 on a HIP device: shapes hav_conv3x3s2_split takes."""
+def s2_eligible(x, weight, stride=2, padding=0, shape=None):
+    """weight [Cout,Cin,3,3]; x [B,Cin,Hin,Win] float32 on a HIP device: shapes hav_conv3x3s2_split takes.  shape: the convolution's input
+    shape when x is the tensor in front of a Blur that has not run yet."""
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and weight.dim() == 4):
         return False
     Cout, Cin, kh, kw = weight.shape
-    B, Ci, H, W = x.shape
+    B, Ci, H, W = x.shape if shape is None else shape
     if not (kh == 3 and kw == 3 and stride == 2 and padding in (0, 1) and Ci == Cin and Cin % 16 == 0 and Cout % 64 == 0):
         return False
     Ho, Wo = (H + 2 * padding - 3) // 2 + 1, (W + 2 * padding - 3) // 2 + 1
@@ -312,29 +313,41 @@ def fused_block(x, W, scale, s=None, d=None, noise=None, noise_weight=None, bias
 
 
 class _S2ConvBlock(torch.autograd.Function):
-    """y = act(conv3x3(x, scale * W, stride 2, padding) + bias) * gain -- the EqualConv2d + FusedLeakyReLU of a down-sampling ConvLayer
-    (reference model/styleUnet.py:326-368; its Blur stays its own autograd op in front) for training: forward = pack + range control +
-    hav_conv3x3s2_split instead of the weight scaling, MIOpen's Im2d2Col + fp32 GEMM and the activation launch; backward =
-    hav_conv_block_bwd (activation and bias gradients in one pass) + ATen's convolution_backward for the data and weight gradients.
-    Under create_graph=True the backward restates the layer with differentiable ATen ops; inside
-    conv2d_gradfix.no_weight_gradients() no weight gradient is formed."""
+    """y = act(conv3x3(blur(x), scale * W, stride 2, padding) + bias) * gain -- a down-sampling ConvLayer (Blur -> EqualConv2d stride 2 ->
+    FusedLeakyReLU, reference model/styleUnet.py:326-368) as ONE autograd node.  Forward = hav_upfirdn2d + pack + range control +
+    hav_conv3x3s2_split instead of the weight scaling, MIOpen's Im2d2Col + fp32 GEMM and the activation launch.  Backward:
+    hav_conv_block_bwd (activation and bias gradients in one pass); the data gradient THROUGH THE BLUR is conv_transpose2d(g, W, stride 2)
+    followed by the blur's adjoint, a 4x4 FIR with padding (1, 1) -- which is the up-sampling StyledConv's forward, so it runs on
+    hav_gemm_split + hav_upconv_finish with Cin and Cout in swapped roles (where their shapes allow; else ATen + hav_upfirdn2d); the weight
+    gradient is ATen's (MIOpen) on the saved blurred map.  `fir` None: x is taken as already blurred.  Under create_graph=True the backward
+    restates the layer with differentiable ATen ops; inside conv2d_gradfix.no_weight_gradients() no weight gradient is formed."""
 
     @staticmethod
-    def forward(ctx, x, W, bias, scale, slope, gain, act, padding):
-        y = conv3x3s2(x, pack(W, scale), W.shape[0], padding, bias=bias, slope=slope, gain=gain, act=act)
-        ctx.save_for_backward(x, W, bias, y)
-        ctx.cfg = (float(scale), float(slope), float(gain), bool(act), int(padding))
+    def forward(ctx, x, W, bias, fir, scale, slope, gain, act, padding, fpad):
+        from ..model.op.upfirdn2d import upfirdn2d as _ufd
+        xb = _ufd(x, fir, pad=fpad) if fir is not None else x
+        y = conv3x3s2(xb, pack(W, scale), W.shape[0], padding, bias=bias, slope=slope, gain=gain, act=act)
+        ctx.save_for_backward(x, xb, W, bias, fir, y)          # (x itself is only read under create_graph; its producer keeps it alive anyway)
+        ctx.cfg = (float(scale), float(slope), float(gain), bool(act), int(padding), tuple(fpad) if fpad is not None else None, tuple(x.shape))
         return y
 
     @staticmethod
     def backward(ctx, g):
         from ..model.op import conv2d_gradfix
-        x, W, bias, y = ctx.saved_tensors
-        scale, slope, gain, act, padding = ctx.cfg
+        from ..model.op.upfirdn2d import upfirdn2d as _ufd
+        x, xb, W, bias, fir, y = ctx.saved_tensors
+        scale, slope, gain, act, padding, fpad, xshape = ctx.cfg
         need = ctx.needs_input_grad
+        B, Cout, Ho, Wo = y.shape
+        Cin = W.shape[1]
         if torch.is_grad_enabled():          # create_graph=True: the layer as differentiable ATen ops
             with torch.enable_grad():
-                v = torch.nn.functional.conv2d(x, W * scale, stride=2, padding=padding)
+                v = x
+                if fir is not None:
+                    kh, kw = fir.shape
+                    p = fpad if len(fpad) == 4 else (fpad[0], fpad[1], fpad[0], fpad[1])
+                    v = torch.nn.functional.conv2d(torch.nn.functional.pad(v, p), fir.flip(0, 1).view(1, 1, kh, kw).expand(Cin, 1, kh, kw), groups=Cin)
+                v = torch.nn.functional.conv2d(v, W * scale, stride=2, padding=padding)
                 if bias is not None:
                     v = v + bias.view(1, -1, 1, 1)
                 if act:
@@ -344,12 +357,11 @@ class _S2ConvBlock(torch.autograd.Function):
                     slots.pop(1)
                 idx = [k for k, t in slots.items() if t is not None and need[k]]
                 got = torch.autograd.grad(v, [slots[k] for k in idx], g, create_graph=True, allow_unused=True) if idx else ()
-            out = [None] * 8
+            out = [None] * 10
             for k, gk in zip(idx, got):
                 out[k] = gk
             return tuple(out)
         g = g.contiguous()
-        B, Cout, Ho, Wo = y.shape
         dev = y.device
         gc = torch.empty_like(y)
         sums = torch.empty(B * Cout * 3, dtype=torch.float32, device=dev)
@@ -359,19 +371,32 @@ class _S2ConvBlock(torch.autograd.Function):
                                                     int(act), 0, B, Cout, Ho * Wo, _stream(dev)), "hav_conv_block_bwd")
         want_w = need[1] and not conv2d_gradfix.weight_gradients_disabled
         gx = gW = None
-        if need[0] or want_w:
-            gx, gW, _ = torch.ops.aten.convolution_backward(gc, x, W * scale, None, [2, 2], [padding, padding], [1, 1], False, [0, 0], 1,
-                                                            [bool(need[0]), bool(want_w), False])
-            if gW is not None:
-                gW = gW * scale
+        if need[0]:
+            wt = W.transpose(0, 1).contiguous()          # [Cin,Cout,3,3]: as an up-sampling layer's parameter it maps Cout -> Cin channels
+            fused = (fir is not None and tuple(fir.shape) == (4, 4) and tuple(fpad) in ((2, 2), (2, 2, 2, 2)) and padding == 0
+                     and tuple(xshape[2:]) == (2 * Ho, 2 * Wo) and upconv_eligible(gc, wt) and os.environ.get("HAVATAR_S2_DGRAD", "1") != "0")
+            if fused:
+                gx = upconv3x3(gc, pack_upconv(wt, scale), Cin, fir.flip(0, 1), act=False, autoscale=True)          # gradient-sized: see hav_absmax
+            else:
+                gx, _, _ = torch.ops.aten.convolution_backward(gc, xb, W * scale, None, [2, 2], [padding, padding], [1, 1], False, [0, 0], 1,
+                                                               [True, False, False])
+                if fir is not None:
+                    kh, kw = fir.shape
+                    p = fpad if len(fpad) == 4 else (fpad[0], fpad[1], fpad[0], fpad[1])
+                    gx = _ufd(gx, fir.flip(0, 1), pad=(kw - 1 - p[0], kw - 1 - p[1], kh - 1 - p[2], kh - 1 - p[3]))
+        if want_w:
+            _, gW, _ = torch.ops.aten.convolution_backward(gc, xb, W, None, [2, 2], [padding, padding], [1, 1], False, [0, 0], 1, [False, True, False])
+            gW = gW * scale
         if gb is not None and bias.shape != gb.shape:
             gb = gb.view(bias.shape)
-        return (gx if need[0] else None), (gW if want_w else None), gb, None, None, None, None, None
+        return gx, gW, gb, None, None, None, None, None, None, None
 
 
-def s2_block(x, W, scale, bias=None, slope=0.2, gain=2 ** 0.5, act=True, padding=0):
-    """see _S2ConvBlock; x [B,Cin,Hin,Win] (already blurred), W [Cout,Cin,3,3] raw parameter; callers check s2_eligible(x, W, 2, padding)."""
-    return _S2ConvBlock.apply(x.contiguous(), W.contiguous(), None if bias is None else bias.contiguous(), scale, slope, gain, act, padding)
+def s2_block(x, W, scale, bias=None, slope=0.2, gain=2 ** 0.5, act=True, padding=0, fir=None, fir_pad=None):
+    """see _S2ConvBlock; x [B,Cin,H,W]; fir / fir_pad: the layer's Blur (kernel [kh,kw], pad (p0,p1) or (x0,x1,y0,y1)), or None when x is
+    already blurred; W [Cout,Cin,3,3] raw parameter.  Callers check s2_eligible on the BLURRED shape."""
+    return _S2ConvBlock.apply(x.contiguous(), W.contiguous(), None if bias is None else bias.contiguous(),
+                              None if fir is None else fir.detach().contiguous(), scale, slope, gain, act, padding, fir_pad)
 
 
 def upconv_eligible(x, weight):

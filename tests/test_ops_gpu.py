@@ -652,6 +652,42 @@ def test_stride2_training_node_matches_fp64_autograd_first_and_second_order(B, C
     assert W.grad is not None
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,dgrad", [(2, 64, 128, 128, "1"), (1, 256, 256, 64, "1"), (2, 64, 128, 128, "0")])
+def test_stride2_training_node_with_its_blur_matches_fp64_autograd(B, Cin, Cout, H, dgrad, monkeypatch):
+    """The same node with the layer's Blur inside (how ConvLayer(downsample=True) calls it): the data gradient through blur + convolution
+    runs as an up-sampling layer on hav_gemm_split + hav_upconv_finish (HAVATAR_S2_DGRAD=0: ATen + hav_upfirdn2d); first and second order
+    against the fp64 statement."""
+    from havatar_amd.native import conv
+    monkeypatch.setenv("HAVATAR_S2_DGRAD", dgrad)
+    g = torch.Generator(device=DEV).manual_seed(B + Cin + H + 1)
+    r = lambda *sh: torch.randn(*sh, device=DEV, generator=g)
+    x0, W0, b0, up = r(B, Cin, H, H), r(Cout, Cin, 3, 3), 0.2 * r(Cout), r(B, Cout, H // 2, H // 2)
+    k1 = torch.tensor([1.0, 3.0, 3.0, 1.0], device=DEV)
+    fir = (k1[:, None] * k1[None, :]) / k1.sum() ** 2
+    scale = 1.0 / (Cin * 9) ** 0.5
+
+    def run(dt, fused, second):
+        x, W, b = (t.to(dt).clone().requires_grad_(True) for t in (x0, W0, b0))
+        if fused:
+            y = conv.s2_block(x, W, scale, bias=b, act=True, padding=0, fir=fir, fir_pad=(2, 2))
+        else:
+            xb = torch.nn.functional.conv2d(torch.nn.functional.pad(x, (2, 2, 2, 2)), fir.to(dt).flip(0, 1).view(1, 1, 4, 4).expand(Cin, 1, 4, 4), groups=Cin)
+            y = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(xb, W * scale, stride=2) + b.view(1, -1, 1, 1), 0.2) * 2 ** 0.5
+        assert y.shape == (B, Cout, H // 2, H // 2)
+        if not second:
+            (y * up.to(dt)).sum().backward()
+            return [y.detach().double()] + [t.grad.double() for t in (x, W, b)]
+        gx, = torch.autograd.grad((y * up.to(dt)).pow(2).sum(), x, create_graph=True)
+        gx.pow(2).sum().backward()
+        return [t.grad.double() for t in (x, W, b)]
+
+    for second in (False, True):
+        truth, ref, got = run(torch.float64, False, second), run(torch.float32, False, second), run(torch.float32, True, second)
+        for i, (t, a, o) in enumerate(zip(truth, ref, got)):
+            err, yard = (o - t).abs().max().item(), (a - t).abs().max().item()
+            assert err <= max(4 * yard, 4e-6 * t.abs().max().item()), (second, i, err, yard)
+
+
 def test_downsampling_convlayer_training_takes_the_stride2_node():
     """ConvLayer(downsample=True) with gradients enabled on HIP tensors: the module goes through _S2ConvBlock (Blur stays its own autograd
     op) and its output and parameter / input gradients equal the unfused route's (HAVATAR_CONV_S2=0)."""
