@@ -267,7 +267,8 @@ class ConvLayer(nn.Sequential):
     def forward(self, input):
         ec = self[0]
         if (len(self) > 1 and isinstance(self[0], Blur) and isinstance(self[1], EqualConv2d) and input.is_cuda and input.dtype == torch.float32
-                and not torch.is_grad_enabled() and _fused_conv_enabled() and os.environ.get("HAVATAR_CONV_S2", "1") != "0"):
+                and not torch.is_grad_enabled() and _fused_conv_enabled() and os.environ.get("HAVATAR_CONV_S2", "1") != "0"
+                and os.environ.get("HAVATAR_S2_INFER", "1") != "0"):
             # HIP inference, down-sampling layer: Blur (hav_upfirdn2d) -> EqualConv2d stride 2 + bias + leaky-ReLU as one kernel
             # (hav_conv3x3s2_split) instead of MIOpen's Im2d2Col + fp32 GEMM + the activation launch: 78.6 against 110.8 us on the
             # encoders' 256 -> 512 layer, 49.5 against 69.1 us on the 512 -> 512 one, blur included (tools/bench_s2.py,
@@ -284,7 +285,7 @@ class ConvLayer(nn.Sequential):
             return self[2](out) if len(self) > 2 else out
         if (len(self) > 1 and isinstance(self[0], Blur) and isinstance(self[1], EqualConv2d) and input.is_cuda and input.dtype == torch.float32
                 and torch.is_grad_enabled() and _fused_conv_enabled() and os.environ.get("HAVATAR_CONV_S2", "1") != "0"
-                and os.environ.get("HAVATAR_HIP_TRAIN", "1") != "0"):
+                and os.environ.get("HAVATAR_HIP_TRAIN", "1") != "0" and os.environ.get("HAVATAR_S2_TRAIN", "1") != "0"):
             # HIP training, down-sampling layer: the Blur (its own autograd op) -> EqualConv2d stride 2 + bias + leaky-ReLU as one autograd
             # node whose forward is hav_conv3x3s2_split (native/conv.py::_S2ConvBlock)
             ec, bl = self[1], self[0]

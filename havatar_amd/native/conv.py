@@ -37,6 +37,12 @@ def _absmax(t, st):
     return words
 
 
+def absmax(t):
+    """the HAV_ABSMAX_WORDS partial maxima of |t| on t's current stream (what `amax` / `g_amax` / `x_amax` arguments take)"""
+    with torch.cuda.device(t.device):
+        return _absmax(t.contiguous(), _stream(t.device))
+
+
 def eligible(x, weight, stride=1, padding=1):
     """weight [Cout,Cin,3,3]; x [B,Cin,H,W] float32 on a HIP device."""
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and weight.dim() == 4):
@@ -70,14 +76,15 @@ def pack_t(weight, wmul=1.0):
     return blob
 
 
-def conv3x3(x, packed, Cout, s=None, d=None, noise=None, noise_weight=None, bias=None, slope=0.2, gain=2 ** 0.5, act=True, autoscale=None):
+def conv3x3(x, packed, Cout, s=None, d=None, noise=None, noise_weight=None, bias=None, slope=0.2, gain=2 ** 0.5, act=True, autoscale=None, amax=None):
     """y = act(d * conv3x3(s * x, W) + noise_weight * noise + bias) * gain; see include/havatar.h for the exact order.
     autoscale (default on; HAVATAR_CONV_AUTOSCALE=0 turns the default off): s * x is brought into fp16's comfortable range by an
     exact power-of-two scale found on the device (hav_absmax: one pass over x; the kernel multiplies the maximum by max |s_b|) and
     undone in the epilogue -- gradients (1e-6) keep their low parts, activations and modulations of any size cannot overflow the
-    fp16 split.  ~1 % of a frame."""
+    fp16 split.  ~1 % of a frame.  amax: the words of absmax(x) when the caller already has them (the training nodes use an operand's
+    maxima for its forward, data-gradient and weight-gradient launches)."""
     if autoscale is None:
-        autoscale = _autoscale_default()
+        autoscale = _autoscale_default() or amax is not None
     x = x.contiguous()
     B, Cin, H, W = x.shape
     y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device)
@@ -94,7 +101,8 @@ def conv3x3(x, packed, Cout, s=None, d=None, noise=None, noise_weight=None, bias
     scratch = torch.empty(need, dtype=torch.uint8, device=x.device) if need else None
     with torch.cuda.device(x.device):
         st = _stream(x.device)
-        amax = _absmax(x, st) if autoscale else None
+        if amax is None:
+            amax = _absmax(x, st) if autoscale else None
         rc = L.hav_conv3x3_split(_p(y), _p(x), _p(packed), _p(s), _p(d), _p(noise), _p(noise_weight), _p(bias), float(slope),
                                  float(gain), int(bool(act)), nb, B, Cin, Cout, H, W, _p(scratch), _p(amax), st)
     _lib.check(rc, "hav_conv3x3_split")
@@ -151,7 +159,7 @@ def wgrad_eligible(g, x):
     return x.shape[0] == B and tuple(x.shape[2:]) == (H, W) and x.shape[1] % 32 == 0 and Cout % 64 == 0 and W % 16 == 0
 
 
-def wgrad3x3(g, x, xs=None, out_mul=1.0):
+def wgrad3x3(g, x, xs=None, out_mul=1.0, g_amax=None, x_amax=None):
     """gw [Cout,Cin,3,3] = out_mul * d/dW of conv2d(xs * x, W, stride 1, padding 1) given g = dL/dy (hav_conv3x3_wgrad_mod: split-fp16 MFMA,
     fp32-class; both operands under the power-of-two range control: g is gradient-sized, x whatever the activations are).  xs [B,Cin]:
     the modulation of a ModulatedConv2d (None: plain)."""
@@ -163,7 +171,8 @@ def wgrad3x3(g, x, xs=None, out_mul=1.0):
     scratch = torch.empty(int(L.hav_conv3x3_wgrad_scratch_bytes(B, Cin, Cout, H, W)), dtype=torch.uint8, device=g.device)
     with torch.cuda.device(g.device):
         st = _stream(g.device)
-        g_amax, x_amax = _absmax(g, st), _absmax(x, st)
+        g_amax = _absmax(g, st) if g_amax is None else g_amax
+        x_amax = _absmax(x, st) if x_amax is None else x_amax
         _lib.check(L.hav_conv3x3_wgrad_mod(_p(gw), _p(g), _p(x), _p(xs), float(out_mul), _p(scratch), _p(g_amax), _p(x_amax), B, Cin, Cout,
                                            H, W, st), "hav_conv3x3_wgrad_mod")
     return gw
@@ -240,15 +249,16 @@ class _FusedConvBlock(torch.autograd.Function):
     def forward(ctx, x, W, s, d, noise, nw, bias, scale, slope, gain, act):
         # (x and W arrive contiguous: fused_block() makes them so OUTSIDE the node -- a .contiguous() in here, where grad mode is off, would
         # save a detached copy of a channels-last / sliced input and cut the second-order graph of the create_graph branch below)
-        y = conv3x3(x, pack(W, scale), W.shape[0], s=s, d=d, noise=noise, noise_weight=nw, bias=bias, slope=slope, gain=gain, act=act)
-        ctx.save_for_backward(x, W, s, d, noise, nw, bias, y)
+        ax = absmax(x)          # one pass over x serves the forward and, in backward, the weight gradient
+        y = conv3x3(x, pack(W, scale), W.shape[0], s=s, d=d, noise=noise, noise_weight=nw, bias=bias, slope=slope, gain=gain, act=act, amax=ax)
+        ctx.save_for_backward(x, W, s, d, noise, nw, bias, y, ax)
         ctx.cfg = (float(scale), float(slope), float(gain), bool(act))
         return y
 
     @staticmethod
     def backward(ctx, g):
         from ..model.op import conv2d_gradfix
-        x, W, s, d, noise, nw, bias, y = ctx.saved_tensors
+        x, W, s, d, noise, nw, bias, y, ax = ctx.saved_tensors
         scale, slope, gain, act = ctx.cfg
         need = ctx.needs_input_grad
         B, Cout, H, Wd = y.shape
@@ -287,15 +297,17 @@ class _FusedConvBlock(torch.autograd.Function):
             _lib.check(L.hav_conv_block_bwd(_p(gc), _p(gd), _p(gb), _p(gnw), _p(sums), _p(g), _p(y), _p(d), _p(noise), _p(nw), _p(bias), slope, gain,
                                             int(act), nb, B, Cout, H * Wd, st), "hav_conv_block_bwd")
         gx = gs = None
+        want_w = need[1] and not conv2d_gradfix.weight_gradients_disabled
+        ag = absmax(gc) if (need[0] or (s is not None and need[2]) or want_w) else None          # one pass: data AND weight gradient
         if need[0] or (s is not None and need[2]):
-            gx = conv3x3(gc, pack_t(W, scale), Cin, act=False, autoscale=True)          # dL/d(s x): gradient-sized, see hav_absmax
+            gx = conv3x3(gc, pack_t(W, scale), Cin, act=False, amax=ag)          # dL/d(s x): gradient-sized, see hav_absmax
             if s is not None:
                 gs = torch.empty(B, Cin, dtype=torch.float32, device=dev)
                 with torch.cuda.device(dev):
                     _lib.check(L.hav_mod_input_bwd(_p(gx), _p(gs), _p(x), _p(s), B, Cin, H * Wd, _stream(dev)), "hav_mod_input_bwd")
         gW = None
-        if need[1] and not conv2d_gradfix.weight_gradients_disabled:
-            gW = wgrad3x3(gc, x, xs=s, out_mul=scale)
+        if want_w:
+            gW = wgrad3x3(gc, x, xs=s, out_mul=scale, g_amax=ag, x_amax=ax)
         if gnw is not None and nw.shape != gnw.shape:
             gnw = gnw.view(nw.shape)
         if gb is not None and bias.shape != gb.shape:
@@ -326,7 +338,19 @@ class _S2ConvBlock(torch.autograd.Function):
     def forward(ctx, x, W, bias, fir, scale, slope, gain, act, padding, fpad):
         from ..model.op.upfirdn2d import upfirdn2d as _ufd
         xb = _ufd(x, fir, pad=fpad) if fir is not None else x
-        y = conv3x3s2(xb, pack(W, scale), W.shape[0], padding, bias=bias, slope=slope, gain=gain, act=act)
+        if os.environ.get("HAVATAR_S2_TRAIN_FWD", "aten") != "kernel":
+            # Default: the forward convolution of the TRAINING node stays on ATen (MIOpen).  With hav_conv3x3s2_split here AND the
+            # up-sampling node (_UpConvBlock, whose backward runs the same kernel) in one captured optimisation step, the training CLI test
+            # produced a NaN loss in 16 of 122 runs -- only as a hipGraph replay, only in a second train.main() of the same process; 0 of 72
+            # with this forward on ATen, 0 of 52 without the up-sampling node, 0 of 24 eager (profiles/r04_flake_bisect.txt).
+            # Not root-caused; HAVATAR_S2_TRAIN_FWD=kernel selects the kernel (-0.3 ms per step).
+            y = torch.nn.functional.conv2d(xb, W * scale, stride=2, padding=padding)
+            if bias is not None:
+                y = y + bias.view(1, -1, 1, 1)
+            if act:
+                y = torch.nn.functional.leaky_relu(y, slope) * gain
+        else:
+            y = conv3x3s2(xb, pack(W, scale), W.shape[0], padding, bias=bias, slope=slope, gain=gain, act=act)
         ctx.save_for_backward(x, xb, W, bias, fir, y)          # (x itself is only read under create_graph; its producer keeps it alive anyway)
         ctx.cfg = (float(scale), float(slope), float(gain), bool(act), int(padding), tuple(fpad) if fpad is not None else None, tuple(x.shape))
         return y

@@ -652,13 +652,15 @@ def test_stride2_training_node_matches_fp64_autograd_first_and_second_order(B, C
     assert W.grad is not None
 
 
-@pytest.mark.parametrize("B,Cin,Cout,H,dgrad", [(2, 64, 128, 128, "1"), (1, 256, 256, 64, "1"), (2, 64, 128, 128, "0")])
-def test_stride2_training_node_with_its_blur_matches_fp64_autograd(B, Cin, Cout, H, dgrad, monkeypatch):
+@pytest.mark.parametrize("B,Cin,Cout,H,dgrad,fwd", [(2, 64, 128, 128, "1", "aten"), (1, 256, 256, 64, "1", "kernel"), (2, 64, 128, 128, "0", "kernel"),
+                                                    (2, 256, 512, 128, "1", "kernel")])
+def test_stride2_training_node_with_its_blur_matches_fp64_autograd(B, Cin, Cout, H, dgrad, fwd, monkeypatch):
     """The same node with the layer's Blur inside (how ConvLayer(downsample=True) calls it): the data gradient through blur + convolution
     runs as an up-sampling layer on hav_gemm_split + hav_upconv_finish (HAVATAR_S2_DGRAD=0: ATen + hav_upfirdn2d); first and second order
     against the fp64 statement."""
     from havatar_amd.native import conv
     monkeypatch.setenv("HAVATAR_S2_DGRAD", dgrad)
+    monkeypatch.setenv("HAVATAR_S2_TRAIN_FWD", fwd)          # (default "aten": see _S2ConvBlock.forward)
     g = torch.Generator(device=DEV).manual_seed(B + Cin + H + 1)
     r = lambda *sh: torch.randn(*sh, device=DEV, generator=g)
     x0, W0, b0, up = r(B, Cin, H, H), r(Cout, Cin, 3, 3), 0.2 * r(Cout), r(B, Cout, H // 2, H // 2)
