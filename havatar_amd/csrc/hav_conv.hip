@@ -737,6 +737,7 @@ __global__ void __launch_bounds__(S2_THREADS, 1) conv3x3s2_split_kernel(ConvS2Ar
                 acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh, acc[rr], 0, 0, 0);
 #endif
             }
+            asm volatile(CV_MFMA_PAD : "+v"(acc[0]), "+v"(acc[1]));
 #ifndef S2_ABL_NOSTASH
             if (cc + 1 < c_hi) stash(buf ^ 1, cc + 1, Sc);
 #endif

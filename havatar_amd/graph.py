@@ -57,12 +57,17 @@ class GraphedTrainStep:
     Trainer draws sample_pdf's stratified u on the device while capturing) and the optimiser must be `capturable`.  Run at least
     one eager step first (solver selection, lazy state); capturing itself executes nothing, so no step is spent on it."""
 
-    def __init__(self, step_fn, optimizer, example):
+    def __init__(self, step_fn, optimizer, example, stream=None):
+        # stream: capture on the stream the eager warm-up steps ran on.  The parameters' AccumulateGrad nodes are bound to the stream
+        # they were created on and can outlive an iteration; captured on another stream, the backward pass becomes a graph with side
+        # branches (PyTorch warns: "AccumulateGrad node's stream does not match ... may break CUDA graph capture"), and on this stack
+        # replays of such a graph were seen to run consecutive kernels of the main chain out of order (DESIGN.md 7,
+        # profiles/r04_flake_bisect.txt): intermittent non-finite activations, gone with AMD_SERIALIZE_KERNEL=3 and with this.
         self.static = {k: v.clone() for k, v in example.items()}
         self.optimizer = optimizer
         optimizer.zero_grad(set_to_none=True)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+        with torch.cuda.graph(self.graph, stream=stream, capture_error_mode="thread_local"):
             self.loss, self.aux = step_fn(**self.static)
             self.loss.backward()
             optimizer.step()

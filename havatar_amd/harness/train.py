@@ -149,8 +149,15 @@ class StepRunner:
         if self.graph and self.eager_left <= 0 and (self.graphed is None or self.graphed.matches(dict(tens, target=target, ray_mask=ray_mask))):
             from ..graph import GraphedTrainStep
             if self.graphed is None:
+                from ..native import conv as _nconv
+                if _nconv._NAN_TRACE is not None:
+                    _nconv._NAN_TRACE.clear()          # (development aid: keep the flags of the captured step only)
+                if self.side is None:
+                    self.side = torch.cuda.Stream(device=dev)
+                self.side.wait_stream(torch.cuda.current_stream(dev))
                 self.graphed = GraphedTrainStep(lambda target, ray_mask, **kw: self._loss(target, ray_mask, **kw), self.optimizer,
-                                                dict(tens, target=target, ray_mask=ray_mask))
+                                                dict(tens, target=target, ray_mask=ray_mask), stream=self.side)
+                torch.cuda.current_stream(dev).wait_stream(self.side)
             loss, aux = self.graphed(**tens, target=target, ray_mask=ray_mask)
             parts = {k: v for k, v in aux.items() if k != "_mse"}
             return loss, parts, mse2psnr(aux["_mse"].item())
@@ -283,6 +290,12 @@ def main(argv=None, device=None):
             i += 1
             inp, target, ray_mask = step_inputs(idx, batch, device)
             loss, parts, psnr = run_step(inp, target, ray_mask)
+            if os.environ.get("HAVATAR_NAN_TRACE"):
+                from ..native import conv as _nconv
+                bad = [(k, n) for k, (n, f) in enumerate(_nconv._NAN_TRACE or []) if not bool(f)]
+                if bad:
+                    print("[nan-trace] iter %d (loss %s): %d traced tensors, %d non-finite; first (index, name): %s" % (
+                        i, float(loss), len(_nconv._NAN_TRACE or []), len(bad), bad[:8]))
             lr_new = learning_rate(cfg, i)
             set_learning_rate(optimizer, lr_new)
             if i % cfg.experiment.print_every == 0 or i == cfg.experiment.train_iters - 1:

@@ -30,6 +30,17 @@ def _autoscale_default():
     return os.environ.get("HAVATAR_CONV_AUTOSCALE", "1") != "0"
 
 
+_NAN_TRACE = [] if os.environ.get("HAVATAR_NAN_TRACE") else None          # development aid (tools/flake_hunt.sh): is-finite flags per tensor,
+                                                                           # evaluated INSIDE a captured step at every replay
+
+
+def _trace(name, *ts):
+    if _NAN_TRACE is not None:
+        for k, t in enumerate(ts):
+            if t is not None:
+                _NAN_TRACE.append(("%s[%d]%s" % (name, k, tuple(t.shape)), torch.isfinite(t if t.is_floating_point() else t.view(torch.float32)).all()))
+
+
 def _absmax(t, st):
     """HAV_ABSMAX_WORDS partial maxima of |t| (hav_absmax: one pass, no host round trip) for the kernels' power-of-two range control"""
     words = torch.empty(256, dtype=torch.int32, device=t.device)
@@ -106,6 +117,7 @@ def conv3x3(x, packed, Cout, s=None, d=None, noise=None, noise_weight=None, bias
         rc = L.hav_conv3x3_split(_p(y), _p(x), _p(packed), _p(s), _p(d), _p(noise), _p(noise_weight), _p(bias), float(slope),
                                  float(gain), int(bool(act)), nb, B, Cin, Cout, H, W, _p(scratch), _p(amax), st)
     _lib.check(rc, "hav_conv3x3_split")
+    _trace("conv3x3 x,amax,y", x, amax, y)
     return y
 
 
@@ -149,6 +161,7 @@ def conv3x3s2(x, packed, Cout, padding=0, s=None, d=None, noise=None, noise_weig
         rc = L.hav_conv3x3s2_split(_p(y), _p(x), _p(packed), _p(s), _p(d), _p(noise), _p(noise_weight), _p(bias), float(slope), float(gain),
                                    int(bool(act)), nb, B, Cin, Cout, H, W, int(padding), _p(scratch), _p(amax), st)
     _lib.check(rc, "hav_conv3x3s2_split")
+    _trace("conv3x3s2 x,amax,y", x, amax, y)
     return y
 
 
@@ -312,6 +325,7 @@ class _FusedConvBlock(torch.autograd.Function):
             gnw = gnw.view(nw.shape)
         if gb is not None and bias.shape != gb.shape:
             gb = gb.view(bias.shape)
+        _trace("FusedConvBlock.bwd g,gc,gx,gs,gW,gd,gnw,gb", g, gc, gx, gs, gW, gd, gnw, gb)
         return (gx if need[0] else None), gW, (gs if need[2] else None), gd, None, gnw, gb, None, None, None, None
 
 
@@ -338,12 +352,7 @@ class _S2ConvBlock(torch.autograd.Function):
     def forward(ctx, x, W, bias, fir, scale, slope, gain, act, padding, fpad):
         from ..model.op.upfirdn2d import upfirdn2d as _ufd
         xb = _ufd(x, fir, pad=fpad) if fir is not None else x
-        if os.environ.get("HAVATAR_S2_TRAIN_FWD", "aten") != "kernel":
-            # Default: the forward convolution of the TRAINING node stays on ATen (MIOpen).  With hav_conv3x3s2_split here AND the
-            # up-sampling node (_UpConvBlock, whose backward runs the same kernel) in one captured optimisation step, the training CLI test
-            # produced a NaN loss in 16 of 122 runs -- only as a hipGraph replay, only in a second train.main() of the same process; 0 of 72
-            # with this forward on ATen, 0 of 52 without the up-sampling node, 0 of 24 eager (profiles/r04_flake_bisect.txt).
-            # Not root-caused; HAVATAR_S2_TRAIN_FWD=kernel selects the kernel (-0.3 ms per step).
+        if os.environ.get("HAVATAR_S2_TRAIN_FWD", "kernel") == "aten":          # (A/B switch: the forward on ATen / MIOpen)
             y = torch.nn.functional.conv2d(xb, W * scale, stride=2, padding=padding)
             if bias is not None:
                 y = y + bias.view(1, -1, 1, 1)
@@ -413,6 +422,7 @@ class _S2ConvBlock(torch.autograd.Function):
             gW = gW * scale
         if gb is not None and bias.shape != gb.shape:
             gb = gb.view(bias.shape)
+        _trace("S2ConvBlock.bwd g,gc,gx,gW,gb", g, gc, gx, gW, gb)
         return gx, gW, gb, None, None, None, None, None, None, None
 
 
@@ -475,6 +485,7 @@ def upconv3x3(x, packed, Cout, fir, s=None, d=None, noise=None, noise_weight=Non
         _lib.check(L.hav_gemm_split(_p(col), _p(x), _p(packed), _p(s), _p(amax), B, Cout * 9, Cin, H * W, st), "hav_gemm_split")
         _lib.check(L.hav_upconv_finish(_p(y), _p(col), _p(fir), _p(d), _p(noise), _p(noise_weight), _p(bias), float(slope), float(gain),
                                        int(bool(act)), nb, B, Cout, H, W, st), "hav_upconv_finish")
+    _trace("upconv3x3 x,col,y", x, col, y)
     return y
 
 
@@ -569,6 +580,7 @@ class _UpConvBlock(torch.autograd.Function):
             gnw = gnw.view(nw.shape)
         if gb is not None and bias.shape != gb.shape:
             gb = gb.view(bias.shape)
+        _trace("UpConvBlock.bwd g,gc,gv,gx,gs,gW,gd,gnw,gb", g, gc, gv if (need[0] or want_w or (s is not None and need[2])) else None, gx, gs, gW, gd, gnw, gb)
         return (gx if need[0] else None), gW, (gs if need[2] else None), gd, None, gnw, gb, None, None, None, None, None
 
 
