@@ -156,7 +156,8 @@ class StepRunner:
                     self.side = torch.cuda.Stream(device=dev)
                 self.side.wait_stream(torch.cuda.current_stream(dev))
                 self.graphed = GraphedTrainStep(lambda target, ray_mask, **kw: self._loss(target, ray_mask, **kw), self.optimizer,
-                                                dict(tens, target=target, ray_mask=ray_mask), stream=self.side)
+                                                dict(tens, target=target, ray_mask=ray_mask),
+                                                stream=None if os.environ.get("HAVATAR_GRAPH_CAPTURE_STREAM") == "own" else self.side)          # ("own": the old, forking capture; A/B only)
                 torch.cuda.current_stream(dev).wait_stream(self.side)
             loss, aux = self.graphed(**tens, target=target, ray_mask=ray_mask)
             parts = {k: v for k, v in aux.items() if k != "_mse"}
