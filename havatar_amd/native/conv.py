@@ -490,11 +490,14 @@ def upconv3x3(x, packed, Cout, fir, s=None, d=None, noise=None, noise_weight=Non
 
 
 def upconv_block_eligible(x, weight):
-    """x [B,Cin,H,W], weight [Cout,Cin,3,3]: shapes for which the forward (hav_gemm_split + hav_upconv_finish) AND the data gradient
-    (a stride-2 3x3 convolution of the blurred output gradient with Cin and Cout in swapped roles: hav_conv3x3s2_split) of
-    upconv_block run on this library's kernels."""
-    if not upconv_eligible(x, weight) or os.environ.get("HAVATAR_FUSED_UPBLOCK", "1") == "0":
-        return False
+    """x [B,Cin,H,W], weight [Cout,Cin,3,3]: shapes whose forward (hav_gemm_split + hav_upconv_finish) runs on this library's kernels; the
+    data gradient does too where _upconv_dgrad_on_s2 says so."""
+    return upconv_eligible(x, weight) and os.environ.get("HAVATAR_FUSED_UPBLOCK", "1") != "0"
+
+
+def _upconv_dgrad_on_s2(x, weight):
+    """can the data gradient of upconv_block(x, weight) run on hav_conv3x3s2_split?  (Its output is x-sized: 32-column tiles; the 16^2 -> 32^2
+    layer of the encoders takes ATen's transposed-convolution gradient instead.)"""
     Cout, Cin = weight.shape[:2]
     B, _, H, W = x.shape
     return Cout % 16 == 0 and Cin % 64 == 0 and H % 4 == 0 and W % 32 == 0 and Cout * (2 * H + 1) * (2 * W + 1) < 2 ** 31
@@ -567,7 +570,11 @@ class _UpConvBlock(torch.autograd.Function):
             gv = _ufd(gc, fir.flip(0, 1), pad=(2, 2))          # d loss / d conv_transpose2d output  [B,Cout,2H+1,2W+1]
             wt = W.transpose(0, 1).contiguous()                          # [Cin,Cout,3,3]: conv_transpose2d's weight = the data gradient's conv weight
             if need[0] or (s is not None and need[2]):
-                gx = conv3x3s2(gv, pack(wt, scale), Cin, 0, act=False, autoscale=True)          # dL/d(s x): gradient-sized, see hav_absmax
+                if _upconv_dgrad_on_s2(x, W):
+                    gx = conv3x3s2(gv, pack(wt, scale), Cin, 0, act=False, autoscale=True)          # dL/d(s x): gradient-sized, see hav_absmax
+                else:
+                    gx, _, _ = torch.ops.aten.convolution_backward(gv, x, wt * scale, None, [2, 2], [0, 0], [1, 1], True, [0, 0], 1, [True, False, False])
+                    gx = gx.contiguous()
                 if s is not None:
                     gs = torch.empty(B, Cin, dtype=torch.float32, device=dev)
                     with torch.cuda.device(dev):

@@ -716,7 +716,8 @@ def test_downsampling_convlayer_training_takes_the_stride2_node():
         assert (a - b).abs().max().item() <= 2e-4 * b.abs().max().item()
 
 
-@pytest.mark.parametrize("B,Cin,Cout,H,W,modulated", [(2, 64, 32, 32, 32, True), (1, 128, 64, 16, 64, True), (2, 64, 64, 32, 32, False)])
+@pytest.mark.parametrize("B,Cin,Cout,H,W,modulated", [(2, 64, 32, 32, 32, True), (1, 128, 64, 16, 64, True), (2, 64, 64, 32, 32, False),
+                                                      (2, 128, 128, 16, 16, True)])          # (16 wide: the data gradient falls back to ATen)
 def test_upsampling_block_training_node_matches_fp64_autograd_first_and_second_order(B, Cin, Cout, H, W, modulated):
     """_UpConvBlock (an up-sampling StyledConv under autograd: forward hav_gemm_split + hav_upconv_finish; backward hav_conv_block_bwd ->
     the blur's adjoint -> the data gradient as a stride-2 convolution on hav_conv3x3s2_split -> hav_mod_input_bwd, weight gradient on
