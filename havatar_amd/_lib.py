@@ -9,8 +9,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libhavatar_hip.so")
 
 HAV_F32, HAV_F16, HAV_BF16, HAV_F64 = 0, 1, 2, 3
-HAV_MLP_SPLIT_BF16, HAV_MLP_F32, HAV_MLP_SPLIT_F16 = 0, 1, 2
-ABI_VERSION = 4
+HAV_MLP_SPLIT_BF16, HAV_MLP_F32, HAV_MLP_SPLIT_F16, HAV_MLP_SPLIT_F16_MX = 0, 1, 2, 3
+ABI_VERSION = 5
 HAV_FLAG_PAIR_KERNEL, HAV_FLAG_FINE_CACHE, HAV_FLAG_FINE_RECOMPUTE, HAV_FLAG_NO_FP16_GUARD = 1, 2, 4, 8
 HAV_STATUS_FP16_FALLBACK = 1
 
@@ -142,6 +142,8 @@ def lib():
     L.hav_mod_input_bwd.restype = i32
     L.hav_absmax.argtypes = [vp, vp, i64, vp]
     L.hav_absmax.restype = i32
+    L.hav_debug_nonfinite.argtypes = [vp, vp, i64, vp]
+    L.hav_debug_nonfinite.restype = i32
     L.hav_conv3x3_split.restype = i32
     L.hav_upsample3d_2x_fwd.argtypes = [vp, vp, i64, i32, i32, i32, vp]
     L.hav_upsample3d_2x_fwd.restype = i32
@@ -170,6 +172,8 @@ def lib():
     L.hav_render_variant_name.restype = i32
     L.hav_gen_rays.argtypes = [vp, i32, i32, C.POINTER(f32), C.POINTER(f32), f32, f32, i32, i32, vp]
     L.hav_gen_rays.restype = i32
+    L.hav_debug_mlp_layer.argtypes = [vp, vp, vp, i32, i32, i64, vp]
+    L.hav_debug_mlp_layer.restype = i32
     _lib = L
     return L
 

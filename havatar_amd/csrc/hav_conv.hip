@@ -521,6 +521,25 @@ extern "C" int hav_absmax(void* out_bits, const float* x, int64_t n, void* strea
     return 0;
 }
 
+// is-finite probe of the graphed training step's tracer (include/havatar.h: hav_debug_nonfinite): exponent field all ones = Inf / NaN
+__global__ void __launch_bounds__(256) nonfinite_kernel(unsigned int* __restrict__ flag, const unsigned int* __restrict__ x, int64_t n)
+{
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) bad |= ((x[i] >> 23) & 0xFFu) == 0xFFu;
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
+extern "C" int hav_debug_nonfinite(void* flag, const void* x, int64_t n, void* stream)
+{
+    if (!flag || !x || n < 0) return HAV_EINVAL;
+    if (n == 0) return 0;
+    const int64_t need = (n + 255) / 256;
+    hipLaunchKernelGGL(nonfinite_kernel, dim3((unsigned)(need < 1024 ? need : 1024)), dim3(256), 0, (hipStream_t)stream, (unsigned int*)flag,
+                       (const unsigned int*)x, n);
+    HAV_LAUNCH_CHECK();
+    return 0;
+}
+
 // K-split epilogue: y = act(d * (sum of the slices, in slice order) + nw * noise + bias) * gain
 __global__ void __launch_bounds__(256) conv3x3_finish_kernel(ConvArgs a, int64_t total)
 {

@@ -80,20 +80,25 @@
 #define OFF_A2H (OFF_A1H + 3 * 4 * 2 * 64 * 4)      // [8 chunks][4][2][64][4 dwords]
 #define OFF_W4H (OFF_A2H + 8 * 4 * 2 * 64 * 4)      // copy of W4: [A1H | A2H | W4H] is one contiguous LDS image
 #define OFF_AFH (OFF_W4H + K2_STEPS * 2 * 4)        // [8 chunks][2 row tiles][2][64][4 dwords]  fc_rgbFeat, same k order as layer 2
-#ifndef HAV_TAPPAIR
-#define HAV_TAPPAIR 1
-#endif
-#ifndef HAV_TG1
-#define HAV_TG1 2         // ... of plane 1 (z,y)
-#endif
-#ifndef HAV_TG
-#define HAV_TG 2          // log2 of the texel group of the prepared-plane layout (4 x-adjacent texels)
-#endif
+#define HAV_TAPPAIR 1      // the two x-adjacent taps of a row are loaded interleaved, piece by piece
+#define HAV_TG 2           // log2 of the texel group of the prepared-plane layout (4 x-adjacent texels) of plane 0 (x,y) ...
+#define HAV_TG1 2          // ... and of plane 1 (z,y)
 #define LDSH_FLOATS (3 * 4 * 2 * 64 * 4 + 8 * 4 * 2 * 64 * 4 + K2_STEPS * 2 * 4 + 8 * 2 * 2 * 64 * 4)    // 31232 dwords = 122 KB
 // fp16 range guard (include/havatar.h, HAV_MLP_SPLIT_F16): [128] |b1_u| + sum_k |W1pe_uk| per hidden unit, in the accumulator
 // order hu of the prepared planes | [1] max |w| over every weight the fp16 mode converts (inf if one is not finite) | pad
 #define OFF_RNG (OFF_AFH + 8 * 2 * 2 * 64 * 4)
-#define BLOB_FLOATS (OFF_RNG + 132)
+// "fp16 x 2 + MX" mode (HAV_MLP_SPLIT_F16_MX, PREC 3): the fp16 hi / lo fragments above ([A1H | A2H | W4H]) evaluate the three leading partial
+// products of every fp32 product; what they leave out -- lo.lo, hi.tail, tail.hi, all of order 2^-22 of the product -- comes from ONE
+// block-scaled 4- / 6-bit matrix instruction per term and 64 k (v_mfma_scale_f32_32x32x64_f8f6f4).  Per (k group of 4 chunks = 32 slots per
+// lane, row tile) one record of MX_G_DWORDS: AH4 [64 lanes][4 dwords] fp4(e2m1) of the weights' hi parts | AT4 [64][4] fp4 of their tails
+// w - hi - lo | AL6 [64][4] + [64][2] fp6(e2m3) of their lo parts | SC [64] E8M0 block scales, bytes (hi, tail, lo, 0).  Slot s = 8 c + e of a
+// lane is element e of chunk c of the group in the fp16 fragments' k order; layer 1 has one group of 3 chunks (slots 24-31 are zero).
+#define MX_G_DWORDS 960
+#define MX_GROUPS 12                                  // layer 1: row tiles 0-3 | layer 2: k group 0, row tiles 0-3 | k group 1, row tiles 0-3
+#define OFF_MX (OFF_RNG + 132)
+#define LDSX_FP16 (OFF_AFH - OFF_A1H)                // 23040 dwords: [A1H | A2H | W4H]
+#define LDSX_FLOATS (LDSX_FP16 + MX_GROUPS * MX_G_DWORDS)      // 34560 dwords = 135 KB
+#define BLOB_FLOATS (OFF_MX + MX_GROUPS * MX_G_DWORDS)
 #define HAV_FP16_LIMIT 60000.0f
 
 extern "C" int64_t hav_mlp_blob_bytes(void) { return (int64_t)BLOB_FLOATS * 4; }
@@ -104,7 +109,7 @@ __host__ __device__ inline int acc_row(int mp, int r, int h) { return 32 * mp + 
 __global__ void __launch_bounds__(256) mlp_pack_kernel(float* __restrict__ blob, HavMlpWeights w)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= BLOB_FLOATS) return;
+    if (e >= OFF_MX) return;                // (the MX records behind it are written by mlp_pack_mx_kernel)
     float v = 0.f;
     if (e < OFF_W2) {                   // PE column consumed by half-wave h at k-step t: 128 + 24h + t
         const int l = e & 63, m = (e >> 6) & 3, t = e >> 8;
@@ -245,6 +250,81 @@ __global__ void __launch_bounds__(256) mlp_wmax_kernel(float* __restrict__ blob,
     if (threadIdx.x == 0) blob[OFF_RNG + 128] = red[0];
 }
 
+// OCP MX element formats (no Inf / NaN encodings): round to nearest even, saturating.  EB / MB exponent / mantissa bits, BIAS.
+template <int EB, int MB, int BIAS>
+__device__ unsigned int mx_quant(float v)
+{
+    const unsigned int sign = v < 0.f ? 1u : 0u;
+    const float a = fabsf(v);
+    if (!(a > 0.f)) return sign << (EB + MB);
+    constexpr int emin = 1 - BIAS, emax = (1 << EB) - 1 - BIAS;
+    int e;
+    (void)frexpf(a, &e);
+    e -= 1;                                  // a = 1.x * 2^e
+    if (e < emin) e = emin;                  // the subnormal grid has the spacing of the smallest normal binade
+    const float ulp = ldexpf(1.0f, e - MB);
+    float q = rintf(a / ulp) * ulp;          // (both scalings are exact; rintf rounds half to even)
+    const float maxv = ldexpf((float)((2 << MB) - 1), emax - MB);
+    if (q > maxv) q = maxv;
+    unsigned int ef, m;
+    if (q < ldexpf(1.0f, emin)) { ef = 0u; m = (unsigned int)(q / ldexpf(1.0f, emin - MB)); }
+    else {
+        int e2;
+        (void)frexpf(q, &e2);
+        e2 -= 1;
+        ef = (unsigned int)(e2 + BIAS);
+        m = (unsigned int)(q / ldexpf(1.0f, e2 - MB)) - (1u << MB);
+    }
+    return (sign << (EB + MB)) | (ef << MB) | m;
+}
+// block exponent: the smallest s with maxabs / 2^s <= top (the format's largest value); E8M0 byte = s + 127
+__device__ int mx_block_exp(float maxabs, float top)
+{
+    if (!(maxabs > 0.f)) return -126;
+    int k;
+    const float f = frexpf(maxabs / top, &k);          // maxabs / top = f * 2^k, f in [0.5, 1)
+    int s = (f == 0.5f) ? k - 1 : k;
+    return s < -126 ? -126 : (s > 127 ? 127 : s);
+}
+// One thread per (record, lane): the lane's 32 weights of the record's k group in fragment order, split exactly as the fp16 fragments are
+// (hi = rn16(w), lo = rn16(w - hi)), tail = w - hi - lo (exact), each kind quantised against its own block scale.
+__global__ void __launch_bounds__(64) mlp_pack_mx_kernel(float* __restrict__ blob, HavMlpWeights w)
+{
+    const int G = blockIdx.x, l = threadIdx.x;
+    const int m = G & 3, hh = l >> 5, row = 32 * m + (l & 31);
+    const bool l2 = G >= 4;
+    const int g = l2 ? (G - 4) >> 2 : 0;
+    float hi[32], lo[32], tl[32];
+    float mh = 0.f, ml = 0.f, mt = 0.f;
+    for (int sl = 0; sl < 32; ++sl) {
+        const int c = sl >> 3, el = sl & 7;
+        float wv = 0.f;
+        if (l2) { const int ch = 4 * g + c; wv = w.W2[row * HAV_HID + acc_row(ch >> 1, 8 * (ch & 1) + el, hh)]; }
+        else if (c < 3) wv = w.W1[row * HAV_IN + 2 * HAV_PC + 24 * hh + 8 * c + el];
+        const float h_ = __half2float(__float2half_rn(wv));
+        const float r_ = wv - h_;
+        const float l_ = __half2float(__float2half_rn(r_));
+        hi[sl] = h_; lo[sl] = l_; tl[sl] = r_ - l_;
+        if (!(fabsf(wv) < HAV_FP16_LIMIT)) { hi[sl] = lo[sl] = tl[sl] = 0.f; }          // (out of the fp16 range: the range guard hands the call to the bf16 kernel)
+        mh = fmaxf(mh, fabsf(hi[sl])); ml = fmaxf(ml, fabsf(lo[sl])); mt = fmaxf(mt, fabsf(tl[sl]));
+    }
+    const int sh = mx_block_exp(mh, 6.0f), st = mx_block_exp(mt, 6.0f), sl_ = mx_block_exp(ml, 7.5f);
+    unsigned int ah[4] = {0, 0, 0, 0}, at[4] = {0, 0, 0, 0}, al[6] = {0, 0, 0, 0, 0, 0};
+    for (int sl = 0; sl < 32; ++sl) {
+        const unsigned int qh = mx_quant<2, 1, 1>(ldexpf(hi[sl], -sh)), qt = mx_quant<2, 1, 1>(ldexpf(tl[sl], -st));
+        const unsigned int ql = mx_quant<2, 3, 1>(ldexpf(lo[sl], -sl_));
+        ah[sl >> 3] |= qh << (4 * (sl & 7));
+        at[sl >> 3] |= qt << (4 * (sl & 7));
+        const int bit = 6 * sl, d = bit >> 5, o = bit & 31;
+        al[d] |= ql << o;
+        if (o + 6 > 32) al[d + 1] |= ql >> (32 - o);
+    }
+    unsigned int* rec = reinterpret_cast<unsigned int*>(blob) + OFF_MX + G * MX_G_DWORDS;
+    for (int d = 0; d < 4; ++d) { rec[l * 4 + d] = ah[d]; rec[256 + l * 4 + d] = at[d]; rec[512 + l * 4 + d] = al[d]; }
+    rec[768 + l * 2 + 0] = al[4]; rec[768 + l * 2 + 1] = al[5];
+    rec[896 + l] = (unsigned int)(sh + 127) | ((unsigned int)(st + 127) << 8) | ((unsigned int)(sl_ + 127) << 16);
+}
+
 extern "C" int hav_mlp_pack(void* blob, const HavMlpWeights* w, void* stream)
 {
     if (!blob || !w || !w->W1 || !w->b1 || !w->W2 || !w->b2 || !w->Wa || !w->ba || !w->Wf || !w->bf || !w->Wc || !w->bc)
@@ -252,6 +332,8 @@ extern "C" int hav_mlp_pack(void* blob, const HavMlpWeights* w, void* stream)
     hipLaunchKernelGGL(mlp_pack_kernel, dim3((BLOB_FLOATS + 255) / 256), dim3(256), 0, (hipStream_t)stream, (float*)blob, *w);
     HAV_LAUNCH_CHECK();
     hipLaunchKernelGGL(mlp_wmax_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (float*)blob, *w);
+    HAV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mlp_pack_mx_kernel, dim3(MX_GROUPS), dim3(64), 0, (hipStream_t)stream, (float*)blob, *w);
     HAV_LAUNCH_CHECK();
     return 0;
 }
@@ -438,38 +520,12 @@ __device__ __forceinline__ float row16_scan_mul(float v)
     return v;
 }
 __device__ __forceinline__ float read_lane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
-// value of the partner lane in the other half-wave (lane ^ 32): ds_bpermute_b32 (__shfl_xor).  gfx950 also has a VALU instruction for it,
-// v_permlane32_swap_b32 (measured, tools/ubench/permlane32.hip: lanes 32-63 of the first operand <-> lanes 0-31 of the second), which
-// would take the exchange off the LDS pipe -- but with ROCm 7.2 it is NOT usable here: results are right on small runs and differ
-// from launch to launch on a full frame (8 % of the launches of a 512^2 frame, lanes 16-31 of a tile; explicit s_nop 7 / 15 on both
-// sides of the instruction change the rate, they do not remove it: profiles/r03_stress_root_cause.txt).  HAV_HALF_SWAP_PERMLANE=1|2
-// keeps the experiment reproducible.
-#ifndef HAV_HALF_SWAP_PERMLANE
-#define HAV_HALF_SWAP_PERMLANE 0
-#endif
-// 1: the two bone-weight quotients of sample_eval as one v_rcp_f32 + a Newton step (<= 1 ulp from the IEEE quotient).  0 = the compiler's
-// IEEE expansion (v_div_scale / v_div_fmas / v_div_fixup, two of them interleaved, VCC and SGPR-pair traffic in between): with ROCm 7.2 on
-// gfx950 that sequence is where the rare run-to-run difference of DESIGN.md 3.12 comes from -- identical inputs, a different warped point
-// in lanes 48-63 of one tile; on a box where the IEEE form differed in 22 % of the launches of a 512^2 frame this form gave 0 of 14 000.
-#ifndef HAV_FAST_DIV
-#define HAV_FAST_DIV 1
-#endif
+// value of the partner lane in the other half-wave (lane ^ 32): ds_bpermute_b32 (__shfl_xor).  gfx950's VALU instruction for it,
+// v_permlane32_swap_b32, is NOT usable here with ROCm 7.2: results are right on small runs and differ from launch to launch on a full
+// frame (8 % of the launches of a 512^2 frame; docs/history/DESIGN_r1-r4.md 3.12, tools/ubench/permlane32.hip).
 __device__ __forceinline__ float half_swap(float v, int h)
 {
-#if HAV_HALF_SWAP_PERMLANE
-    const unsigned int u = __float_as_uint(v);
-    // measured (tools/ubench/permlane32.hip): the instruction swaps lanes 32-63 of its first operand with lanes 0-31 of its second
-#if HAV_HALF_SWAP_PERMLANE == 2          // experiment: the instruction from inline asm with explicit wait states on both sides
-    unsigned int x = u, y = u;
-    asm volatile("s_nop 7\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 7" : "+v"(x), "+v"(y));
-    return __uint_as_float(h ? x : y);
-#else
-    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);          // r[0]: lanes 32-63 = v[0-31];  r[1]: lanes 0-31 = v[32-63]
-    return __uint_as_float(h ? r[0] : r[1]);
-#endif
-#else
     return __shfl_xor(v, 32, 64);
-#endif
 }
 // sigmoid with the reciprocal instruction (1 ulp) instead of the compiler's IEEE division sequence -- three of those interleaved per
 // sample is the pattern DESIGN.md 3.12 is about; rcp(inf) = 0 covers exp overflow (no Newton step: inf * 0 would poison it)
@@ -632,41 +688,11 @@ struct LaneCtx {
     const float* sW1; const float* sW2; const float4* sW4;
     const uint4* sA1; const uint4* sA2;         // split-bf16 fragments (PREC == 1 kernels)
     const uint4* sAF;                           // fc_rgbFeat fragments (fp16 split; feature parking, PREC == 2)
+    const unsigned int* sMX;                    // MX correction records (PREC == 3): layer 1 at 0, layer 2 at 4 * MX_G_DWORDS
     const float4* sB;                           // LDS copy of b1 | b2 (block kernel; the pair kernel reads them through the buffer path)
     __amdgpu_buffer_rsrc_t wrs;
     int lane, h, hoff;
-    int* lock;                                  // LDS word shared by the two waves of this wave's SIMD (mfma_lock); nullptr: no turn-taking
 };
-#ifndef HAV_MFMA_LOCK
-#define HAV_MFMA_LOCK 0
-#endif
-// Optional turn-taking of the two waves of a SIMD around every matrix-core sequence (an LDS spin lock per SIMD, index = the hardware
-// SIMD id of HW_REG_HW_ID; waves w and w + 4 of a 512-thread workgroup share one: tools/ubench/simd_map.hip).  Built to test whether the
-// rare run-to-run differences of DESIGN.md 3.5 come from the two waves' MFMAs interleaving in the shared pipe: on one MI355X 6000
-// launches per production variant came out bit-identical with it against 14 differing launches without -- on two other boxes the
-// differences persisted with the lock.  1-2 % of kernel time; off by default (-DHAV_MFMA_LOCK=1 builds it in).
-__device__ __forceinline__ void mfma_lock(const LaneCtx& L)
-{
-#if HAV_MFMA_LOCK
-    if (!L.lock) return;                        // (the ray-pair kernel: fp32 MFMA only, one sequence at a time per SIMD by construction)
-    int got;
-    do {
-        got = 1;
-        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) got = atomicCAS(L.lock, 0, 1);
-        got = __builtin_amdgcn_readfirstlane(got);
-        if (got) __builtin_amdgcn_s_sleep(2);
-    } while (got);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#endif
-}
-__device__ __forceinline__ void mfma_unlock(const LaneCtx& L)
-{
-#if HAV_MFMA_LOCK
-    if (!L.lock) return;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) atomicExch(L.lock, 0);
-#endif
-}
 
 #define LDB4(off_floats) __builtin_amdgcn_raw_buffer_load_b128(L.wrs, h * 16, (off_floats) * 4, 0)
 
@@ -700,16 +726,10 @@ __device__ __forceinline__ void split3(float v0, float v1, uint32_t& ph, uint32_
 // requirement) and ties all four tiles to it.
 // (In the variants that also carry the composited-hidden-unit accumulators the in-place form costs more in spills than it
 // saves in moves: they keep the two-operand form, INPLACE = false.)
-#ifndef HAV_RELU_NOPS
 #define HAV_RELU_NOPS "s_nop 15\n\ts_nop 7"
-#endif
-#ifndef HAV_RELU_INPLACE
-#define HAV_RELU_INPLACE 1      // 0: the lean variants use the two-operand form too (experiment)
-#endif
-template <bool INPLACE_>
+template <bool INPLACE>
 __device__ __forceinline__ void relu_tiles(f32x16 (&acc)[4])
 {
-    constexpr bool INPLACE = INPLACE_ && HAV_RELU_INPLACE;
     if (!INPLACE) {
         asm volatile(HAV_RELU_NOPS : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
 #pragma unroll
@@ -739,43 +759,16 @@ __device__ __forceinline__ void relu_tiles(f32x16 (&acc)[4])
 // class.  The A fragments of group g+1 (one row tile of one chunk: 3 x ds_read_b128) are requested before the six MFMAs of
 // group g are issued (explicit register double buffer: under this kernel's register pressure the compiler otherwise
 // re-uses one buffer and every group waits out a full LDS round trip).
-// WAR hazard on gfx950 (found the hard way, ROCm 7.2): v_mfma_f32_32x32x16_bf16 keeps reading its 4-VGPR A/B operands after
-// issue (the second half of the output columns re-reads them), the compiler does not know, and happily lets the very next
-// VALU instruction recycle an operand register -- ~1 % of rays came out wrong, columns 16-31 of a tile, run to run.
-// KEEP() extends an operand's live range (no instruction is emitted) until the FOLLOWING MFMA has issued, i.e. >= 32 cycles.
-// The accumulator rides along as an in/out operand so that the (otherwise freely movable) empty asm stays between the two
-// MFMAs it separates: the compiler does reorder register-only MFMAs across a plain asm volatile.
-// HAV_MFMA_PADS (default 0).  Rounds 1-2 believed that v_mfma_f32_32x32x16_* keeps reading its A / B operands after issue (a run-to-run
-// difference in columns 16-31 of a tile) and padded the matrix sequences: operand keep-alives (KEEP), 32 wait states behind every group
-// (HARD) and a scheduling barrier per group.  Round 3 traced that difference to the IEEE division sequence of the skinning blend
-//  and measured the operands directly (tools/ubench/mfma_war.hip: an operand register overwritten by the very next
-// instruction, single and in dependent chains of three, two waves per SIMD: 0 of 10^10 results change).  The pads are off (-1.3 % kernel
-// time); HAV_MFMA_PADS=1 brings them back.
-#ifndef HAV_MFMA_PADS
-#define HAV_MFMA_PADS 0
-#endif
-#if HAV_MFMA_PADS
-#define KEEP(acc, x) asm volatile("" : "+v"(acc) : "v"(x))
-#else
-#define KEEP(acc, x) do { } while (0)
-#endif
-
-// HARD (see mfma_split2h below): wait the last MFMA of a k-chunk out before the splitting code of the next chunk may write registers.
-#ifndef HAV_MFMA_IL
-#define HAV_MFMA_IL 0     // 1: the interleaved, hand-placed sequences further down (parity-tested; measured neutral: DESIGN.md 3.13)
-#endif
+// (gfx950 does NOT read matrix operands after issue -- tools/ubench/mfma_war.hip: an operand register overwritten by the very next
+// instruction, 0 of 10^10 results change; rounds 1-2 believed otherwise and padded these sequences.  What is left of that period in this
+// routine -- 32 wait states behind a chunk's last group and a scheduling barrier per group -- is part of the binary that went through
+// the determinism stress runs (41 000 launches, docs/history/DESIGN_r1-r4.md 3.12) and is kept as it is.)
 template <int NCH, typename GetV>
-__device__ __forceinline__ void mfma_split3_il(f32x16 (&acc)[4], const uint4* frag, int lane, GetV getv);
-template <int NCH, bool HARD = true, typename GetV>
 __device__ __forceinline__ void mfma_split3(f32x16 (&acc)[4], const uint4* frag /* [NCH][4 m][3 parts][64 lanes] */, int lane, GetV getv)
 {
-#if HAV_MFMA_IL
-    mfma_split3_il<NCH>(acc, frag, lane, getv);
-    return;
-#endif
     uint4 A[2][3];
     uint4 bh, bm, bl;
-    bf16x8_t pa, pb;                  // operands of the previous group's last MFMA
+    bf16x8_t pa, pb;                  // operands of the previous group's last MFMA (tied to the wait states below)
     // (Do NOT launder `frag` through an empty asm to stop address hoisting: the pointer then loses its LDS address space and every
     // fragment read becomes a FLAT load -- +0.8 ms per frame, measured.)
 #pragma unroll
@@ -793,29 +786,24 @@ __device__ __forceinline__ void mfma_split3(f32x16 (&acc)[4], const uint4* frag 
         const bf16x8_t ah = __builtin_bit_cast(bf16x8_t, A[g & 1][0]), am = __builtin_bit_cast(bf16x8_t, A[g & 1][1]);
         const bf16x8_t al = __builtin_bit_cast(bf16x8_t, A[g & 1][2]);
         acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh, acc[m], 0, 0, 0);
-        if (g > 0) { KEEP(acc[m], pa); KEEP(acc[m], pb); }
         if (g + 1 < NCH * 4) {        // next group's fragments go into the buffer whose last reader (group g-1) is long done
 #pragma unroll
             for (int q = 0; q < 3; ++q) A[(g + 1) & 1][q] = frag[((g + 1) * 3 + q) * 64 + lane];
         }
         acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl, acc[m], 0, 0, 0);
-        KEEP(acc[m], al);
         acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, xm, acc[m], 0, 0, 0);
-        KEEP(acc[m], xl);
         acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, xh, acc[m], 0, 0, 0);
         acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xm, acc[m], 0, 0, 0);
-        KEEP(acc[m], am);
         acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh, acc[m], 0, 0, 0);
-        KEEP(acc[m], xm);
         pa = ah; pb = xh;
-        if (HARD && m == 3 && g + 1 < NCH * 4) asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[m]) : "v"(pa), "v"(pb));
+        if (m == 3 && g + 1 < NCH * 4) asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[m]) : "v"(pa), "v"(pb));
         __builtin_amdgcn_sched_barrier(0);
     }
     asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[3]) : "v"(pa), "v"(pb));      // the last MFMA's operands outlive it by 32 wait states
 }
 // Two-part fp16 variant: x = hi + lo with both parts rounded to nearest (representation error <= 2^-22 |x|, the order of the fp32
 // accumulation error of a 128-term dot product), three products (hi.lo, lo.hi, hi.hi) on v_mfma_f32_32x32x16_f16: half the
-// matrix time and two thirds of the LDS of the bf16 triple split.  Same operand keep-alive discipline as above.
+// matrix time and two thirds of the LDS of the bf16 triple split.
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void split2h(float v0, float v1, uint32_t& ph, uint32_t& pl)
 {
@@ -824,59 +812,19 @@ __device__ __forceinline__ void split2h(float v0, float v1, uint32_t& ph, uint32
     const f2 v = {v0, v1};
     const h2 hi = __builtin_convertvector(v, h2);
     ph = __builtin_bit_cast(uint32_t, hi);
-#ifndef HAV_NO_FMA_MIX
     // lo = fp16(v - (float)hi), the subtraction exact in fp32: the mixed-precision FMAs read the fp16 half directly and write the rounded
     // fp16 result into one half of the destination -- 3 instructions per operand pair instead of 5 (two cvt_f32_f16, pk_add, cvt_pk)
     uint32_t lo;
     asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(ph), "v"(v0));
     asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(ph), "v"(v1));
     pl = lo;
-#else
-    const f2 r = v - __builtin_convertvector(hi, f2);           // exact
-    const h2 lo = __builtin_convertvector(r, h2);
-    pl = __builtin_bit_cast(uint32_t, lo);
-#endif
 }
-// HARD: the keep-alives above pin VALUES, not physical registers: when the allocator has to spill or split the live range of an
-// operand between its MFMA and the KEEP (seen in the one instantiation that runs with 64 more live accumulators than the others:
-// the feature projection of a parked tile inside the kernels that also composite the coarse outputs, ~0.4 % of the rays of a
-// full frame wrong in columns 16-31, run to run), the register the MFMA is still reading is free again.  HARD waits the matrix
-// instruction out (32 cycles) before the vector code of the next k-chunk may touch anything.
-// reads of what the wave wrote itself (parked head values, weights).  1 = L1-bypassing (non-temporal) loads: round 2's guard against the
-// run-to-run difference that round 3 traced to something else; a wave's own stores are coherent with its CU's L1, so
-// plain cached loads are correct, and 2 % faster (6.12 vs 6.23 ms on the same box).
-#ifndef HAV_SELF_NT
-#define HAV_SELF_NT 0
-#endif
-#if HAV_SELF_NT
-#define HAV_SELF_LOAD(p) __builtin_nontemporal_load(p)
-#define HAV_SELF_LOAD4(p) nt_load4(p)
-#else
-#define HAV_SELF_LOAD(p) (*(p))
-#define HAV_SELF_LOAD4(p) (*(p))
-#endif
-#ifndef HAV_BLOCK_FENCE
-#define HAV_BLOCK_FENCE 0     // 1: drain + L1 invalidate at every block start (measured: -2.5 % speed, no robust effect on the rare event of DESIGN.md 3.5)
-#endif
-#ifndef HAV_HARD_NOPS
-#define HAV_HARD_NOPS "s_nop 15\n\ts_nop 15"
-#endif
 template <int NCH, int NM, typename GetV>
-__device__ __forceinline__ void mfma_split2h_il(f32x16 (&acc)[NM], const uint4* frag, int lane, GetV getv);
-template <int NCH, int NM, bool HARD = true, typename GetV>
 __device__ __forceinline__ void mfma_split2h(f32x16 (&acc)[NM], const uint4* frag /* [NCH][NM row tiles][2 parts][64 lanes] */, int lane, GetV getv)
 {
-#if HAV_MFMA_IL
-    mfma_split2h_il<NCH, NM>(acc, frag, lane, getv);
-    return;
-#endif
-#ifndef HAV_FRAG_DIST
-#define HAV_FRAG_DIST 1     // groups of MFMAs a fragment read runs ahead of its use (1: 64-96 cycles; 2 and 3 measured the same: the loops do not wait on the LDS)
-#endif
-    constexpr int FD = HAV_FRAG_DIST, NBUF = FD + 1, NG = NCH * NM;
+    constexpr int FD = 1, NBUF = FD + 1, NG = NCH * NM;      // FD: groups of MFMAs a fragment read runs ahead of its use (2 and 3 measured the same)
     uint4 A[NBUF][2];
     uint4 bh, bl;
-    f16x8_t pa, pb;
 #pragma unroll
     for (int d = 0; d < FD; ++d)
 #pragma unroll
@@ -894,210 +842,139 @@ __device__ __forceinline__ void mfma_split2h(f32x16 (&acc)[NM], const uint4* fra
         const f16x8_t xh = __builtin_bit_cast(f16x8_t, bh), xl = __builtin_bit_cast(f16x8_t, bl);
         const f16x8_t ah = __builtin_bit_cast(f16x8_t, A[g % NBUF][0]), al = __builtin_bit_cast(f16x8_t, A[g % NBUF][1]);
         acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh, acc[m], 0, 0, 0);
-        if (g > 0) { KEEP(acc[m], pa); KEEP(acc[m], pb); }
         if (g + FD < NG) {           // into the buffer whose last reader (group g - 1) is long done
 #pragma unroll
             for (int q = 0; q < 2; ++q) A[(g + FD) % NBUF][q] = frag[((g + FD) * 2 + q) * 64 + lane];
         }
         acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl, acc[m], 0, 0, 0);
-        KEEP(acc[m], al);
         acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh, acc[m], 0, 0, 0);
-        KEEP(acc[m], xl);
-        pa = ah; pb = xh;
-#if HAV_MFMA_PADS
-        if (HARD && m == NM - 1 && g + 1 < NCH * NM) asm volatile(HAV_HARD_NOPS : "+v"(acc[m]) : "v"(pa), "v"(pb));
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-    }
-#if HAV_MFMA_PADS
-    asm volatile(HAV_HARD_NOPS : "+v"(acc[NM - 1]) : "v"(pa), "v"(pb));
-#endif
-}
-#undef KEEP
-
-// ---- Interleaved, hand-placed matrix sequences (round 4; HAV_MFMA_IL, default 0: measured neutral under the power cap) ------------------------------------------------
-// What the compiler made of the two routines below (hipcc 7.2, -O3): it sinks every fragment read next to the MFMA that consumes it
-// (ds_read_b128 -> s_waitcnt lgkmcnt(0) -> v_mfma: a full LDS round trip per group, whatever prefetch distance the source spells out),
-// it puts the 12-36 VALU instructions of a chunk's operand split in FRONT of the chunk's first MFMA, and the three (six) products of
-// a group accumulate back to back into one register tuple.  The layer phases ran at about half the matrix pipe's pace.
-// Measured (tools/ubench/mfma_overlap2.hip, profiles/r04_ubench_overlap2.txt): plain VALU / LDS instructions issue in the shadow of a
-// matrix instruction -- up to ~6 per v_mfma_f32_32x32x16 at 1-2 cycles each, from the same wave; a partner wave's plain VALU stream runs
-// at 95 % of its solo pace beside a saturating MFMA stream -- and only PACKED fp32 VALU (v_pk_fma/mul/add_f32) excludes the matrix pipe.
-// (Rounds 1-3 concluded "VALU does not overlap with MFMA" from microbenchmarks whose C fillers hipcc had SLP-packed into v_pk_fma_f32.)
-// So: two row tiles per group, their products interleaved (consecutive MFMAs never share an accumulator); the fragments of group g+1
-// are read behind the first two MFMAs of group g; the NEXT chunk's operand split (non-packed instructions only) is dealt out over
-// the gaps of the current chunk; a scheduling barrier behind every slot pins the order.
-#define HAV_SB() __builtin_amdgcn_sched_barrier(0)
-template <int NCH, int NM, typename GetV>
-__device__ __forceinline__ void mfma_split2h_il(f32x16 (&acc)[NM], const uint4* frag /* [NCH][NM row tiles][2 parts][64 lanes] */, int lane, GetV getv)
-{
-    static_assert(NM % 2 == 0, "row tiles are processed in pairs");
-    constexpr int NP = NM / 2, NPG = NCH * NP;
-    uint4 A[2][4];                  // [ring slot][tile 0 hi, tile 0 lo, tile 1 hi, tile 1 lo]
-    uint4 bh[2], bl[2];             // B operand of chunk ch (slot ch & 1) and of the next one
-    auto load_pair = [&](uint4 (&dst)[4], int pg) {
-        const int base = ((pg / NP) * NM + 2 * (pg % NP)) * 2;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) dst[q] = frag[(base + q) * 64 + lane];
-    };
-    auto split_dword = [&](int ch, int q) {       // dword q of chunk ch's operand: 3 VALU instructions
-        float v[8];
-        getv(ch, v);
-        uint32_t ph, pl;
-        split2h(v[2 * q], v[2 * q + 1], ph, pl);
-        uint4& H = bh[ch & 1]; uint4& Lo = bl[ch & 1];
-        if (q == 0) { H.x = ph; Lo.x = pl; } else if (q == 1) { H.y = ph; Lo.y = pl; } else if (q == 2) { H.z = ph; Lo.z = pl; } else { H.w = ph; Lo.w = pl; }
-    };
-    load_pair(A[0], 0);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) split_dword(0, q);
-    HAV_SB();
-#pragma unroll
-    for (int pg = 0; pg < NPG; ++pg) {
-        const int ch = pg / NP, p = pg % NP, m0 = 2 * p, m1 = 2 * p + 1;
-        const f16x8_t xh = __builtin_bit_cast(f16x8_t, bh[ch & 1]), xl = __builtin_bit_cast(f16x8_t, bl[ch & 1]);
-        const f16x8_t ah0 = __builtin_bit_cast(f16x8_t, A[pg & 1][0]), al0 = __builtin_bit_cast(f16x8_t, A[pg & 1][1]);
-        const f16x8_t ah1 = __builtin_bit_cast(f16x8_t, A[pg & 1][2]), al1 = __builtin_bit_cast(f16x8_t, A[pg & 1][3]);
-        // the four split steps of the next chunk go into gaps 2..5 of this chunk's groups
-        auto next_split = [&](int slot) {         // slot 0..3 of this group
-            if (ch + 1 >= NCH) return;
-            if (NP == 1) split_dword(ch + 1, slot);
-            else if (NP == 2) { if (slot == 0 || slot == 2) split_dword(ch + 1, 2 * p + (slot >> 1)); }
-            else if (p < 4 && slot == 0) split_dword(ch + 1, p);
-        };
-        acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, xh, acc[m0], 0, 0, 0);
-        HAV_SB();
-        if (pg + 1 < NPG) {
-            const int base = (((pg + 1) / NP) * NM + 2 * ((pg + 1) % NP)) * 2;
-            A[(pg + 1) & 1][0] = frag[(base + 0) * 64 + lane];
-            A[(pg + 1) & 1][1] = frag[(base + 1) * 64 + lane];
-        }
-        HAV_SB();
-        acc[m1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, xh, acc[m1], 0, 0, 0);
-        HAV_SB();
-        if (pg + 1 < NPG) {
-            const int base = (((pg + 1) / NP) * NM + 2 * ((pg + 1) % NP)) * 2;
-            A[(pg + 1) & 1][2] = frag[(base + 2) * 64 + lane];
-            A[(pg + 1) & 1][3] = frag[(base + 3) * 64 + lane];
-        }
-        HAV_SB();
-        acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, xl, acc[m0], 0, 0, 0);
-        HAV_SB();
-        next_split(0);
-        HAV_SB();
-        acc[m1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, xl, acc[m1], 0, 0, 0);
-        HAV_SB();
-        next_split(1);
-        HAV_SB();
-        acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, xh, acc[m0], 0, 0, 0);
-        HAV_SB();
-        next_split(2);
-        HAV_SB();
-        acc[m1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, xh, acc[m1], 0, 0, 0);
-        HAV_SB();
-        next_split(3);
-        HAV_SB();
-    }
-}
-// the bf16 triple split without packed-fp32 instructions (they exclude the matrix pipe): v = hi + mid + lo exactly, 11 plain VALU per pair
-__device__ __forceinline__ void split3_a(float v0, float v1, uint32_t& ph, float& r0, float& r1)
-{
-    const uint32_t u0 = __float_as_uint(v0), u1 = __float_as_uint(v1);
-    ph = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
-    r0 = v0 - __uint_as_float(u0 & 0xFFFF0000u);
-    r1 = v1 - __uint_as_float(u1 & 0xFFFF0000u);
-}
-__device__ __forceinline__ void split3_b(float r0, float r1, uint32_t& pm, uint32_t& pl)
-{
-    const uint32_t a0 = __float_as_uint(r0), a1 = __float_as_uint(r1);
-    pm = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
-    const float q0 = r0 - __uint_as_float(a0 & 0xFFFF0000u), q1 = r1 - __uint_as_float(a1 & 0xFFFF0000u);
-    pl = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
-}
-template <int NCH, typename GetV>
-__device__ __forceinline__ void mfma_split3_il(f32x16 (&acc)[4], const uint4* frag /* [NCH][4 m][3 parts][64 lanes] */, int lane, GetV getv)
-{
-    constexpr int NM = 4, NP = 2, NPG = NCH * NP;
-    uint4 A[2][6];                  // [ring slot][tile 0 hi, mid, lo, tile 1 hi, mid, lo]
-    uint4 bh[2], bm[2], bl[2];
-    float rr[2];                    // residuals between the two halves of a split step
-    auto setw = [](uint4& t, int q, uint32_t w) { if (q == 0) t.x = w; else if (q == 1) t.y = w; else if (q == 2) t.z = w; else t.w = w; };
-    auto split_a = [&](int ch, int q) { float v[8]; getv(ch, v); uint32_t ph; split3_a(v[2 * q], v[2 * q + 1], ph, rr[0], rr[1]); setw(bh[ch & 1], q, ph); };
-    auto split_b = [&](int ch, int q) { uint32_t pm, pl; split3_b(rr[0], rr[1], pm, pl); setw(bm[ch & 1], q, pm); setw(bl[ch & 1], q, pl); };
-#pragma unroll
-    for (int q = 0; q < 6; ++q) A[0][q] = frag[q * 64 + lane];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { split_a(0, q); split_b(0, q); }
-    HAV_SB();
-#pragma unroll
-    for (int pg = 0; pg < NPG; ++pg) {
-        const int ch = pg / NP, p = pg % NP, m0 = 2 * p, m1 = 2 * p + 1;
-        const bf16x8_t xh = __builtin_bit_cast(bf16x8_t, bh[ch & 1]), xm = __builtin_bit_cast(bf16x8_t, bm[ch & 1]), xl = __builtin_bit_cast(bf16x8_t, bl[ch & 1]);
-        const bf16x8_t ah0 = __builtin_bit_cast(bf16x8_t, A[pg & 1][0]), am0 = __builtin_bit_cast(bf16x8_t, A[pg & 1][1]), al0 = __builtin_bit_cast(bf16x8_t, A[pg & 1][2]);
-        const bf16x8_t ah1 = __builtin_bit_cast(bf16x8_t, A[pg & 1][3]), am1 = __builtin_bit_cast(bf16x8_t, A[pg & 1][4]), al1 = __builtin_bit_cast(bf16x8_t, A[pg & 1][5]);
-        const int nbase = (((pg + 1) / NP) * NM + 2 * ((pg + 1) % NP)) * 3;
-        auto nload = [&](int q) { if (pg + 1 < NPG) { A[(pg + 1) & 1][2 * q] = frag[(nbase + 2 * q) * 64 + lane]; A[(pg + 1) & 1][2 * q + 1] = frag[(nbase + 2 * q + 1) * 64 + lane]; } };
-        // next chunk's split: dwords 2p, 2p+1 in this group, each in two halves (5 + 6 instructions)
-        auto nsplit = [&](int half) {
-            if (ch + 1 >= NCH) return;
-            const int q = 2 * p + (half >> 1);
-            if (half & 1) split_b(ch + 1, q); else split_a(ch + 1, q);
-        };
-        // the six products >= 2^-16 of the leading one, smallest first per accumulator: l.h, h.l, m.m, m.h, h.m, h.h
-        acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, xh, acc[m0], 0, 0, 0); HAV_SB(); nload(0); HAV_SB();
-        acc[m1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, xh, acc[m1], 0, 0, 0); HAV_SB(); nload(1); HAV_SB();
-        acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, xl, acc[m0], 0, 0, 0); HAV_SB(); nload(2); HAV_SB();
-        acc[m1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, xl, acc[m1], 0, 0, 0); HAV_SB();
-        acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am0, xm, acc[m0], 0, 0, 0); HAV_SB(); nsplit(0); HAV_SB();
-        acc[m1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am1, xm, acc[m1], 0, 0, 0); HAV_SB();
-        acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am0, xh, acc[m0], 0, 0, 0); HAV_SB(); nsplit(1); HAV_SB();
-        acc[m1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am1, xh, acc[m1], 0, 0, 0); HAV_SB();
-        acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, xm, acc[m0], 0, 0, 0); HAV_SB(); nsplit(2); HAV_SB();
-        acc[m1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, xm, acc[m1], 0, 0, 0); HAV_SB();
-        acc[m0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, xh, acc[m0], 0, 0, 0); HAV_SB(); nsplit(3); HAV_SB();
-        acc[m1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, xh, acc[m1], 0, 0, 0); HAV_SB();
     }
 }
 
-// Phase timing (tools/phase_profile.sh builds an alternative library with -DHAV_PROFILE): wave-uniform s_memtime deltas summed
-// per phase and added to g_prof at kernel exit.  Waits are attributed to the phase in which the s_waitcnt / s_nop sits.
-#ifdef HAV_PROFILE
-#define HAV_NPROF 24      // 16 stage set-up | 17 stage prologue (first box loads landed) | 18 stage chunk loop | 19 bias init
-//  0-9 phases | 10 wave lifetime | 11 gather set-up (corners, boxes) | 12 lean tiles | 13 general tiles | 14 staged planes | 15 direct planes (inside general tiles)
-__device__ unsigned long long g_prof[HAV_NPROF];
-struct ProfCtx { unsigned long long t, acc[HAV_NPROF]; };
-#define PROF_ARG , ProfCtx& P
-#define PROF_PASS , P
-#define TICK(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
-                     P.acc[i] += t_ - P.t; P.t = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define PROF_ARG
-#define PROF_PASS
-#define TICK(i) do { } while (0)
-#endif
+
+// "fp16 x 2 + MX" (PREC 3): acc[0..3] += W . x with every operand = hi + lo + tail, hi = rn16(v), lo = rn16(v - hi), tail = v - hi - lo
+// (exact: 11 + 11 + sign bits leave <= 2^-23 |v| for the tail).  The three leading partial products (lo.hi, hi.lo, hi.hi) run on
+// v_mfma_f32_32x32x16_f16 exactly as in mfma_split2h; the three terms of order 2^-22 that the fp16 mode drops -- hi.tail, tail.hi, lo.lo --
+// are added by ONE block-scaled 4- / 6-bit matrix instruction each per 64 k (v_mfma_scale_f32_32x32x64_f8f6f4, K = 64: 4 chunks x 16):
+//     acc += A[fp4  hi  ] . B[bf6 tail]      acc += A[fp4 tail] . B[bf6  hi  ]      acc += A[fp6  lo  ] . B[fp6  lo  ]
+// Their factors need 2-4 significant bits: a relative error of 2^-3 on a term of 2^-22 |a b| is 2^-25 |a b|, below the rounding of the fp32
+// product itself, so the mode carries the full 24-bit operands at 3 + 3 x 1.25 / 4 = 3.9 sixteen-bit-product equivalents per k chunk instead
+// of the bf16 triple split's 6 (tools/ubench/mx6_probe.hip: operand layouts, scale semantics and the instruction's issue rate, measured).
+// Weights: pre-split, pre-quantised records in LDS (hav_mlp_pack, MX_G_DWORDS), block scale per (row, 32 k).  Activations: per lane and group
+// the 32 values are split here, the three kinds converted with one v_cvt_scalef32_pk32 / 2xpk16 instruction each against a per-lane power of
+// two taken from the largest value (DYN; the positional encoding is bounded by 1: static).
+// NCH = 3 (layer 1: one group, slots 24-31 zero) or 8 (layer 2: two groups).  getv(ch, v[8]) as in mfma_split2h.
+typedef int i32x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x6_t __attribute__((ext_vector_type(6)));
+typedef _Float16 f16x32_t __attribute__((ext_vector_type(32)));
+__device__ __forceinline__ i32x8_t mx_op4(const uint4 a) { return i32x8_t{(int)a.x, (int)a.y, (int)a.z, (int)a.w, 0, 0, 0, 0}; }
+__device__ __forceinline__ i32x8_t mx_op6(const uint4 a, const uint2 b) { return i32x8_t{(int)a.x, (int)a.y, (int)a.z, (int)a.w, (int)b.x, (int)b.y, 0, 0}; }
+__device__ __forceinline__ i32x8_t mx_op6(const u32x6_t a) { return i32x8_t{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)a[4], (int)a[5], 0, 0}; }
+template <int NCH, bool DYN, typename GetV>
+__device__ __forceinline__ void mfma_split2x(f32x16 (&acc)[4], const uint4* frag /* fp16: [NCH][4 row tiles][2 parts][64 lanes] */,
+                                             const unsigned int* mx /* this layer's records: [k group][4 row tiles][MX_G_DWORDS] */, int lane, GetV getv)
+{
+    constexpr int NGRP = (NCH + 3) / 4;
+#pragma unroll
+    for (int g = 0; g < NGRP; ++g) {
+        constexpr int dummy = 0; (void)dummy;
+        const int nc = (NCH - 4 * g) < 4 ? (NCH - 4 * g) : 4;
+        // ---- activations of the group: hi, lo (packed fp16: the B operands of the fp16 products) and the tails ----
+        uint4 xh4[4], xl4[4];          // per chunk: 8 packed fp16 = the B operand of the chunk's fp16 products
+        f32x16 T0, T1;          // tails of the even / odd slots (the f32 conversion interleaves its two source vectors)
+        float vmax = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v[8];
+            if (c < nc) getv(4 * g + c, v);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                const float v0 = v[2 * q], v1 = v[2 * q + 1];
+                const h2 hi = __builtin_convertvector(f2{v0, v1}, h2);
+                const uint32_t ph = __builtin_bit_cast(uint32_t, hi);
+                float d0, d1;          // v - hi, exact
+                asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d0) : "v"(ph), "v"(v0));
+                asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d1) : "v"(ph), "v"(v1));
+                const h2 lo = __builtin_convertvector(f2{d0, d1}, h2);
+                const uint32_t pl = __builtin_bit_cast(uint32_t, lo);
+                float t0, t1;          // v - hi - lo, exact
+                asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(t0) : "v"(pl), "v"(d0));
+                asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(t1) : "v"(pl), "v"(d1));
+                if (q == 0) { xh4[c].x = ph; xl4[c].x = pl; } else if (q == 1) { xh4[c].y = ph; xl4[c].y = pl; }
+                else if (q == 2) { xh4[c].z = ph; xl4[c].z = pl; } else { xh4[c].w = ph; xl4[c].w = pl; }
+                T0[4 * c + q] = t0; T1[4 * c + q] = t1;
+                if (DYN) vmax = fmaxf(vmax, fmaxf(fabsf(v0), fabsf(v1)));
+            }
+        }
+        // per-lane block exponent E (biased) of the group: values < 2^(E - 126).  hi / 2^(E-130) < 16 (bf6: 28), |lo| / 2^(E-140) <= 4 (fp6: 7.5),
+        // |tail| / 2^(E-153) <= 8 (bf6).  An all-zero (or denormal) group keeps the bytes valid with E clamped from below.
+        unsigned int E = DYN ? (__float_as_uint(vmax) >> 23) : 127u;          // (PE inputs: |v| <= 1 + 1e-7 < 2)
+        if (DYN) E = E < 40u ? 40u : (E > 254u ? 254u : E);
+        const unsigned int bh = E - 3u, bl = E - 13u, bt = E - 26u;
+        const float sch = __uint_as_float(bh << 23), scl = __uint_as_float(bl << 23), sct = __uint_as_float(bt << 23);
+        const int sbv = (int)(bh | (bl << 8) | (bt << 16));
+        typedef _Float16 f16x16_t __attribute__((ext_vector_type(16)));
+        auto cat32 = [](const uint4 (&x)[4]) {
+            const f16x16_t a = __builtin_shufflevector(__builtin_bit_cast(f16x8_t, x[0]), __builtin_bit_cast(f16x8_t, x[1]), 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+            const f16x16_t b = __builtin_shufflevector(__builtin_bit_cast(f16x8_t, x[2]), __builtin_bit_cast(f16x8_t, x[3]), 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+            return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31);
+        };
+        const f16x32_t H = cat32(xh4), Lo = cat32(xl4);
+        const i32x8_t H6 = mx_op6(__builtin_amdgcn_cvt_scalef32_pk32_bf6_f16(H, sch));
+        const i32x8_t L6 = mx_op6(__builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(Lo, scl));
+        const i32x8_t T6 = mx_op6(__builtin_amdgcn_cvt_scalef32_2xpk16_bf6_f32(T0, T1, sct));
+        // ---- the three correction terms, row tile by row tile (consecutive matrix instructions never share an accumulator) ----
+        const unsigned int* rec = mx + g * 4 * MX_G_DWORDS;
+        uint4 ah[2], at[2], ala[2]; uint2 alb[2]; int sc[2];
+        auto ldrec = [&](int slot, int m) {
+            const unsigned int* r = rec + m * MX_G_DWORDS;
+            ah[slot] = reinterpret_cast<const uint4*>(r)[lane];
+            at[slot] = reinterpret_cast<const uint4*>(r + 256)[lane];
+            ala[slot] = reinterpret_cast<const uint4*>(r + 512)[lane];
+            alb[slot] = reinterpret_cast<const uint2*>(r + 768)[lane];
+            sc[slot] = (int)r[896 + lane];
+        };
+        ldrec(0, 0);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            if (m + 1 < 4) ldrec((m + 1) & 1, m + 1);
+            const int k = m & 1;
+            acc[m] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(mx_op4(ah[k]), T6, acc[m], 4, 3, 0, sc[k], 2, sbv);          // hi . tail
+            acc[m] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(mx_op4(at[k]), H6, acc[m], 4, 3, 1, sc[k], 0, sbv);          // tail . hi
+            acc[m] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(mx_op6(ala[k], alb[k]), L6, acc[m], 2, 2, 2, sc[k], 1, sbv);  // lo . lo
+        }
+        // ---- the three leading products of the group's chunks on the fp16 instruction (as mfma_split2h) ----
+        uint4 A[2][2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) A[0][q] = frag[((4 * g * 4) * 2 + q) * 64 + lane];
+#pragma unroll
+        for (int gg = 0; gg < 16; ++gg) {
+            const int c = gg >> 2, m = gg & 3;
+            if (c < nc) {
+                const f16x8_t xh = __builtin_bit_cast(f16x8_t, xh4[c]), xl = __builtin_bit_cast(f16x8_t, xl4[c]);
+                const f16x8_t ahh = __builtin_bit_cast(f16x8_t, A[gg & 1][0]), all_ = __builtin_bit_cast(f16x8_t, A[gg & 1][1]);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(all_, xh, acc[m], 0, 0, 0);
+                if (gg + 1 < 4 * nc) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) A[(gg + 1) & 1][q] = frag[(((4 * g) * 4 + gg + 1) * 2 + q) * 64 + lane];
+                }
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahh, xl, acc[m], 0, 0, 0);
+                acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahh, xh, acc[m], 0, 0, 0);
+            }
+        }
+    }
+}
+
+#include "hav_render_lab.h"      // ABL / TICK / PROF_* / DBG_*: diagnostic builds only, all empty in the shipped library
 
 // PREC = 0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  PREC = 1: split-operand bf16 MFMA (3 x bf16 per operand, 6 products).
 // The evaluation ends by calling cont(acc2, hd0, hd1, hd2, hd3): the caller's per-tile epilogue (compositing, parking).
-#ifdef HAV_DEBUG_TRACE
-// diagnostic build (tools/stress_diag.py DUMP=41): twelve per-lane stage values of EVERY tile evaluation go to a trace buffer
-// [12 quantities x 2 half-waves][rays][80 slots] behind the merged-depth dump, to be compared between launches on the host:
-// 0 gather checksum, 1 after layer 1, 2 after layer 2, 3 heads, 4 depth, 5 own bone weight, 6 partner's, 7 warped point, 8 den, 9 n0, 10 n1, 11 p + p1
-struct DbgTrace { float* p; long long plane; };
-#define DBG_ARG , DbgTrace dtr
-#define DBG_PASS(x) , x
-#define DBG_SUM(dst, t4) do { float s_ = 0.f; for (int m_ = 0; m_ < 4; ++m_) for (int r_ = 0; r_ < 16; ++r_) s_ += (t4)[m_][r_]; dst = s_; } while (0)
-#define DBG_PUT(i, v) do { if (dtr.p) dtr.p[(i) * dtr.plane] = (v); } while (0)
-#elif defined(HAV_DEBUG_DUMP3)
-// diagnostic build: checksums of this lane's values after the gather, after layer 1, after layer 2 and of the heads (self-check of
-// repeated evaluations, tools/stress_diag.py DUMP=10)
-#define DBG_ARG , float (&dcs)[12]
-#define DBG_PASS(x) , x
-#define DBG_SUM(dst, t4) do { float s_ = 0.f; for (int m_ = 0; m_ < 4; ++m_) for (int r_ = 0; r_ < 16; ++r_) s_ += (t4)[m_][r_]; dst = s_; } while (0)
-#else
-#define DBG_ARG
-#define DBG_PASS(x)
-#define DBG_SUM(dst, t4) do { } while (0)
-#endif
 template <int GQ, int PREC, bool BLK, bool LEAN = false, typename Cont>
 __device__ __forceinline__ void sample_eval(const MarchArgs& a_in, const LaneCtx& L, int b, float ox, float oy, float oz, float dx,
                                             float dy, float dz, float z, Cont&& cont PROF_ARG DBG_ARG)
@@ -1106,9 +983,7 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a_in, const LaneCtx
     // the lane id is opaque per tile: what derives from it (half-wave, fragment columns, strip slots) is then re-derived in one or two
     // ALU ops where it is used instead of being hoisted out of the sample loop as dozens of loop invariants, spilled and RELOADED
     int lane = L.lane;
-#ifndef HAV_NO_OPAQUE_LANE
     asm volatile("" : "+v"(lane));
-#endif
     const int h = lane >> 5;
     const float* sW1 = L.sW1;
     const float* sW2 = L.sW2;
@@ -1157,22 +1032,16 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a_in, const LaneCtx
     const float wother = half_swap(wmine, h);
     const float w0 = h ? wother : wmine, w1 = h ? wmine : wother;
     const float den = (w0 + w1) + 1e-8f;
-#if HAV_FAST_DIV
-    // one reciprocal + one Newton step (<= 1 ulp from the IEEE quotient) instead of two v_div_scale / v_div_fmas / v_div_fixup sequences
+    // one reciprocal + one Newton step (<= 1 ulp from the IEEE quotient), NOT w / den: with ROCm 7.2 on gfx950 the compiler's IEEE expansion
+    // (two interleaved v_div_scale / v_div_fmas / v_div_fixup sequences, VCC and SGPR-pair traffic in between) is where a rare run-to-run
+    // difference came from -- identical inputs, a different warped point in lanes 48-63 of one tile; 22 % of the launches of a 512^2 frame on
+    // one box with the IEEE form, 0 of 41 000 with this one (docs/history/DESIGN_r1-r4.md 3.12)
     float rden = __builtin_amdgcn_rcpf(den);
     rden = rden * (2.0f - den * rden);
     float n0 = w0 * rden, n1 = w1 * rden;
-#else
-    float n0 = w0 / den, n1 = w1 / den;
-#endif
     const float qx_ = n0 * px + n1 * p1x, qy_ = n0 * py + n1 * p1y, qz_ = n0 * pz + n1 * p1z;   // p'
-#ifdef HAV_DEBUG_TRACE
     DBG_PUT(4, z); DBG_PUT(5, wmine); DBG_PUT(6, wother); DBG_PUT(7, (qx_ + qy_) + qz_);
     DBG_PUT(8, den); DBG_PUT(9, n0); DBG_PUT(10, n1); DBG_PUT(11, (px + py + pz) + (p1x + p1y + p1z));
-#elif defined(HAV_DEBUG_DUMP3)
-    dcs[4] = z; dcs[5] = wmine; dcs[6] = wother; dcs[7] = (qx_ + qy_) + qz_;
-    dcs[8] = den; dcs[9] = n0; dcs[10] = n1; dcs[11] = (px + py + pz) + (p1x + p1y + p1z);
-#endif
     TICK(1);
 
     // ---- layer 1 (model/nerf_model.py:104-108): bias + 8 projected tri-plane taps + PE columns on the MFMA ----
@@ -1192,7 +1061,7 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a_in, const LaneCtx
             }
     };
     auto gather = [&](f32x16 (&acc1)[4]) {
-        if (!(a.ablate & 1)) {
+        if (!ABL(1)) {
             // sample_from_triplane_new (utils/util.py:359-392): plane0 at (x,y), plane1 at (z,y); zeros padding.
             // Each texel of the prepared planes already carries W1f . texel for this half-wave's 64 hidden units.
             const float lim = a.plim;
@@ -1264,15 +1133,11 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a_in, const LaneCtx
     auto finish = [&](f32x16 (&acc1)[4]) {
         f32x16 acc2[4];
         float hd0, hd1, hd2, hd3;
-#ifdef HAV_DEBUG_TRACE
-        { float s0_; DBG_SUM(s0_, acc1); DBG_PUT(0, s0_); }
-#elif defined(HAV_DEBUG_DUMP3)
-        DBG_SUM(dcs[0], acc1);
-#endif
+        DBG_STAGE(0, acc1);
         TICK(2);
         // ---- PE octaves 4h..4h+3 of this half-wave (model/network/embedder.py:32-61) ---------------------
         float pe[KPE_STEPS];
-        if (a.ablate & 2) {          // timing experiment: no sin / cos
+        if (ABL(2)) {          // timing experiment: no sin / cos
 #pragma unroll
             for (int kk = 0; kk < KPE_STEPS; ++kk) pe[kk] = qx_ * (float)(kk + 1);
         } else
@@ -1285,22 +1150,27 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a_in, const LaneCtx
         }
         __builtin_amdgcn_sched_barrier(0);
         TICK(3);
-        mfma_lock(L);
 
-        if (PREC == 2) {
-            if (!(a.ablate & 16))
+        if (PREC == 3) {
+            if (!ABL(16))
+            mfma_split2x<3, false>(acc1, L.sA1, L.sMX, lane, [&](int c, float (&v)[8]) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = pe[8 * c + e];
+            });
+        } else if (PREC == 2) {
+            if (!ABL(16))
             mfma_split2h<3, 4>(acc1, L.sA1, lane, [&](int c, float (&v)[8]) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = pe[8 * c + e];
             });
         } else if (PREC == 1) {
-            if (!(a.ablate & 16))
+            if (!ABL(16))
             mfma_split3<3>(acc1, L.sA1, lane, [&](int c, float (&v)[8]) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = pe[8 * c + e];
             });
         }
-        else if (!(a.ablate & 16)) {
+        else if (!ABL(16)) {
             float af[2][4];               // explicit double buffer: the A fragments of k-step t+1 are requested before the MFMAs of step t
 #pragma unroll
             for (int m = 0; m < 4; ++m) af[0][m] = sW1[m * 64 + lane];
@@ -1316,11 +1186,7 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a_in, const LaneCtx
             }
         }
         relu_tiles<LEAN>(acc1);
-#ifdef HAV_DEBUG_TRACE
-        { float s1_; DBG_SUM(s1_, acc1); DBG_PUT(1, s1_); }
-#elif defined(HAV_DEBUG_DUMP3)
-        DBG_SUM(dcs[1], acc1);
-#endif
+        DBG_STAGE(1, acc1);
         TICK(4);
 
         __builtin_amdgcn_sched_barrier(0);
@@ -1338,19 +1204,25 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a_in, const LaneCtx
                 acc2[m][4 * q + 0] = __uint_as_float(bb[0]); acc2[m][4 * q + 1] = __uint_as_float(bb[1]);
                 acc2[m][4 * q + 2] = __uint_as_float(bb[2]); acc2[m][4 * q + 3] = __uint_as_float(bb[3]);
             }
-        if (PREC == 2) {
-            if (!(a.ablate & 32))
+        if (PREC == 3) {
+            if (!ABL(32))
+            mfma_split2x<8, true>(acc2, L.sA2, L.sMX + 4 * MX_G_DWORDS, lane, [&](int ch, float (&v)[8]) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = acc1[ch >> 1][8 * (ch & 1) + e];
+            });
+        } else if (PREC == 2) {
+            if (!ABL(32))
             mfma_split2h<8, 4>(acc2, L.sA2, lane, [&](int ch, float (&v)[8]) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = acc1[ch >> 1][8 * (ch & 1) + e];
             });
         } else if (PREC == 1) {
-            if (!(a.ablate & 32))
+            if (!ABL(32))
             mfma_split3<8>(acc2, L.sA2, lane, [&](int ch, float (&v)[8]) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = acc1[ch >> 1][8 * (ch & 1) + e];
             });
-        } else if (!(a.ablate & 32)) {
+        } else if (!ABL(32)) {
             float af[2][4];
 #pragma unroll
             for (int m = 0; m < 4; ++m) af[0][m] = sW2[m * 64 + lane];
@@ -1366,12 +1238,7 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a_in, const LaneCtx
             }
         }
         relu_tiles<LEAN>(acc2);
-#ifdef HAV_DEBUG_TRACE
-        { float s2_; DBG_SUM(s2_, acc2); DBG_PUT(2, s2_); }
-#elif defined(HAV_DEBUG_DUMP3)
-        DBG_SUM(dcs[2], acc2);
-#endif
-        mfma_unlock(L);
+        DBG_STAGE(2, acc2);
         TICK(5);
 
         __builtin_amdgcn_sched_barrier(0);
@@ -1380,7 +1247,7 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a_in, const LaneCtx
         {
             typedef float f2 __attribute__((ext_vector_type(2)));
             f2 hA = {0.f, 0.f}, hB = {0.f, 0.f};                 // packed FMAs: (rgb0, rgb1) and (rgb2, alpha)
-            if (!(a.ablate & 64)) {
+            if (!ABL(64)) {
                 if (LEAN) {
 #pragma unroll
                 for (int mp = 0; mp < 4; ++mp)
@@ -1429,11 +1296,7 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a_in, const LaneCtx
             hd0 += __uint_as_float(b4[0]); hd1 += __uint_as_float(b4[1]); hd2 += __uint_as_float(b4[2]); hd3 += __uint_as_float(b4[3]);
         }
         TICK(6);
-#ifdef HAV_DEBUG_TRACE
         DBG_PUT(3, (hd0 + hd1) + (hd2 + hd3));
-#elif defined(HAV_DEBUG_DUMP3)
-        dcs[3] = (hd0 + hd1) + (hd2 + hd3);
-#endif
         cont(acc2, hd0, hd1, hd2, hd3);
     };
     f32x16 acc1[4];
@@ -1446,9 +1309,7 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a_in, const LaneCtx
 // ------------------------------------------------------------------------------------------------
 // the kernel
 // ------------------------------------------------------------------------------------------------
-#ifndef MARCH_THREADS
 #define MARCH_THREADS 512
-#endif
 #define MARCH_WAVES (MARCH_THREADS / 64)
 #define RACC_N 136  // 0..127 composited hidden units | 128..130 rgb | 131 depth | 132 acc | 133 wmax
 #define R_RGB 128
@@ -1498,7 +1359,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
     const int j = lane & 31, h = lane >> 5, col = lane & 15, rowt = (lane >> 4) & 1;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.blob), 0, BLOB_FLOATS * 4, 0x00020000);
     LaneCtx L;
-    L.sW1 = sW1; L.sW2 = sW2; L.sW4 = sW4; L.wrs = wrs; L.lane = lane; L.h = h; L.hoff = h * 16; L.lock = nullptr;
+    L.sW1 = sW1; L.sW2 = sW2; L.sW4 = sW4; L.wrs = wrs; L.lane = lane; L.h = h; L.hoff = h * 16;
 
     const int S_c = a.p.S_c, S_fp = a.S_fp;
     const long long NR = a.NR;
@@ -1559,14 +1420,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                 }
                 const float dist = (s + 1 < S) ? (znb - z) : (z - znb);
 
-#ifdef HAV_PROFILE
-                ProfCtx P;
-#endif
-#ifdef HAV_DEBUG_TRACE
-                DbgTrace dbg_dummy{nullptr, 0};
-#elif defined(HAV_DEBUG_DUMP3)
-                float dbg_dummy[12];
-#endif
+                PROF_DECL();
                 sample_eval<16, 0, false>(a, L, b, ox, oy, oz, dx, dy, dz, z, [&](f32x16 (&acc2)[4], float hd0, float hd1, float hd2, float hd3) {
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- volume_render_radiance_field (utils/nerf_util.py:28-73) -------------------------------
@@ -1596,7 +1450,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                 // [4*(2*col + h) .. +3] (64*b3 + 32*b2 + 16*b1 + 8*b0 + 4h), i.e. one aligned float4 of the LDS accumulator.
                 const bool same = (2 * tile) / nr == (2 * tile + 1) / nr;    // both rows of this tile belong to one ray
                 float* racc = s_racc + slot * RACC_N;
-                if (!(a.ablate & 8)) {
+                if (!ABL(8)) {
                     const bool b3 = (col & 8) != 0, b2 = (col & 4) != 0, b1 = (col & 2) != 0, b0 = (col & 1) != 0;
                     float v1[32];
 #pragma unroll
@@ -1648,7 +1502,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                         racc[R_WMAX] = fmaxf(racc[R_WMAX], v5);
                     }
                 }
-                } PROF_PASS DBG_PASS(dbg_dummy));
+                } PROF_PASS DBG_PASS(DBG_NONE()));
                 wave_lds_sync();
             }   // tiles
 
@@ -1687,7 +1541,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
             }
 
             // ---- inverse-CDF resampling + merge (utils/nerf_util.py:76-117, model/nerf_trainer.py:166-170) ---
-            if (pass == 0 && S_fp > 0 && !(a.ablate & 128)) {
+            if (pass == 0 && S_fp > 0 && !ABL(128)) {
                 const int slot = h, li = j;                       // half-wave h prepares ray slot h
                 const long long gr = (slot == 0 || has1) ? ray0 + slot : ray0;
                 const RKey rkey = RANDOM ? rng_ray_key(a, gr, call_off) : RKey{0u, 0u, 0u, a.step_c};
@@ -1775,23 +1629,10 @@ __device__ __forceinline__ float4 nt_load4(const float4* p)
     const nt_f4 t = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p));
     return make_float4(t.x, t.y, t.z, t.w);
 }
-#ifndef HAV_GQ2
-#define HAV_GQ2 16         // float4 loads per gather stage in the fine-maps-only variant (its register budget allows a whole tap: -2 %)
-#endif
-#ifndef HAV_RESAMPLE_PF
-#define HAV_RESAMPLE_PF 8      // coarse weights in flight in the resampling sweep (8 or 4)
-#endif
-#ifndef HAV_WSUM_INLOOP
-#define HAV_WSUM_INLOOP 0
-#endif
-#ifndef HAV_STAGEB_PF
-#define HAV_STAGEB_PF 1        // parked entries in flight in stage B (measured: 2 = +2 %, 3 = +8 %, 4 = +12 % kernel time; profiles/r04_ab_lat.txt)
-#endif
-#define HAV_LDS_BIAS 264          // LDS copy of b1 | b2 | b4 (folded rgb biases, alpha bias) | pad, behind the weight image
+#define HAV_GQ2 16               // float4 loads per gather stage in the fine-maps-only variant (its register budget allows a whole tap: -2 %)
+#define HAV_RESAMPLE_PF 8        // coarse weights in flight in the resampling sweep
+#define HAV_LDS_BIAS 264         // LDS copy of b1 | b2 | b4 (folded rgb biases, alpha bias) | pad, behind the weight image
 #define WS_H2_FLOATS 4096
-#ifndef HAV_FEATPARK
-#define HAV_FEATPARK 1      // fp16 mode: park the 64 features of a sample (48 more MFMAs per parked tile) instead of its 128 hidden units
-#endif
 #define WS_ENTRY_FLOATS (WS_H2_FLOATS + 128 + 32)
 // CACHE = 2: additionally, the caller does not want the coarse pass's composited outputs (Trainer.forward with a fine pass only
 // uses the fine ones): the coarse pass then carries no composited-hidden-unit accumulators at all (64 VGPRs less in its loop).
@@ -1802,7 +1643,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
     constexpr bool COUT = CACHE != 2;
     // fp16 mode: the fc_rgbFeat fragments fit in LDS next to the layer weights, so what is parked per sample is its 64 FEATURES
     // (8 rows of 1 KB per wave) instead of its 128 hidden units (16 rows): half the parking traffic for 48 more MFMAs per parked tile
-    constexpr bool FEATPARK = (PREC == 2) && (CACHE != 0) && HAV_FEATPARK;
+    constexpr bool FEATPARK = (PREC == 2) && (CACHE != 0);
     constexpr int H2F = FEATPARK ? WS_H2_FLOATS / 2 : WS_H2_FLOATS, ENTF = H2F + 128 + 32;      // floats of one parked entry
     if (a.guard) {          // fp16 range guard: the fp16 kernel and its bf16 fallback are both launched, one of them proceeds
         const unsigned int unsafe = __builtin_amdgcn_readfirstlane(*a.guard);
@@ -1811,13 +1652,20 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
     }
     const uint32_t call_off = RANDOM ? rng_call_off(a) : 0u;      // one memory read per kernel, not per draw
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int WLDS = PREC == 2 ? LDSH_FLOATS : (PREC == 1 ? LDS3_FLOATS : LDS_FLOATS);     // LDS image: fp32 | split-bf16 | split-fp16 fragments
+    constexpr int WLDS = PREC == 3 ? LDSX_FLOATS : (PREC == 2 ? LDSH_FLOATS : (PREC == 1 ? LDS3_FLOATS : LDS_FLOATS));     // LDS image: fp32 | split-bf16 | split-fp16 fragments | fp16 fragments + MX records
     const float* sWFF = smem + OFF_WFT;           // PREC 0: fc_rgbFeat fragments live in the WFT slot (PREC 1 streams them from L2)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* s_n = smem + WLDS + HAV_LDS_BIAS + wave * a.scr_floats;      // [S_f][32] importance samples of this wave's rays (after the b1|b2|b4 copy)
-    if (PREC >= 1) {
+    if (PREC == 3) {          // [A1H | A2H | W4H] as in the fp16 mode, then the MX records (stored behind the range-guard words in the blob)
+        const float4* src = reinterpret_cast<const float4*>(a.blob + OFF_A1H);
+        float4* dst = reinterpret_cast<float4*>(smem);
+        for (int i = tid; i < LDSX_FP16 / 4; i += MARCH_THREADS) dst[i] = src[i];
+        const float4* srcx = reinterpret_cast<const float4*>(a.blob + OFF_MX);
+        float4* dstx = reinterpret_cast<float4*>(smem + LDSX_FP16);
+        for (int i = tid; i < MX_GROUPS * MX_G_DWORDS / 4; i += MARCH_THREADS) dstx[i] = srcx[i];
+    } else if (PREC >= 1) {
         const float4* src = reinterpret_cast<const float4*>(a.blob + (PREC == 2 ? OFF_A1H : OFF_A1S));
         float4* dst = reinterpret_cast<float4*>(smem);
         for (int i = tid; i < WLDS / 4; i += MARCH_THREADS) dst[i] = src[i];
@@ -1832,51 +1680,26 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
     if (tid < 65) reinterpret_cast<float4*>(smem + WLDS)[tid] = reinterpret_cast<const float4*>(a.blob + OFF_B1)[tid];   // b1 | b2 | b4 (contiguous in the blob)
     __syncthreads();
 
-#ifdef HAV_PROFILE
-    ProfCtx P;
-    for (int i = 0; i < HAV_NPROF; ++i) P.acc[i] = 0;
-    const unsigned long long t_kernel0 = __builtin_amdgcn_s_memtime();
-    P.t = t_kernel0;
-#endif
+    PROF_DECL();
+    PROF_BEGIN();
     const int j = lane & 31, h = lane >> 5;
     LaneCtx L;
     L.sW1 = smem + OFF_W1PE; L.sW2 = smem + OFF_W2;
-    L.sW4 = reinterpret_cast<const float4*>(smem + (PREC == 2 ? (OFF_W4H - OFF_A1H) : (PREC == 1 ? (OFF_W4S - OFF_A1S) : OFF_W4)));
+    L.sW4 = reinterpret_cast<const float4*>(smem + (PREC >= 2 ? (OFF_W4H - OFF_A1H) : (PREC == 1 ? (OFF_W4S - OFF_A1S) : OFF_W4)));
     L.sA1 = reinterpret_cast<const uint4*>(smem);
-    L.sA2 = reinterpret_cast<const uint4*>(smem + (PREC == 2 ? (OFF_A2H - OFF_A1H) : (OFF_A2S - OFF_A1S)));
+    L.sA2 = reinterpret_cast<const uint4*>(smem + (PREC >= 2 ? (OFF_A2H - OFF_A1H) : (OFF_A2S - OFF_A1S)));
     L.sAF = reinterpret_cast<const uint4*>(smem + (OFF_AFH - OFF_A1H));
+    L.sMX = reinterpret_cast<const unsigned int*>(smem + LDSX_FP16);
     L.sB = reinterpret_cast<const float4*>(smem + WLDS);
     L.wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.blob), 0, BLOB_FLOATS * 4, 0x00020000);
     L.lane = lane; L.h = h; L.hoff = h * 16;
-    {   // one lock word per SIMD behind the per-wave scratch, indexed by the SIMD this wave really runs on (HW_REG_HW_ID bits 5:4)
-        int* locks = reinterpret_cast<int*>(smem + WLDS + HAV_LDS_BIAS + MARCH_WAVES * a.scr_floats);
-#ifdef HAV_LOCK_BY_WAVE
-        const unsigned simd = wave & 3;
-#else
-        const unsigned simd = __builtin_amdgcn_readfirstlane((__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) >> 4) & 3u);
-#endif
-        L.lock = locks + simd;
-        if (tid < 4) locks[tid] = 0;
-        __syncthreads();
-    }
-#ifdef HAV_HALF_WAVES
-    // experiment (complete results, half the waves): 1 = waves 4..7 exit, one live wave per SIMD (waves w and w + 4 share a SIMD,
-    // tools/ubench/simd_map.hip); 2 = the odd waves exit, the same number of live waves but still two on SIMDs 0 and 2.  The live
-    // waves deal the blocks among themselves.
-    if (HAV_HALF_WAVES == 1 ? wave >= 4 : (wave & 1)) return;
-    const int wave_rank = HAV_HALF_WAVES == 1 ? wave : wave >> 1;
-    constexpr int WAVES_LIVE = MARCH_WAVES / 2;
-#else
-    const int wave_rank = wave;
-    constexpr int WAVES_LIVE = MARCH_WAVES;
-#endif
 
     const int S_c = a.p.S_c, S_f = a.p.S_f, S_fp = a.S_fp, S_half = (S_c + 1) >> 1;
     const int R = a.p.R;
     const int bpf = (R + 31) >> 5;                       // blocks per frame: a block never straddles two frames
     const long long nblk = (long long)bpf * a.p.B;
 
-    for (int q = 0; q < wave * a.stagger; ++q) __builtin_amdgcn_s_sleep(1);      // 64 cycles each
+    LAB_STAGGER(wave);
     long long chunk, base, span;
     int lb, nbx;
     if ((gridDim.x & 7) == 0) {
@@ -1887,7 +1710,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
         span = nblk - base; if (span > chunk) span = chunk; if (span < 0) span = 0;
     } else { base = 0; span = nblk; lb = blockIdx.x; nbx = gridDim.x; }
 
-    for (long long local = (long long)lb * WAVES_LIVE + wave_rank; local < span; local += (long long)nbx * WAVES_LIVE) {
+    for (long long local = (long long)lb * MARCH_WAVES + wave; local < span; local += (long long)nbx * MARCH_WAVES) {
         const long long blk = base + local;
         const int b = (int)(blk / bpf);
         const int r0 = (int)(blk - (long long)b * bpf) * 32 + j;
@@ -1899,24 +1722,13 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
         const float dn = sqrtf(dx * dx + dy * dy + dz * dz);
         float* wpark = a.out.rgb_fine ? a.out.rgb_fine + gr * 67 : nullptr;   // this ray's parking row for w[0..S_c)
         RKey rkey = RANDOM ? rng_ray_key(a, gr, call_off) : RKey{0u, 0u, 0u, a.step_c};
-#ifdef HAV_DEBUG_TRACE
-        // trace slot of (this lane's ray, tile): behind the [rays][S_fp] depth dump; 80 slots per ray = S_c coarse tiles + S_f new samples
-        const long long dbg_plane_ = (long long)a.p.B * a.p.R * 80;
-#define DBG_TILE(slot_) DbgTrace{(a.dbg_zfine && rayok && CACHE == 2 && a.p.S_c + a.p.S_f <= 80) ? a.dbg_zfine + (long long)a.p.B * a.p.R * a.S_fp + (12 * h) * dbg_plane_ + gr * 80 + (slot_) : nullptr, dbg_plane_}
-#elif defined(HAV_DEBUG_DUMP3)
-#define DBG_TILE(slot_) cB
-#endif
         // Register hygiene: the phases of a block (sample loop | resampling | stage 1 | A | B | stores) all start from these four
         // per-ray values.  Left transparent, the compiler shares sub-expressions BETWEEN phases (coarse depths of fixed indices,
         // output addresses, hash pieces): dozens of values that then live -- spilled -- through the sample loops.  An opaque fence
         // at each phase boundary makes every phase recompute its own (a handful of ALU ops per block).
-#ifndef HAV_NO_RAY_FENCE
 #define RAY_FENCE() asm volatile("" : "+v"(near), "+v"(far), "+v"(gr), "+v"(rkey.ray), "+v"(rkey.step))
-#else
-#define RAY_FENCE() do { } while (0)
-#endif
         RAY_FENCE();
-        float* slot = CACHE ? a.ws + ((a.ablate & 1024) ? 0 : a.ws_slot * ((long long)blockIdx.x * MARCH_WAVES + wave)) : nullptr;   // 1024: timing experiment, all waves share one L2-resident slot
+        float* slot = CACHE ? a.ws + (ABL(1024) ? 0 : a.ws_slot * ((long long)blockIdx.x * MARCH_WAVES + wave)) : nullptr;   // 1024: timing experiment, all waves share one L2-resident slot
         // coarse weights w[0..S_c) of the block's rays for the inverse CDF: with a workspace, one coalesced 128-byte row per sample in
         // this wave's own slot (wrow: written and read by the same wave, plain cached loads -- a wave's stores are coherent with its own
         // CU's L1); without (CACHE == 0, not the production path), the ray's (not yet written) rgb_fine row (wpark).  rgb_fine rows of
@@ -1924,37 +1736,19 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
         // stale on another CU only -- the row is private to the ray, so it is the same-CU case too, but the wpark reads stay
         // L1-bypassing (non-temporal): that path is outside the determinism stress runs.
         float* wrow = CACHE ? slot + (size_t)a.S_fp * ENTF : nullptr;
-#if HAV_BLOCK_FENCE
-        if (CACHE) {        // the slot is re-used block after block: everything the previous block did to it has landed, and no L1 line of it survives
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-#endif
         auto park = [&](int e, const f32x16 (&v)[4], float r0, float r1, float r2, float r3) {       // entry e of this block's slot
             float4* H2 = reinterpret_cast<float4*>(slot + (size_t)e * ENTF);
-#ifdef HAV_DEBUG_DUMP3
-            if (a.dbg_zfine && rayok) {          // diagnostic build: a checksum of this lane's 64 hidden units per (ray, entry, half-wave)
-                float cs = 0.f;
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) cs += v[m][r];
-                a.dbg_zfine[(4 + h) * ((long long)a.p.B * a.p.R * a.S_fp) + gr * a.S_fp + e] = cs;
-            }
-#endif
             if (FEATPARK) {
                 f32x16 ft[2];
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) ft[m][r] = 0.f;
-                mfma_lock(L);
-                if (!(a.ablate & 4))
+                if (!ABL(4))
                 mfma_split2h<8, 2>(ft, L.sAF, lane, [&](int ch, float (&x)[8]) {
 #pragma unroll
                     for (int el = 0; el < 8; ++el) x[el] = v[ch >> 1][8 * (ch & 1) + el];
                 });
-                mfma_unlock(L);
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -2038,7 +1832,6 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
 #pragma unroll
                 for (int r = 0; r < 16; ++r) hsum[m][r] = 0.f;
             float T = 1.0f, c0 = 0.f, c1 = 0.f, c2 = 0.f, dep = 0.f, accw = 0.f, wmax = 0.f;
-            float wsum = 0.f;           // sum_{i=1}^{S_c-2} (w_i + 1e-5), accumulated in the resampling's own (sequential) order while the weights are produced
             // merged fine depths are produced on the fly: even coarse depths and the LDS-resident importance samples
             int ie = 0, ik = 0;
             float ze = 0.f, nk = 0.f;
@@ -2054,27 +1847,12 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                 // ---- stage 1: the S_f new samples (same k for all 32 rays), parked behind the even coarse entries ----
                 for (int k = 0; k < S_f; ++k) {
                     TICK(0);
-#ifdef HAV_DEBUG_DUMP3
-                    float cA[12], cB[12];
-                    sample_eval<(CACHE == 2 ? HAV_GQ2 : 8), PREC, true, CACHE == 2>(a, L, b, ox, oy, oz, dx, dy, dz, s_n[k * 32 + j],
-                                                                 [&](f32x16 (&acc2)[4], float hd0, float hd1, float hd2, float hd3) {
-                        __builtin_amdgcn_sched_barrier(0);
-                    } PROF_PASS, cA);
-#endif
                     const float zk = s_n[k * 32 + j];
                     sample_eval<(CACHE == 2 ? HAV_GQ2 : 8), PREC, true, CACHE == 2>(a, L, b, ox, oy, oz, dx, dy, dz, zk,
                                                                  [&](f32x16 (&acc2)[4], float hd0, float hd1, float hd2, float hd3) {
                         __builtin_amdgcn_sched_barrier(0);
                         park(S_half + k, acc2, hd0, hd1, hd2, hd3);
                     } PROF_PASS DBG_PASS(DBG_TILE(S_c + k)));
-#ifdef HAV_DEBUG_DUMP3
-                    if (a.dbg_zfine && rayok) {          // self-check: the same tile evaluated twice; which stage differs first
-                        const int code = (cA[0] != cB[0] ? 1 : 0) | (cA[1] != cB[1] ? 2 : 0) | (cA[2] != cB[2] ? 4 : 0) | (cA[3] != cB[3] ? 8 : 0) |
-                                         (cA[4] != cB[4] ? 16 : 0) | (cA[5] != cB[5] ? 32 : 0) | (cA[6] != cB[6] ? 64 : 0) | (cA[7] != cB[7] ? 128 : 0) |
-                                         (cA[8] != cB[8] ? 256 : 0) | (cA[9] != cB[9] ? 512 : 0) | (cA[10] != cB[10] ? 1024 : 0) | (cA[11] != cB[11] ? 2048 : 0);
-                        a.dbg_zfine[(6 + h) * ((long long)a.p.B * a.p.R * a.S_fp) + gr * a.S_fp + S_half + k] = (float)code;
-                    }
-#endif
                     TICK(7);
                 }
                 RAY_FENCE();
@@ -2101,7 +1879,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                 for (int u = 0; u < FQ; ++u) {
                     zq[u] = 0.f; eq[u] = 0;
                     if (produced < S) { zq[u] = next_entry(eq[u]); ++produced; }
-                    rq[u] = HAV_SELF_LOAD4(&RAWp[(size_t)eq[u] * (ENTF / 4) + j]);
+                    rq[u] = *(&RAWp[(size_t)eq[u] * (ENTF / 4) + j]);
                 }
                 float dist = 0.f;
                 for (int s0 = 0; s0 < S; s0 += FQ) {
@@ -2115,7 +1893,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                             // refill this slot with merged sample sidx + FQ (if any) before using its neighbour's depth
                             if (produced < S) {
                                 zq[u] = next_entry(eq[u]); ++produced;
-                                rq[u] = HAV_SELF_LOAD4(&RAWp[(size_t)eq[u] * (ENTF / 4) + j]);
+                                rq[u] = *(&RAWp[(size_t)eq[u] * (ENTF / 4) + j]);
                             }
                             if (sidx + 1 < S) dist = zq[(u + 1) % FQ] - zc;          // dists[-1] repeats dists[-2] (:36-37)
                             float sg = raw.w;
@@ -2135,15 +1913,6 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                             wmax = fmaxf(wmax, wgt);
                             if (h == 0) slot[(size_t)ec * ENTF + H2F + 128 + j] = wgt;      // one writer per address
                             if (a.dbg_zfine && h == 0 && rayok) a.dbg_zfine[gr * S_fp + sidx] = zc;
-#ifdef HAV_DEBUG_DUMP3
-                            // diagnostic build (tools/stress_diag.py DUMP=3): the parked density head and the weight of every merged sample
-                            if (a.dbg_zfine && h == 0 && rayok) {
-                                const long long plane = (long long)a.p.B * a.p.R * S_fp;
-                                a.dbg_zfine[plane + gr * S_fp + sidx] = raw.w;
-                                a.dbg_zfine[2 * plane + gr * S_fp + sidx] = raw.x;
-                                a.dbg_zfine[3 * plane + gr * S_fp + sidx] = (float)ec;          // which entry: < S_half = coarse sample 2 e, else new sample e - S_half
-                            }
-#endif
                         }
                     }
                 }
@@ -2158,11 +1927,10 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
 #pragma unroll
                     for (int r = 0; r < 16; ++r) hsumB[m][r] = 0.f;
                 constexpr int NROW = FEATPARK ? 8 : 16;
-                constexpr int PF = HAV_STAGEB_PF < 1 ? 1 : (FEATPARK ? HAV_STAGEB_PF : (HAV_STAGEB_PF + 1) / 2);      // entries in flight (32 / 64 registers each)
-                if constexpr (PF == 1) {          // one entry at a time (the default: more in flight measured slower, and cost registers)
+                // one entry at a time: two / three / four in flight measured +2 / +8 / +12 % kernel time (profiles/r04_ab_lat.txt) and cost registers
                 for (int e = 0; e < S; ++e) {
                     const float4* H2 = reinterpret_cast<const float4*>(slot + (size_t)e * ENTF);
-                    const float wgt = HAV_SELF_LOAD(&slot[(size_t)e * ENTF + H2F + 128 + j]);
+                    const float wgt = *(&slot[(size_t)e * ENTF + H2F + 128 + j]);
 #pragma unroll
                     for (int q = 0; q < NROW; ++q) {
                         const float4 v = nt_load4(&H2[q * 64 + lane]);
@@ -2171,38 +1939,6 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                         hsumB[q >> 2][4 * (q & 3) + 2] = fmaf(wgt, v.z, hsumB[q >> 2][4 * (q & 3) + 2]);
                         hsumB[q >> 2][4 * (q & 3) + 3] = fmaf(wgt, v.w, hsumB[q >> 2][4 * (q & 3) + 3]);
                     }
-                }
-                } else {
-                float4 vb[PF][NROW];
-                float wb[PF];
-                auto ldB = [&](int u, int e) {
-                    if (e < S) {
-                        const float4* H2 = reinterpret_cast<const float4*>(slot + (size_t)e * ENTF);
-                        wb[u] = HAV_SELF_LOAD(&slot[(size_t)e * ENTF + H2F + 128 + j]);
-#pragma unroll
-                        for (int q = 0; q < NROW; ++q) vb[u][q] = nt_load4(&H2[q * 64 + lane]);
-                    }
-                };
-#pragma unroll
-                for (int u = 0; u < PF; ++u) ldB(u, u);
-                for (int e0 = 0; e0 < S; e0 += PF) {
-#pragma unroll
-                    for (int u = 0; u < PF; ++u) {
-                        if (e0 + u < S) {
-                            const float wgt = wb[u];
-#pragma unroll
-                            for (int q = 0; q < NROW; ++q) {
-                                const float4 v = vb[u][q];
-                                hsumB[q >> 2][4 * (q & 3) + 0] = fmaf(wgt, v.x, hsumB[q >> 2][4 * (q & 3) + 0]);
-                                hsumB[q >> 2][4 * (q & 3) + 1] = fmaf(wgt, v.y, hsumB[q >> 2][4 * (q & 3) + 1]);
-                                hsumB[q >> 2][4 * (q & 3) + 2] = fmaf(wgt, v.z, hsumB[q >> 2][4 * (q & 3) + 2]);
-                                hsumB[q >> 2][4 * (q & 3) + 3] = fmaf(wgt, v.w, hsumB[q >> 2][4 * (q & 3) + 3]);
-                            }
-                        }
-                        asm volatile("" ::: "memory");          // the refill stays behind the FMAs that free its registers
-                        ldB(u, e0 + u + PF);
-                    }
-                }
                 }
                 TICK(3);
                 emit(1, hsumB, c0, c1, c2, dep, accw, wmax, FEATPARK ? hsumB : nullptr);       // (feature parking: hsumB[0..1] are the features)
@@ -2217,13 +1953,6 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
 
             for (int s = 0; s < ((CACHE && pass == 1) ? 0 : S); ++s) {
                 TICK(0);
-#ifdef HAV_DEBUG_DUMP3
-                float cA[12], cB[12];
-                sample_eval<(CACHE == 2 ? HAV_GQ2 : 8), PREC, true, CACHE == 2>(a, L, b, ox, oy, oz, dx, dy, dz, z,
-                                                             [&](f32x16 (&acc2)[4], float hd0, float hd1, float hd2, float hd3) {
-                    __builtin_amdgcn_sched_barrier(0);
-                } PROF_PASS, cA);
-#endif
                 sample_eval<(CACHE == 2 ? HAV_GQ2 : 8), PREC, true, CACHE == 2>(a, L, b, ox, oy, oz, dx, dy, dz, z,
                                                              [&](f32x16 (&acc2)[4], float hd0, float hd1, float hd2, float hd3) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -2250,9 +1979,6 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                 accw += wgt;
                 wmax = fmaxf(wmax, wgt);
                 if (pass == 0 && S_fp > 0 && h == 0) { if (CACHE) wrow[s * 32 + j] = wgt; else if (rayok) wpark[s] = wgt; }
-#if HAV_WSUM_INLOOP
-                if (pass == 0 && s >= 1 && s <= S_c - 2) wsum += (wgt + 1e-5f);
-#endif
                 if (CACHE && pass == 0 && S_fp > 0 && !(s & 1)) park(s >> 1, acc2, hd0, hd1, hd2, hd3);
                 if (pass == 1 && a.dbg_zfine && h == 0 && rayok) a.dbg_zfine[gr * S_fp + s] = z;
                 // advance: dists[-1] repeats dists[-2] (:36-37)
@@ -2262,14 +1988,6 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                     dist = znext - z;
                 }
                 } PROF_PASS DBG_PASS(DBG_TILE(s)));
-#ifdef HAV_DEBUG_DUMP3
-                if (a.dbg_zfine && rayok && pass == 0 && a.S_fp > 0) {          // coarse tiles: even s -> planes 6/7 at entry s/2, odd s -> planes 8/9
-                    const int code = (cA[0] != cB[0] ? 1 : 0) | (cA[1] != cB[1] ? 2 : 0) | (cA[2] != cB[2] ? 4 : 0) | (cA[3] != cB[3] ? 8 : 0) |
-                                     (cA[4] != cB[4] ? 16 : 0) | (cA[5] != cB[5] ? 32 : 0) | (cA[6] != cB[6] ? 64 : 0) | (cA[7] != cB[7] ? 128 : 0) |
-                                     (cA[8] != cB[8] ? 256 : 0) | (cA[9] != cB[9] ? 512 : 0) | (cA[10] != cB[10] ? 1024 : 0) | (cA[11] != cB[11] ? 2048 : 0);
-                    a.dbg_zfine[(6 + 2 * (s & 1) + h) * ((long long)a.p.B * a.p.R * a.S_fp) + gr * a.S_fp + (s >> 1)] = (float)code;
-                }
-#endif
                 __builtin_amdgcn_sched_barrier(0);
                 TICK(7);
             }
@@ -2283,22 +2001,18 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
             // ---- inverse-CDF resampling (utils/nerf_util.py:76-117): one ray per lane, one sequential sweep over the CDF ----
             if (pass == 0 && S_fp > 0) {
                 const int nw = S_c - 2, nb = S_c - 1;
-#if HAV_WSUM_INLOOP
-                const float sum = wsum;
-#else
                 float sum = 0.f;
                 constexpr int SPF = HAV_RESAMPLE_PF;
                 for (int i0 = 0; i0 < nw; i0 += SPF) {          // SPF loads in flight per round trip, summed in index order
                     float t8[SPF];
 #pragma unroll
-                    for (int q = 0; q < SPF; ++q) t8[q] = (i0 + q < nw) ? (CACHE ? HAV_SELF_LOAD(&wrow[(1 + i0 + q) * 32 + j]) : __builtin_nontemporal_load(&wpark[1 + i0 + q])) : 0.f;
+                    for (int q = 0; q < SPF; ++q) t8[q] = (i0 + q < nw) ? (CACHE ? *(&wrow[(1 + i0 + q) * 32 + j]) : __builtin_nontemporal_load(&wpark[1 + i0 + q])) : 0.f;
 #pragma unroll
                     for (int q = 0; q < SPF; ++q) if (i0 + q < nw) sum += (t8[q] + 1e-5f);
                 }
-#endif
                 // the weights come back through an 8-deep rotation of registers: a lone load in this phase queues behind the other waves' tap
                 // loads in the texture path (~1 K cycles each, measured: the two passes over 62 weights were 170 K cycles per block)
-                auto wload = [&](int i) -> float { return (i < nw) ? (CACHE ? HAV_SELF_LOAD(&wrow[(1 + i) * 32 + j]) : __builtin_nontemporal_load(&wpark[1 + i])) : 0.f; };
+                auto wload = [&](int i) -> float { return (i < nw) ? (CACHE ? *(&wrow[(1 + i) * 32 + j]) : __builtin_nontemporal_load(&wpark[1 + i])) : 0.f; };
                 constexpr int WPF = HAV_RESAMPLE_PF;
                 float wq[WPF];
 #pragma unroll
@@ -2350,38 +2064,18 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
         wave_lds_sync();
     }       // blocks
 #undef RAY_FENCE
-#ifdef HAV_PROFILE
-    P.acc[10] = __builtin_amdgcn_s_memtime() - t_kernel0;
-    if (lane == 0)
-        for (int i = 0; i < HAV_NPROF; ++i) atomicAdd(&g_prof[i], P.acc[i]);
-#endif
+    PROF_END(lane);
 }
 
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-#ifdef HAV_PROFILE
-// phase-timing build only: copy (and clear) the per-phase cycle sums
-extern "C" int hav_debug_read_prof(unsigned long long* out12)
-{
-    hipError_t e = hipDeviceSynchronize();
-    if (e == hipSuccess) e = hipMemcpyFromSymbol(out12, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * HAV_NPROF);
-    unsigned long long z[HAV_NPROF] = {};
-    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z));
-    return (int)e;
-}
-#endif
-// Process-wide knobs of timing experiments (results are wrong when set), read from the environment ONCE: HAV_ABLATE bit mask,
-// HAV_STAGGER.  Everything that selects behaviour per call travels in HavRenderParams (mlp_mode, flags, dbg_zfine, status).
+// Lab builds (-DHAV_LAB, hav_render_lab.h) read the timing-experiment knobs HAV_ABLATE / HAV_STAGGER from the environment once; the shipped
+// library reads no environment variable at all: everything that selects behaviour per call travels in HavRenderParams.
 struct EnvKnobs { int ablate, stagger; };
 static const EnvKnobs& env_knobs()
 {
-    static const EnvKnobs k = [] {
-        EnvKnobs r{0, 0};
-        if (const char* e = getenv("HAV_ABLATE")) r.ablate = atoi(e);
-        if (const char* e = getenv("HAV_STAGGER")) r.stagger = atoi(e);
-        return r;
-    }();
+    static const EnvKnobs k{LAB_ENV_INT("HAV_ABLATE"), LAB_ENV_INT("HAV_STAGGER")};
     return k;
 }
 
@@ -2399,12 +2093,15 @@ static int march_grid_blocks(const HavRenderParams* p)
     if (needb < gridb) gridb = (int)((needb + 7) / 8 * 8);
     return gridb;
 }
-// 0 = exact f32 MFMA, 1 = bf16 triple split, 2 = fp16 double split
-static int mlp_prec(const HavRenderParams* p) { return p->mlp_mode == HAV_MLP_F32 ? 0 : (p->mlp_mode == HAV_MLP_SPLIT_F16 ? 2 : 1); }
+// 0 = exact f32 MFMA, 1 = bf16 triple split, 2 = fp16 double split, 3 = fp16 double split + MX correction terms
+static int mlp_prec(const HavRenderParams* p)
+{
+    return p->mlp_mode == HAV_MLP_F32 ? 0 : (p->mlp_mode == HAV_MLP_SPLIT_F16 ? 2 : (p->mlp_mode == HAV_MLP_SPLIT_F16_MX ? 3 : 1));
+}
 static long long fine_cache_slot_floats(const HavRenderParams* p)
 {
     const long long S_fp = (p->S_c + 1) / 2 + p->S_f;
-    return S_fp * (((mlp_prec(p) == 2 && HAV_FEATPARK) ? WS_H2_FLOATS / 2 : WS_H2_FLOATS) + 128 + 32)       // features (fp16 mode) or hidden units
+    return S_fp * (((mlp_prec(p) == 2) ? WS_H2_FLOATS / 2 : WS_H2_FLOATS) + 128 + 32)       // features (fp16 mode) or hidden units
            + (long long)((p->S_c + 3) & ~3) * 32;                                                // + the coarse weights of the block, [S_c][32]
 }
 // Would a workspace be used at all?  Measured on MI355X: with stratified jitter on (the production setting)
@@ -2452,7 +2149,7 @@ static MarchVariant pick_variant(const HavRenderParams* p, bool no_coarse_out, b
     v.rm = !random ? 0 : ((injected || v.prec == 0) ? 2 : 1);              // (the f32 mode only instantiates the injected-tensor RNG variant)
     const bool cache = use_fine_cache(p);
     v.cm = !cache ? 0 : (no_coarse_out ? 2 : (v.prec == 2 ? 0 : 1));
-    v.guard = v.prec == 2 && !(p->flags & HAV_FLAG_NO_FP16_GUARD);
+    v.guard = v.prec >= 2 && !(p->flags & HAV_FLAG_NO_FP16_GUARD);          // both fp16-based modes convert weights and activations to fp16
     return v;
 }
 
@@ -2475,11 +2172,13 @@ struct BlkEntry { int rm, prec, cm; const void* fn; void (*launch)(int, size_t, 
 static const BlkEntry kBlk[] = {
 #ifdef HAV_FAST_BUILD      // development builds: the production kernel only (seconds instead of a minute per compile)
     BLK(0, 2, 2), BLK(1, 2, 2), BLK(0, 1, 0), BLK(1, 1, 0),       // + the fp16 guard's bf16 stand-ins
-    BLK(0, 1, 2), BLK(1, 1, 2)};                                  // + the bf16 production pair
+    BLK(0, 1, 2), BLK(1, 1, 2),                                   // + the bf16 production pair
+    BLK(0, 3, 2), BLK(1, 3, 2)};                                  // + the fp16 + MX production pair
 #else
     BLK(0, 0, 0), BLK(2, 0, 0),
     BLK(0, 1, 0), BLK(1, 1, 0), BLK(2, 1, 0), BLK(0, 1, 1), BLK(1, 1, 1), BLK(2, 1, 1), BLK(0, 1, 2), BLK(1, 1, 2), BLK(2, 1, 2),
-    BLK(0, 2, 0), BLK(1, 2, 0), BLK(2, 2, 0), BLK(0, 2, 2), BLK(1, 2, 2), BLK(2, 2, 2)};
+    BLK(0, 2, 0), BLK(1, 2, 0), BLK(2, 2, 0), BLK(0, 2, 2), BLK(1, 2, 2), BLK(2, 2, 2),
+    BLK(0, 3, 0), BLK(1, 3, 0), BLK(2, 3, 0), BLK(0, 3, 1), BLK(1, 3, 1), BLK(2, 3, 1), BLK(0, 3, 2), BLK(1, 3, 2), BLK(2, 3, 2)};
 #endif
 #undef BLK
 static const BlkEntry* find_blk(int rm, int prec, int cm)
@@ -2499,7 +2198,8 @@ extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, cons
     if (p->plane_res < 2 || p->vol_res < 2) return HAV_EINVAL;
     if (p->S_c > 256 || p->S_f > 128) return HAV_EUNSUP;
     if ((p->flags & ~HAV_FLAGS_ALL) || ((p->flags & HAV_FLAG_FINE_CACHE) && (p->flags & HAV_FLAG_FINE_RECOMPUTE))) return HAV_EINVAL;
-    if (p->mlp_mode != HAV_MLP_SPLIT_BF16 && p->mlp_mode != HAV_MLP_F32 && p->mlp_mode != HAV_MLP_SPLIT_F16) return HAV_EINVAL;
+    if (p->mlp_mode != HAV_MLP_SPLIT_BF16 && p->mlp_mode != HAV_MLP_F32 && p->mlp_mode != HAV_MLP_SPLIT_F16 && p->mlp_mode != HAV_MLP_SPLIT_F16_MX)
+        return HAV_EINVAL;
     // the coarse pass's composited outputs may be declined (all three NULL) when there is a fine pass: Trainer.forward then only
     // uses the fine ones, and the kernel drops the accumulators that exist for them
     const bool no_coarse_out = !out->rgb_coarse && !out->depth_coarse && !out->acc_coarse;
@@ -2560,7 +2260,7 @@ extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, cons
     if (v.blk) {
         a.scr_floats = ((p->S_f > 0 ? p->S_f : 1) * 32 + 3) & ~3;
         auto lds_of = [&](int prec) {
-            return ((size_t)(prec == 2 ? LDSH_FLOATS : (prec == 1 ? LDS3_FLOATS : LDS_FLOATS)) + HAV_LDS_BIAS + (size_t)MARCH_WAVES * a.scr_floats + 4) * sizeof(float);
+            return ((size_t)(prec == 3 ? LDSX_FLOATS : (prec == 2 ? LDSH_FLOATS : (prec == 1 ? LDS3_FLOATS : LDS_FLOATS))) + HAV_LDS_BIAS + (size_t)MARCH_WAVES * a.scr_floats) * sizeof(float);
         };
         if (lds_of(v.prec) > 160 * 1024 || (v.guard && lds_of(1) > 160 * 1024)) return HAV_EUNSUP;
         const int gridb = march_grid_blocks(p);
@@ -2602,6 +2302,103 @@ extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, cons
         HAV_LAUNCH_CHECK();
     }
     if (p->rng_counter && random) { hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, st, (unsigned long long*)p->rng_counter); HAV_LAUNCH_CHECK(); }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Test hook (include/havatar.h: hav_debug_mlp_layer): one dense layer of the radiance MLP, WITHOUT its activation, evaluated by the very
+// matrix routine the march kernel uses in `mlp_mode` -- so that the arithmetic modes can be held against an fp64 product directly
+// (tests/test_render_gpu.py, tools/err_modes.py) instead of through 80 compositing steps that hide the last three bits.
+// ------------------------------------------------------------------------------------------------
+template <int PREC, int LAYER>
+__global__ void __launch_bounds__(64) debug_mlp_layer_kernel(float* __restrict__ y, const float* __restrict__ x, const float* __restrict__ blob, long long n)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
+    {
+        const int base = PREC == 0 ? 0 : (PREC == 1 ? OFF_A1S : OFF_A1H);
+        const int cnt = PREC == 0 ? OFF_W4 : (PREC == 1 ? LDS3_FLOATS : LDSX_FP16);
+        for (int i = lane; i < cnt / 4; i += 64) reinterpret_cast<float4*>(smem)[i] = reinterpret_cast<const float4*>(blob + base)[i];
+        if (PREC == 3)
+            for (int i = lane; i < MX_GROUPS * MX_G_DWORDS / 4; i += 64) reinterpret_cast<float4*>(smem + LDSX_FP16)[i] = reinterpret_cast<const float4*>(blob + OFF_MX)[i];
+    }
+    __syncthreads();
+    const uint4* sA1 = reinterpret_cast<const uint4*>(smem);
+    const uint4* sA2 = reinterpret_cast<const uint4*>(smem + (PREC >= 2 ? (OFF_A2H - OFF_A1H) : (OFF_A2S - OFF_A1S)));
+    const unsigned int* sMX = reinterpret_cast<const unsigned int*>(smem + LDSX_FP16);
+    constexpr int KIN = LAYER == 1 ? 48 : 128;
+    for (long long tile = blockIdx.x; tile * 32 < n; tile += gridDim.x) {
+        const long long q = tile * 32 + j;
+        const long long qc = q < n ? q : n - 1;
+        f32x16 acc[4], in[4];
+        float pe[KPE_STEPS];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[m][r] = blob[(LAYER == 1 ? OFF_B1 : OFF_B2) + acc_row(m, r, h)];
+                in[m][r] = LAYER == 2 ? x[qc * KIN + acc_row(m, r, h)] : 0.f;
+            }
+#pragma unroll
+        for (int k = 0; k < KPE_STEPS; ++k) pe[k] = LAYER == 1 ? x[qc * KIN + 24 * h + k] : 0.f;
+        auto get1 = [&](int c, float (&v)[8]) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = pe[8 * c + e];
+        };
+        auto get2 = [&](int ch, float (&v)[8]) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = in[ch >> 1][8 * (ch & 1) + e];
+        };
+        if (LAYER == 1) {
+            if (PREC == 3) mfma_split2x<3, false>(acc, sA1, sMX, lane, get1);
+            else if (PREC == 2) mfma_split2h<3, 4>(acc, sA1, lane, get1);
+            else if (PREC == 1) mfma_split3<3>(acc, sA1, lane, get1);
+            else {
+#pragma unroll
+                for (int t = 0; t < KPE_STEPS; ++t)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(smem[OFF_W1PE + (t * 4 + m) * 64 + lane], pe[t], acc[m], 0, 0, 0);
+            }
+        } else {
+            if (PREC == 3) mfma_split2x<8, true>(acc, sA2, sMX + 4 * MX_G_DWORDS, lane, get2);
+            else if (PREC == 2) mfma_split2h<8, 4>(acc, sA2, lane, get2);
+            else if (PREC == 1) mfma_split3<8>(acc, sA2, lane, get2);
+            else {
+#pragma unroll
+                for (int ks = 0; ks < K2_STEPS; ++ks)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(smem[OFF_W2 + (ks * 4 + m) * 64 + lane], in[ks >> 4][ks & 15], acc[m], 0, 0, 0);
+            }
+        }
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+        if (q < n) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) y[q * 128 + acc_row(m, r, h)] = acc[m][r];
+        }
+    }
+}
+
+extern "C" int hav_debug_mlp_layer(float* y, const float* x, const void* mlp_blob, int mlp_mode, int layer, int64_t n, void* stream)
+{
+    if (!y || !x || !mlp_blob || n < 0 || (layer != 1 && layer != 2)) return HAV_EINVAL;
+    if (n == 0) return 0;
+    const int prec = mlp_mode == HAV_MLP_F32 ? 0 : (mlp_mode == HAV_MLP_SPLIT_BF16 ? 1 : (mlp_mode == HAV_MLP_SPLIT_F16 ? 2 : (mlp_mode == HAV_MLP_SPLIT_F16_MX ? 3 : -1)));
+    if (prec < 0) return HAV_EINVAL;
+    const size_t lds = (size_t)(prec == 0 ? OFF_W4 : (prec == 1 ? LDS3_FLOATS : (prec == 2 ? LDSX_FP16 : LDSX_FLOATS))) * sizeof(float);
+    const void* fn[4][2] = {{(const void*)debug_mlp_layer_kernel<0, 1>, (const void*)debug_mlp_layer_kernel<0, 2>},
+                            {(const void*)debug_mlp_layer_kernel<1, 1>, (const void*)debug_mlp_layer_kernel<1, 2>},
+                            {(const void*)debug_mlp_layer_kernel<2, 1>, (const void*)debug_mlp_layer_kernel<2, 2>},
+                            {(const void*)debug_mlp_layer_kernel<3, 1>, (const void*)debug_mlp_layer_kernel<3, 2>}};
+    hipError_t er = hipFuncSetAttribute(fn[prec][layer - 1], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (er != hipSuccess) return (int)er;
+    const long long tiles = (n + 31) / 32;
+    const int grid = (int)(tiles < hav_num_cus() ? tiles : hav_num_cus());
+    float* yy = y; const float* xx = x; const float* bb = (const float*)mlp_blob; long long nn = n;
+    void* args[] = {&yy, &xx, &bb, &nn};
+    er = hipLaunchKernel(fn[prec][layer - 1], dim3(grid), dim3(64), args, lds, (hipStream_t)stream);
+    if (er != hipSuccess) return (int)er;
     return 0;
 }
 

@@ -79,6 +79,9 @@ class GraphedTrainStep:
     def __call__(self, **tensors):
         for k, v in tensors.items():
             self.static[k].copy_(v, non_blocking=True)
+        from .native import conv as _nconv
+        if _nconv._NAN_TRACE is not None:          # development aid: the replay's is-finite flags start from zero
+            _nconv.nan_trace_reset(next(iter(self.static.values())).device)
         self.graph.replay()
         bump_weights_epoch()
         return self.loss, self.aux

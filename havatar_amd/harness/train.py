@@ -59,6 +59,9 @@ def training_loss(trainer, cfg, inp, target, ray_mask, rgb_loss_func, percep_los
     """One forward of the step and its scalar loss (train_avatar.py:121-146).  Returns (loss, parts, psnr)."""
     rgb_coarse, _, acc_coarse, weights, rgb_fine, _, acc_fine, latent_code_loss = trainer(**inp)
     sw_grad_loss = skin_weight_smoothness(trainer)
+    if rgb_coarse.is_cuda:
+        from ..native import conv as _nconv
+        _nconv._trace("Trainer outputs rgb_c,acc_c,weights,rgb_f,acc_f", rgb_coarse, acc_coarse, weights, rgb_fine, acc_fine)      # (development aid; a no-op unless HAVATAR_NAN_TRACE)
     parts = {"coarse_loss": rgb_loss_func(rgb_coarse[..., :3], target[..., :3]),
              "mask_coarse_loss": F.binary_cross_entropy(acc_coarse.clip(1e-3, 1.0 - 1e-3), ray_mask)}
     if rgb_fine is not None:
@@ -152,6 +155,7 @@ class StepRunner:
                 from ..native import conv as _nconv
                 if _nconv._NAN_TRACE is not None:
                     _nconv._NAN_TRACE.clear()          # (development aid: keep the flags of the captured step only)
+                    _nconv.nan_trace_reset(dev)        # (its flag buffer exists before the capture: never a graph-pool block)
                 if self.side is None:
                     self.side = torch.cuda.Stream(device=dev)
                 self.side.wait_stream(torch.cuda.current_stream(dev))

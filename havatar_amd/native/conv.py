@@ -30,15 +30,59 @@ def _autoscale_default():
     return os.environ.get("HAVATAR_CONV_AUTOSCALE", "1") != "0"
 
 
-_NAN_TRACE = [] if os.environ.get("HAVATAR_NAN_TRACE") else None          # development aid (tools/flake_hunt.sh): is-finite flags per tensor,
-                                                                           # evaluated INSIDE a captured step at every replay
+# Development aid (tools/graph_anomaly_hunt.py, tests/test_harness.py): is-finite flags per operand / result of the wrappers below, evaluated
+# INSIDE a captured step at every replay.  HAVATAR_NAN_TRACE=1: torch.isfinite(t).all() -- two ATen launches and two temporaries per tensor in
+# the graph's memory pool.  HAVATAR_NAN_TRACE=2 (what the tests use): one hav_debug_nonfinite launch per tensor into a flag buffer that is
+# allocated OUTSIDE any graph pool -- no temporaries; the buffer is zeroed by nan_trace_reset() before a step / replay.
+_NAN_MODE = int(os.environ.get("HAVATAR_NAN_TRACE", "0") or 0)
+_NAN_TRACE = [] if _NAN_MODE else None
+_NAN_BUF = {}          # device -> int32 flag buffer (mode 2)
+_NAN_BUF_WORDS = 8192
+
+
+class _Flag:
+    """truthy iff the traced tensor was finite (mode 2: word i of the flag buffer is still 0)"""
+
+    def __init__(self, buf, i):
+        self.buf, self.i = buf, i
+
+    def __bool__(self):
+        return int(self.buf[self.i]) == 0
+
+
+def _nan_buf(device):
+    b = _NAN_BUF.get(device)
+    if b is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("nan trace: allocate the flag buffer before the capture (nan_trace_reset(device))")
+        b = _NAN_BUF[device] = torch.zeros(_NAN_BUF_WORDS, dtype=torch.int32, device=device)
+    return b
+
+
+def nan_trace_reset(device):
+    """zero the flag words on the current stream (before an eager step or a graph replay); allocates the buffer on first use"""
+    if _NAN_TRACE is not None and _NAN_MODE != 1:
+        _nan_buf(torch.device(device)).zero_()
 
 
 def _trace(name, *ts):
-    if _NAN_TRACE is not None:
-        for k, t in enumerate(ts):
-            if t is not None:
-                _NAN_TRACE.append(("%s[%d]%s" % (name, k, tuple(t.shape)), torch.isfinite(t if t.is_floating_point() else t.view(torch.float32)).all()))
+    if _NAN_TRACE is None:
+        return
+    for k, t in enumerate(ts):
+        if t is None:
+            continue
+        label = "%s[%d]%s" % (name, k, tuple(t.shape))
+        if _NAN_MODE == 1:
+            _NAN_TRACE.append((label, torch.isfinite(t if t.is_floating_point() else t.view(torch.float32)).all()))
+            continue
+        if not t.is_contiguous() or t.element_size() != 4:
+            continue
+        buf, i = _nan_buf(t.device), len(_NAN_TRACE)
+        if i >= _NAN_BUF_WORDS:
+            continue
+        with torch.cuda.device(t.device):
+            _lib.check(_lib.lib().hav_debug_nonfinite(C.c_void_p(buf.data_ptr() + 4 * i), _p(t), t.numel(), _stream(t.device)), "hav_debug_nonfinite")
+        _NAN_TRACE.append((label, _Flag(buf, i)))
 
 
 def _absmax(t, st):

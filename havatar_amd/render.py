@@ -36,6 +36,15 @@ def _chk_f32_cuda(name, t, allow_none=False):
     return t.contiguous()
 
 
+# HAVATAR_MLP -> HavRenderParams.mlp_mode.  "mx": fp16 hi + lo for the three leading partial products + block-scaled 4- / 6-bit matrix
+# instructions for the three terms of order 2^-22 (operands hi + lo + tail = the fp32 value; 0.65 of the bf16 split's matrix time);
+# "split": every operand = hi + mid + lo bf16 exactly, six partial products; "half": the fp16 double split alone (22-bit operands:
+# NARROWER than the reference's fp32, the fastest); "f32": exact fp32 MFMA (an fmaf chain).
+MLP_MODES = {"mx": _lib.HAV_MLP_SPLIT_F16_MX, "split": _lib.HAV_MLP_SPLIT_BF16, "bf16": _lib.HAV_MLP_SPLIT_BF16, "half": _lib.HAV_MLP_SPLIT_F16,
+             "fp16": _lib.HAV_MLP_SPLIT_F16, "f32": _lib.HAV_MLP_F32}
+DEFAULT_MLP = "split"
+
+
 class RayMarcher:
     """Device state + launcher for `hav_render_rays`."""
 
@@ -50,11 +59,8 @@ class RayMarcher:
         self.rng_counter = None
         self.rng_offset = 0
         self.seed = 0x9E3779B97F4A7C15
-        # arithmetic of the two dense layers (include/havatar.h).  Default: the bf16 triple split -- every operand = hi + mid + lo bf16
-        # exactly (24 bits, as wide as the reference's fp32), six partial products.  HAVATAR_MLP=half selects the fp16 double split
-        # (22-bit operands: narrower than fp32, ~25 % faster), HAVATAR_MLP=f32 the exact fp32 MFMA (an fmaf chain).
-        self.mlp_mode = {"f32": _lib.HAV_MLP_F32, "half": _lib.HAV_MLP_SPLIT_F16, "fp16": _lib.HAV_MLP_SPLIT_F16}.get(
-            os.environ.get("HAVATAR_MLP", "split"), _lib.HAV_MLP_SPLIT_BF16)
+        # arithmetic of the two dense layers (include/havatar.h): MLP_MODES / DEFAULT_MLP below
+        self.mlp_mode = MLP_MODES.get(os.environ.get("HAVATAR_MLP", DEFAULT_MLP), MLP_MODES[DEFAULT_MLP])
         # fine-pass cache: re-use the coarse pass's field values for the even coarse samples the merged list repeats
         self.fine_cache = os.environ.get("HAVATAR_FINE_CACHE", "1") != "0"
         self._workspace = None
@@ -188,6 +194,19 @@ class RayMarcher:
         self.last_variant = self._variant_of(p, rgb_c is not None, any(t is not None for t in (t_rand, u_rand, noise_c, noise_f)))
         res = (rgb_c, d_c, a_c, wmax, rgb_f, d_f, a_f)
         return res + (zf,) if dbg_zfine else res
+
+    def mlp_layer(self, x, layer, mode=None):
+        """Test hook (hav_debug_mlp_layer): y [n,128] = W . x + b of dense layer 1 (x [n,48]: the positional-encoding columns) or 2
+        (x [n,128]) WITHOUT the activation, evaluated by the march kernel's matrix routine of `mode` (default: this marcher's)."""
+        x = _chk_f32_cuda("x", x)
+        n = x.shape[0]
+        if x.dim() != 2 or x.shape[1] != (48 if layer == 1 else 128):
+            raise RuntimeError("mlp_layer: x must be [n,48] (layer 1) or [n,128] (layer 2)")
+        y = torch.empty(n, 128, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().hav_debug_mlp_layer(_ptr(y), _ptr(x), _ptr(self.blob), self.mlp_mode if mode is None else mode, int(layer), n,
+                                                      _stream()), "hav_debug_mlp_layer")
+        return y
 
     def fp16_fallback_happened(self):
         """True if, since the last call of this method, the fp16 range guard made the bf16-split kernel render a call

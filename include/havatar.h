@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define HAV_ABI_VERSION 4
+#define HAV_ABI_VERSION 5
 
 #define HAV_EINVAL   (-1) /* bad size / null pointer / inconsistent arguments            */
 #define HAV_EUNSUP   (-2) /* valid for the reference, not supported by this build        */
@@ -212,6 +212,10 @@ int hav_conv3x3s2_split(float* y, const float* x, const void* packed, const floa
  * becomes Inf.  hav_gemm_split (`in_amax`) and both operands of hav_conv3x3_wgrad (`g_amax`, `x_amax`) take the same words. */
 #define HAV_ABSMAX_WORDS 256
 int hav_absmax(void* out_bits, const float* x, int64_t n, void* stream);
+/* Development aid of the graphed training step (havatar_amd/native/conv.py::_trace, HAVATAR_NAN_TRACE=2): *flag |= 1 iff one of the n
+ * words of x, read as float32, is Inf or NaN.  One launch, no allocation, no temporary: the caller owns `flag` (4 bytes, zeroed by the
+ * caller before the launch or the graph replay), so the check adds nothing to a captured graph's memory pool.  ABI 5. */
+int hav_debug_nonfinite(void* flag, const void* x, int64_t n, void* stream);
 
 /* Weight gradient of the same convolution (training): gw[o,i,ky,kx] = sum_{b,y,x} g[b,o,y,x] * x[b,i,y+ky-1,x+kx-1] on the split-fp16
  * matrix path (Cin % 32 == 0, Cout % 64 == 0, W % 16 == 0).  scratch: hav_conv3x3_wgrad_scratch_bytes() bytes (K-split partial sums);
@@ -317,7 +321,7 @@ typedef struct HavRenderParams {
     float   skin_scale[3], skin_trans[3];   /* ... of the skinning box (nerf_trainer.py:29-34)  */
     uint64_t seed;        /* key of the on-device xi/zeta/eps streams used when the rand pointers are NULL */
     uint64_t rng_offset;  /* counter base of the on-device streams (advance per call)          */
-    int32_t mlp_mode;     /* HAV_MLP_SPLIT_BF16 (0), HAV_MLP_F32 (1) or HAV_MLP_SPLIT_F16 (2)   */
+    int32_t mlp_mode;     /* HAV_MLP_SPLIT_BF16 (0), HAV_MLP_F32 (1), HAV_MLP_SPLIT_F16 (2) or HAV_MLP_SPLIT_F16_MX (3) */
     int32_t flags;        /* HAV_FLAG_* bit mask (0 = library defaults); unknown bits -> HAV_EINVAL */
     uint64_t* rng_counter; /* optional DEVICE counter: the call uses rng_offset + *rng_counter and increments the counter
                             * on the stream afterwards, so a hipGraph replay of a captured call draws fresh jitter    */
@@ -349,6 +353,13 @@ typedef struct HavRenderParams {
  *  HAV_MLP_F32:        v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fmaf chain. */
 #define HAV_MLP_SPLIT_BF16 0
 #define HAV_MLP_F32        1
+#define HAV_MLP_SPLIT_F16_MX 3    /* ABI 5.  hi + lo fp16 as in HAV_MLP_SPLIT_F16 for the three leading partial products, PLUS the three terms of
+                                  * order 2^-22 that mode drops (hi.tail, tail.hi, lo.lo; tail = v - hi - lo, exact) from one block-scaled
+                                  * 4- / 6-bit matrix instruction each per 64 k (v_mfma_scale_f32_32x32x64_f8f6f4; factors rounded to 2-4
+                                  * significant bits against per-(row, 32 k) / per-(query, 32 k) power-of-two scales: <= 2^-25 of the
+                                  * product).  Operands carry hi + lo + tail = the fp32 value itself; per-product error <= ~2^-24 -- the
+                                  * class of the bf16 triple split at 0.65 of its matrix time.  Same fp16 RANGE guard and bf16 stand-in
+                                  * as HAV_MLP_SPLIT_F16.  The Python layer's default since round 5 (HAVATAR_MLP=mx). */
 #define HAV_MLP_SPLIT_F16  2     /* each fp32 operand = hi + lo fp16 (both rounded to nearest: <= 2^-22 relative -- the size of the
                                   * fp32 accumulation error of a 128-term dot product), 3 products on v_mfma_f32_32x32x16_f16:
                                   * half the matrix time and two thirds of the LDS of the bf16 triple split -- 22-bit operands, i.e.
@@ -424,6 +435,12 @@ int hav_render_rays(const HavRenderParams* p, const float* rays, const float* bg
                     const void* mlp_blob, const float* t_rand, const float* u_rand,
                     const float* noise_c, const float* noise_f, const HavRenderOut* out,
                     void* stream);
+
+/* Test hook (ABI 5): one dense layer of the radiance MLP without its activation, evaluated by the matrix routine hav_render_rays uses
+ * in `mlp_mode` -- y[n,128] = W . x + b with layer 1: x [n,48] = the positional-encoding inputs of layers_xyz.0 (its columns 128..175,
+ * |x| <= 1), layer 2: x [n,128] >= 0 (layers_xyz.1 sees relu outputs; model/nerf_model.py:104-109).  Lets a test hold each arithmetic
+ * mode against an fp64 product directly.  mlp_blob: hav_mlp_pack output. */
+int hav_debug_mlp_layer(float* y, const float* x, const void* mlp_blob, int mlp_mode, int layer, int64_t n, void* stream);
 
 /* Name of the ray-march kernel variant hav_render_rays launches for these parameters ("hav_march_blk_kernel<RNG, PREC, CACHE>",
  * the same decision function the launch uses), written NUL-terminated into buf[len].  coarse_outputs = 0 if the call declines
