@@ -47,13 +47,20 @@ DTYPE = {"fp16x2": "f32 emulated as 2 x fp16 split-operand MFMA with fp32 accumu
                    "exponent range guarded on the device -- NARROWER than fp32: never the headline, reported as modes.fp16x2",
          "bf16x3": "f32 emulated exactly-split: every operand = hi + mid + lo bf16 = 24 significant bits (the fp32 value itself), six partial "
                    "products on v_mfma_f32_32x32x16_bf16 with fp32 accumulate (dropped terms <= 2^-23 relative): not narrower than fp32",
+         "fp16x2+mx": "f32 emulated, full-width operands: every operand = hi + lo fp16 + tail (= the fp32 value itself, >= 24 significant bits); the three "
+                      "leading partial products on v_mfma_f32_32x32x16_f16, the three terms of order 2^-22 (hi.tail, tail.hi, lo.lo) on block-scaled "
+                      "4-/6-bit v_mfma_scale_f32_32x32x64_f8f6f4 (factors to 2-4 bits: <= 2^-25 of the product), fp32 accumulate; per-product error "
+                      "<= 2^-23 like the bf16 triple split (tests/test_render_gpu.py::test_arithmetic_modes_of_the_dense_layers_against_fp64_products): not narrower than fp32",
          "f32": "f32 (v_mfma_f32_32x32x2_f32: bit-for-bit an fmaf chain)"}
 # arithmetic modes of the radiance MLP (include/havatar.h): key -> (HAVATAR_MLP value, operand bits, not narrower than the reference's fp32?)
-MODES = {"bf16x3": ("split", 24, True), "f32": ("f32", 24, True), "fp16x2": ("half", 22, False)}
-MODE_OF_ENV = {"split": "bf16x3", "bf16": "bf16x3", "half": "fp16x2", "f32": "f32"}
+MODES = {"fp16x2+mx": ("mx", 24, True), "bf16x3": ("split", 24, True), "f32": ("f32", 24, True), "fp16x2": ("half", 22, False)}
+DEFAULT_MODE = "fp16x2+mx"          # what the Python layer runs when HAVATAR_MLP is unset (havatar_amd/render.py::DEFAULT_MLP)
+MODE_OF_ENV = {"mx": "fp16x2+mx", "split": "bf16x3", "bf16": "bf16x3", "half": "fp16x2", "f32": "f32"}
 # matrix-core work the kernel executes per 32-sample tile: 11 k-chunks x 4 row tiles x 3 (fp16) / 6 (bf16) products of a
 # 16-bit 32x32x16 MFMA (32768 FLOP each), or 352 v_mfma_f32_32x32x2_f32 (4096 FLOP each) in the exact-fp32 mode
-EXEC_FLOP_PER_TILE = {"fp16x2": 132 * 32768, "bf16x3": 264 * 32768, "f32": 352 * 4096}
+# (fp16x2+mx: 132 fp16 products + 36 block-scaled 32x32x64 instructions of 131072 FLOP each, priced against the 16-bit peak like the rest)
+EXEC_FLOP_PER_TILE = {"fp16x2": 132 * 32768, "bf16x3": 264 * 32768, "f32": 352 * 4096, "fp16x2+mx": 132 * 32768 + 36 * 131072}
+EXEC_INSTR_PER_TILE = {"fp16x2": 132, "bf16x3": 264, "f32": 352, "fp16x2+mx": 168}
 # feature parking (fp16 cache kernels): the 48 parked tiles of the 80 evaluated per ray block also run fc_rgbFeat on
 # the matrix cores, 8 chunks x 2 row tiles x 3 products = 48 more -> 132 + 48 * 48/80 = 160.8 per evaluated tile (= SQ_INSTS_MFMA)
 PARK_FLOP_PER_TILE = 48 * 32768
@@ -421,6 +428,15 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)        # backend "nccl" IS RCCL on ROCm
+    # what the process group itself reports, for the driver's SCALE record: every rank contributes (1, its device index) to one all-reduce
+    ranks_seen = None
+    if dist.is_initialized():
+        probe = torch.tensor([1.0, float(local)], dtype=torch.float64, device=dev if not cpu else "cpu")
+        dist.all_reduce(probe)
+        ranks_seen = {"ranks": int(probe[0].item()), "backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                      "sum_of_local_device_indices": int(probe[1].item()),
+                      "devices_visible_to_this_rank": 0 if cpu else torch.cuda.device_count(),
+                      "visible_devices_env": os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")}
     sync = (lambda: None) if cpu else torch.cuda.synchronize
 
     from havatar_amd import synth
@@ -493,11 +509,11 @@ def main():
     elif all_modes:
         mode_list = list(MODES)                                 # bf16x3, f32, fp16x2: each gets its own timed loop
     else:
-        mode_list = [env_mode or "bf16x3"]
+        mode_list = [env_mode or DEFAULT_MODE]
     m = None
     if not cpu:
         from havatar_amd import _lib
-        MLP_CONST = {"bf16x3": _lib.HAV_MLP_SPLIT_BF16, "f32": _lib.HAV_MLP_F32, "fp16x2": _lib.HAV_MLP_SPLIT_F16}
+        MLP_CONST = {"bf16x3": _lib.HAV_MLP_SPLIT_BF16, "f32": _lib.HAV_MLP_F32, "fp16x2": _lib.HAV_MLP_SPLIT_F16, "fp16x2+mx": _lib.HAV_MLP_SPLIT_F16_MX}
         m = tr._hip_marcher()
 
     def set_mode(mode):
@@ -542,7 +558,7 @@ def main():
         dt, fps = loops["f32"]["dt"], loops["f32"]["fps"]
         if rank == 0:
             emit_line(({"metric": "rendered frames/sec @%d^2, 64 samples/ray" % H, "value": round(fps, 4), "unit": "frames/s",
-                              "n_gpus": 0, "ranks": world, "steps": args.steps, "warmup": args.warmup,
+                              "n_gpus": 0, "ranks": world, "rccl_ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
                               "scaling": "strong" if args.workload == "cfg3" else "weak", "vs_baseline": None, "dtype": "f32",
                               "data": "synthetic", "config": {"workload": args.workload + " (CPU plumbing mode: PyTorch statement of the path, gloo)",
@@ -639,7 +655,8 @@ def main():
         return {"kernel": kname, "kernel_ms": round(kms, 3), "achieved": round(FLOP_PER_FRAME / (kms * 1e-3) / 1e12, 3), "peak": peak / 1e12,
                 "frac": round(FLOP_PER_FRAME / (kms * 1e-3) / peak, 4), "field_evaluations_per_ray": {"reference": Q_PER_RAY, "executed": q_exec},
                 "mfma_executed_TFLOPs": round(exec_flop / (kms * 1e-3) / 1e12, 2), "mfma_executed_frac_of_peak": round(exec_flop / (kms * 1e-3) / peak, 4),
-                "mfma_instructions_per_launch_model": exec_flop // (4096 if mode == "f32" else 32768), "tiles": tiles}
+                "mfma_instructions_per_launch_model": EXEC_INSTR_PER_TILE[mode] * tiles + (48 * (H * W // 32) * ((S_C + 1) // 2 + S_F) if (mode == "fp16x2" and cached) else 0),
+                "tiles": tiles}
 
     if rank == 0:
         kname = variants[head]
@@ -684,7 +701,7 @@ def main():
         res = {
             "metric": ("stage-two HD frames/sec: 512^2 NeRF volume render (64 samples/ray) + SWGAN_unet upsampler to 1024^2" if args.workload == "cfg4"
                        else "rendered frames/sec @512^2, 64 samples/ray"), "value": round(fps, 3), "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "n_gpus": world, "rccl_ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "strong" if args.workload == "cfg3" else "weak", "vs_baseline": None, "dtype": DTYPE[head],
             "data": "synthetic",
             "config": {"batch": CFG3_NOTE % (args.frames, world, -(-args.frames // world)) if args.workload == "cfg3" else None,
@@ -716,7 +733,11 @@ def main():
                          "achieved": rf["achieved"], "peak": rf["peak"], "unit": "TFLOP/s", "frac": rf["frac"],
                          "traffic": traffic["bytes"] if traffic else None, "traffic_detail": traffic,
                          "kernel_ms": rf["kernel_ms"], "flop_per_launch": FLOP_PER_FRAME,
-                         "frac_of_fp32_mfma_peak": round(FLOP_PER_FRAME / (kms * 1e-3) / PEAK_FP32_MFMA, 4),
+                         "algebraic_reduction": {"algorithmic_flop_rate_over_fp32_mfma_peak": round(FLOP_PER_FRAME / (kms * 1e-3) / PEAK_FP32_MFMA, 4),
+                                                 "what": "NOT a fraction of a roofline: the reference network's FLOP per second over the fp32 matrix peak.  It exceeds 1 because "
+                                                         "the kernel does not execute those FLOP: layer 1's 128 plane columns are folded into the planes once per frame, the "
+                                                         "feature head is applied to composited hidden units, the fine pass re-uses the even coarse samples (80 of 112 "
+                                                         "evaluations), and what is left runs on the 16-bit pipe; the fraction of a peak is mfma_executed_frac_of_peak"},
                          "note": "the path's only dense contraction is the radiance MLP, so the roofline is priced in FLOP ('bound': mfma): "
                                  "achieved = ALGORITHMIC fp32 FLOP of the reference network (94848/query x 112 x 262144) / kernel time; peak = the "
                                  "dense peak of the matrix pipe the kernel runs on (16-bit MFMA 2.5 PFLOP/s in the split modes, where one fp32 "
@@ -736,7 +757,8 @@ def main():
             r_ = march_roofline(mode, kern_ms[mode])
             res["modes"][mode] = {"frames_per_s": round(loops[mode]["fps"], 3), "ms_per_step": round(1e3 * loops[mode]["dt"] / args.steps, 3),
                                   "timed_loop": True, "operand_bits": MODES[mode][1], "not_narrower_than_fp32": MODES[mode][2],
-                                  "kernel": r_["kernel"], "kernel_ms": r_["kernel_ms"], "roofline_frac": r_["frac"],
+                                  "kernel": r_["kernel"], "kernel_ms": r_["kernel_ms"],
+                                  "algorithmic_flop_rate_over_peak": r_["frac"],          # (> 1 in the exact-f32 mode: an algebraic-reduction factor, roofline.algebraic_reduction)
                                   "mfma_executed_frac_of_peak": r_["mfma_executed_frac_of_peak"], "dtype": DTYPE[mode]}
         res["extra"] = {}
         if world == 1 and args.workload == "cfg2" and args.extras:
@@ -766,6 +788,17 @@ def main():
                                         "config": r5["config"], "what": "BASELINE configs[4]: train_avatar.py's optimisation step (train_avatar.py:106-158), one hipGraph launch"}
             except Exception as e:
                 res["extra"]["cfg5"] = {"error": repr(e)[:300]}
+            # P13 / P14 at the cfg4 sizes under the driver's clock: tools/bench_ops.py --brief in its own process (every timed launch on its own
+            # buffers, >= 1 GiB of distinct memory per timed sequence: DRAM bandwidth, not the Infinity Cache)
+            try:
+                import subprocess
+                r_ops = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_ops.py"), "--brief"], capture_output=True, text=True, timeout=240)
+                rows_ops = json.loads(r_ops.stdout.strip().splitlines()[-1])
+                res["extra"]["ops"] = {"rows": rows_ops, "bound": "hbm", "peak_GBps": 8000,
+                                       "what": "fused_bias_act (P13) and upfirdn2d (P14) at BASELINE configs[3] sizes, f32: algorithmic bytes (in + out) / kernel "
+                                               "time (HIP events around a hipGraph of K back-to-back launches on K distinct buffer sets)"}
+            except Exception as e:
+                res["extra"]["ops"] = {"error": repr(e)[:300]}
         if not args.no_cpu_baseline and world == 1:          # (rank 0 at N = 1 only: at N > 1 the other ranks would sit in the final barrier)
             threads = os.cpu_count() or 1
             rows = args.cpu_rows or 8

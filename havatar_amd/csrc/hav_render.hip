@@ -866,10 +866,16 @@ __device__ __forceinline__ void mfma_split2h(f32x16 (&acc)[NM], const uint4* fra
 // NCH = 3 (layer 1: one group, slots 24-31 zero) or 8 (layer 2: two groups).  getv(ch, v[8]) as in mfma_split2h.
 typedef int i32x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x6_t __attribute__((ext_vector_type(6)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x32_t __attribute__((ext_vector_type(32)));
-__device__ __forceinline__ i32x8_t mx_op4(const uint4 a) { return i32x8_t{(int)a.x, (int)a.y, (int)a.z, (int)a.w, 0, 0, 0, 0}; }
-__device__ __forceinline__ i32x8_t mx_op6(const uint4 a, const uint2 b) { return i32x8_t{(int)a.x, (int)a.y, (int)a.z, (int)a.w, (int)b.x, (int)b.y, 0, 0}; }
+__device__ __forceinline__ i32x8_t mx_op4(const u32x4_t a) { return i32x8_t{(int)a[0], (int)a[1], (int)a[2], (int)a[3], 0, 0, 0, 0}; }
+__device__ __forceinline__ i32x8_t mx_op6(const u32x4_t a, const u32x2_t b) { return i32x8_t{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], 0, 0}; }
 __device__ __forceinline__ i32x8_t mx_op6(const u32x6_t a) { return i32x8_t{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)a[4], (int)a[5], 0, 0}; }
+// (tools/ubench/mx6_probe.hip T4: like v_mfma_f32_32x32x16_f16, the scaled instruction does NOT read its A / B / scale registers after issue.)
+#ifndef HAV_MX_TERMS
+#define HAV_MX_TERMS 7          // lab: bit 0 hi.tail, bit 1 tail.hi, bit 2 lo.lo
+#endif
 template <int NCH, bool DYN, typename GetV>
 __device__ __forceinline__ void mfma_split2x(f32x16 (&acc)[4], const uint4* frag /* fp16: [NCH][4 row tiles][2 parts][64 lanes] */,
                                              const unsigned int* mx /* this layer's records: [k group][4 row tiles][MX_G_DWORDS] */, int lane, GetV getv)
@@ -877,11 +883,16 @@ __device__ __forceinline__ void mfma_split2x(f32x16 (&acc)[4], const uint4* frag
     constexpr int NGRP = (NCH + 3) / 4;
 #pragma unroll
     for (int g = 0; g < NGRP; ++g) {
-        constexpr int dummy = 0; (void)dummy;
         const int nc = (NCH - 4 * g) < 4 ? (NCH - 4 * g) : 4;
         // ---- activations of the group: hi, lo (packed fp16: the B operands of the fp16 products) and the tails ----
         uint4 xh4[4], xl4[4];          // per chunk: 8 packed fp16 = the B operand of the chunk's fp16 products
-        f32x16 T0, T1;          // tails of the even / odd slots (the f32 conversion interleaves its two source vectors)
+        // tails as packed bf16 (the upper halves of the exact fp32 tails: 8 significant bits, of which the 6-bit format keeps 3).  NOT through
+        // v_cvt_scalef32_2xpk16_bf6_f32, the conversion that takes fp32 sources: in this kernel its results differed from launch to launch
+        // on two thirds of the rays (profiles/r05_mx_bisect.txt: the term that uses them alone breaks the bitwise repeatability, the other
+        // two conversions never do), while the bf16 / fp16-source forms are stable -- and the bf16 form needs half the registers.
+        typedef unsigned int u32x16_t __attribute__((ext_vector_type(16)));
+        typedef __bf16 bf16x32_t __attribute__((ext_vector_type(32)));
+        u32x16_t TB;
         float vmax = 0.f;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -908,15 +919,16 @@ __device__ __forceinline__ void mfma_split2x(f32x16 (&acc)[4], const uint4* frag
                 asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(t1) : "v"(pl), "v"(d1));
                 if (q == 0) { xh4[c].x = ph; xl4[c].x = pl; } else if (q == 1) { xh4[c].y = ph; xl4[c].y = pl; }
                 else if (q == 2) { xh4[c].z = ph; xl4[c].z = pl; } else { xh4[c].w = ph; xl4[c].w = pl; }
-                T0[4 * c + q] = t0; T1[4 * c + q] = t1;
+                TB[4 * c + q] = __builtin_amdgcn_perm(__float_as_uint(t1), __float_as_uint(t0), 0x07060302u);
                 if (DYN) vmax = fmaxf(vmax, fmaxf(fabsf(v0), fabsf(v1)));
             }
         }
         // per-lane block exponent E (biased) of the group: values < 2^(E - 126).  hi / 2^(E-130) < 16 (bf6: 28), |lo| / 2^(E-140) <= 4 (fp6: 7.5),
-        // |tail| / 2^(E-153) <= 8 (bf6).  An all-zero (or denormal) group keeps the bytes valid with E clamped from below.
+        // |tail| / 2^(E-153) <= 8 (bf6) -- where lo is a NORMAL fp16; below 2^-14 lo is rounded on the subnormal grid and the tail can reach
+        // 2^-25 whatever E is: its scale never goes below 2^-29 (tail / scale <= 16).  An all-zero group keeps the bytes valid the same way.
         unsigned int E = DYN ? (__float_as_uint(vmax) >> 23) : 127u;          // (PE inputs: |v| <= 1 + 1e-7 < 2)
         if (DYN) E = E < 40u ? 40u : (E > 254u ? 254u : E);
-        const unsigned int bh = E - 3u, bl = E - 13u, bt = E - 26u;
+        const unsigned int bh = E - 3u, bl = E - 13u, bt = (E - 26u) < 98u ? 98u : (E - 26u);
         const float sch = __uint_as_float(bh << 23), scl = __uint_as_float(bl << 23), sct = __uint_as_float(bt << 23);
         const int sbv = (int)(bh | (bl << 8) | (bt << 16));
         typedef _Float16 f16x16_t __attribute__((ext_vector_type(16)));
@@ -925,19 +937,18 @@ __device__ __forceinline__ void mfma_split2x(f32x16 (&acc)[4], const uint4* frag
             const f16x16_t b = __builtin_shufflevector(__builtin_bit_cast(f16x8_t, x[2]), __builtin_bit_cast(f16x8_t, x[3]), 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
             return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31);
         };
-        const f16x32_t H = cat32(xh4), Lo = cat32(xl4);
-        const i32x8_t H6 = mx_op6(__builtin_amdgcn_cvt_scalef32_pk32_bf6_f16(H, sch));
-        const i32x8_t L6 = mx_op6(__builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(Lo, scl));
-        const i32x8_t T6 = mx_op6(__builtin_amdgcn_cvt_scalef32_2xpk16_bf6_f32(T0, T1, sct));
-        // ---- the three correction terms, row tile by row tile (consecutive matrix instructions never share an accumulator) ----
+        const u32x6_t H6 = __builtin_amdgcn_cvt_scalef32_pk32_bf6_f16(cat32(xh4), sch);
+        const u32x6_t L6 = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(cat32(xl4), scl);
+        const u32x6_t T6 = __builtin_amdgcn_cvt_scalef32_pk32_bf6_bf16(__builtin_bit_cast(bf16x32_t, TB), sct);
+        // ---- the three correction terms, row tile by row tile ----
         const unsigned int* rec = mx + g * 4 * MX_G_DWORDS;
-        uint4 ah[2], at[2], ala[2]; uint2 alb[2]; int sc[2];
+        u32x4_t ah[2], at[2], ala[2]; u32x2_t alb[2]; int sc[2];
         auto ldrec = [&](int slot, int m) {
             const unsigned int* r = rec + m * MX_G_DWORDS;
-            ah[slot] = reinterpret_cast<const uint4*>(r)[lane];
-            at[slot] = reinterpret_cast<const uint4*>(r + 256)[lane];
-            ala[slot] = reinterpret_cast<const uint4*>(r + 512)[lane];
-            alb[slot] = reinterpret_cast<const uint2*>(r + 768)[lane];
+            ah[slot] = reinterpret_cast<const u32x4_t*>(r)[lane];
+            at[slot] = reinterpret_cast<const u32x4_t*>(r + 256)[lane];
+            ala[slot] = reinterpret_cast<const u32x4_t*>(r + 512)[lane];
+            alb[slot] = reinterpret_cast<const u32x2_t*>(r + 768)[lane];
             sc[slot] = (int)r[896 + lane];
         };
         ldrec(0, 0);
@@ -945,9 +956,9 @@ __device__ __forceinline__ void mfma_split2x(f32x16 (&acc)[4], const uint4* frag
         for (int m = 0; m < 4; ++m) {
             if (m + 1 < 4) ldrec((m + 1) & 1, m + 1);
             const int k = m & 1;
-            acc[m] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(mx_op4(ah[k]), T6, acc[m], 4, 3, 0, sc[k], 2, sbv);          // hi . tail
-            acc[m] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(mx_op4(at[k]), H6, acc[m], 4, 3, 1, sc[k], 0, sbv);          // tail . hi
-            acc[m] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(mx_op6(ala[k], alb[k]), L6, acc[m], 2, 2, 2, sc[k], 1, sbv);  // lo . lo
+            if (HAV_MX_TERMS & 1) acc[m] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(mx_op4(ah[k]), mx_op6(T6), acc[m], 4, 3, 0, sc[k], 2, sbv);          // hi . tail
+            if (HAV_MX_TERMS & 2) acc[m] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(mx_op4(at[k]), mx_op6(H6), acc[m], 4, 3, 1, sc[k], 0, sbv);          // tail . hi
+            if (HAV_MX_TERMS & 4) acc[m] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(mx_op6(ala[k], alb[k]), mx_op6(L6), acc[m], 2, 2, 2, sc[k], 1, sbv);  // lo . lo
         }
         // ---- the three leading products of the group's chunks on the fp16 instruction (as mfma_split2h) ----
         uint4 A[2][2];

@@ -66,6 +66,8 @@ class FieldInputs(Function):
                 rc = _lib.lib().hav_field_inputs_bwd(_p(dpl), _p(dvol), _p(dX), C.byref(p), _p(pts), _p(inv_T), _p(vol), _p(planes_cl),
                                                      _stream())
             _lib.check(rc, "hav_field_inputs_bwd")
+            from .conv import _trace
+            _trace("FieldInputs.bwd dX,dvol,dplanes,vol", dX, dvol, dpl, vol)          # (development aid; a no-op unless HAVATAR_NAN_TRACE)
         return None, None, dvol, dpl, None
 
 
@@ -111,6 +113,8 @@ class Composite(Function):
             rc = _lib.lib().hav_composite_bwd(_p(d_rf), _p(d_rgb), _p(d_acc), _p(d_w), _p(d_depth), _p(rf), _p(z), _p(rd), _p(noise),
                                               _p(bg), n, S, RW - 1, ctx.n_sigmoid, _stream())
         _lib.check(rc, "hav_composite_bwd")
+        from .conv import _trace
+        _trace("Composite.bwd d_rf,d_rgb,rf", d_rf, d_rgb, rf)
         return d_rf, None, None, None, None, None
 
 

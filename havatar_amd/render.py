@@ -42,7 +42,7 @@ def _chk_f32_cuda(name, t, allow_none=False):
 # NARROWER than the reference's fp32, the fastest); "f32": exact fp32 MFMA (an fmaf chain).
 MLP_MODES = {"mx": _lib.HAV_MLP_SPLIT_F16_MX, "split": _lib.HAV_MLP_SPLIT_BF16, "bf16": _lib.HAV_MLP_SPLIT_BF16, "half": _lib.HAV_MLP_SPLIT_F16,
              "fp16": _lib.HAV_MLP_SPLIT_F16, "f32": _lib.HAV_MLP_F32}
-DEFAULT_MLP = "split"
+DEFAULT_MLP = "mx"
 
 
 class RayMarcher:

@@ -41,7 +41,8 @@ def hip_render(sc, S_c, S_f, perturb=False, noise_std=0.0, t_rand=None, u_rand=N
     t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
     from havatar_amd import _lib
     rm = RayMarcher(sc["nerf_scale"], sc["nerf_trans"], sc["skin_scale"], sc["skin_trans"])
-    rm.mlp_mode = {"f32": _lib.HAV_MLP_F32, "half": _lib.HAV_MLP_SPLIT_F16}.get(mlp, _lib.HAV_MLP_SPLIT_BF16)
+    from havatar_amd.render import MLP_MODES
+    rm.mlp_mode = MLP_MODES[mlp]
     if flags is not None:
         rm.flags = flags
     m = sc["mlp"]
@@ -95,3 +96,56 @@ def pdf_floor_sensitive(sub, jitter, okw, nth=8):
         den_last = cdf[:, -1] - cdf[:, -2]
         slack = d["w_fine"][:, -2:].sum(-1) * np.minimum(1.0, 3.7e-6 / np.maximum(den_last, 1e-12))
     return flagged, slack
+
+
+def mlp_layer_errors(n_random=4096, seed=0):
+    """{(layer, input kind, mode): (max, rms)} of |y - y64| / (sum_k |w_k x_k| + |b|): one dense layer of the radiance MLP evaluated by each
+    arithmetic mode's own matrix routine (hav_debug_mlp_layer) against the fp64 product of the same fp32 weights and inputs.
+    Input kinds: "random" -- dense inputs (relu of normals for layer 2, uniform [-1,1] for the positional-encoding columns of layer 1) and
+    weights of mixed magnitude: the fp32 ACCUMULATION error of a 48- / 128-term sum dominates and every mode should look alike;
+    "onehot" -- one non-zero input per query and zero biases, every k position, full-mantissa operands of magnitude [1/8, 2): the result is
+    ONE product, so what is left is the mode's product error itself (fp32: 2^-24 from the final rounding; fp16 x 2: the dropped lo.lo /
+    hi.tail / tail.hi terms, up to ~2^-22); "onehot_small" -- the same with weights in [2^-8, 2^-3): their fp16 lo parts are fp16
+    SUBNORMALS (absolute operand error up to 2^-25 in the fp16 x 2 mode, include/havatar.h), which the MX mode's exact tails repair."""
+    import torch
+    from havatar_amd.render import MLP_MODES, RayMarcher
+    from havatar_amd import synth
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(seed)
+    sc = synth.scene(8, 8, "primary")
+    m = {k: np.array(v, np.float32) for k, v in sc["mlp"].items()}
+    out = {}
+    for kind in ("random", "onehot", "onehot_small"):
+        mm = dict(m)
+        for name in ("W1", "W2"):
+            shp = m[name].shape
+            if kind == "random":          # full-mantissa weights of mixed magnitude
+                mm[name] = (rng.standard_normal(shp) * np.exp2(rng.integers(-6, 1, shp))).astype(np.float32)
+            else:
+                lo, hi = (-2, 2) if kind == "onehot" else (-7, -2)
+                mm[name] = (rng.choice([-1.0, 1.0], shp) * rng.uniform(0.5, 1.0, shp) * np.exp2(rng.integers(lo, hi, shp))).astype(np.float32)
+        if kind != "random":
+            mm["b1"], mm["b2"] = np.zeros_like(m["b1"]), np.zeros_like(m["b2"])
+        rm = RayMarcher(sc["nerf_scale"], sc["nerf_trans"], sc["skin_scale"], sc["skin_trans"])
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+        rm.set_mlp(*[t(mm[k]) for k in ("W1", "b1", "W2", "b2", "Wa", "ba", "Wf", "bf", "Wc", "bc")])
+        for layer, K in ((1, 48), (2, 128)):
+            W = mm["W1"][:, 128:176] if layer == 1 else mm["W2"]
+            b = mm["b1"] if layer == 1 else mm["b2"]
+            if kind == "random":
+                x = rng.uniform(-1, 1, (n_random, K)) if layer == 1 else np.maximum(rng.standard_normal((n_random, K)), 0) * np.exp2(rng.integers(-3, 3, (n_random, 1)))
+            else:
+                reps = 8
+                x = np.zeros((K * reps, K))
+                vals = rng.uniform(0.5, 1.0, K * reps) * (np.exp2(rng.integers(-2, 2, K * reps)) if layer == 2 else np.exp2(rng.integers(-1, 1, K * reps)))
+                if layer == 1:
+                    vals *= rng.choice([-1.0, 1.0], K * reps)
+                x[np.arange(K * reps), np.repeat(np.arange(K), reps)] = vals
+            x = x.astype(np.float32)
+            y64 = x.astype(np.float64) @ W.astype(np.float64).T + b.astype(np.float64)
+            mag = np.abs(x).astype(np.float64) @ np.abs(W).astype(np.float64).T + np.abs(b).astype(np.float64)
+            for name in ("f32", "split", "half", "mx"):
+                y = rm.mlp_layer(t(x), layer, MLP_MODES[name]).cpu().numpy().astype(np.float64)
+                e = np.abs(y - y64) / np.maximum(mag, 1e-30)
+                out[(layer, kind, name)] = (float(e.max()), float(np.sqrt((e ** 2).mean())))
+    return out

@@ -141,23 +141,28 @@ def test_shard_frames_partition():
         assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
 
 
-@pytest.mark.parametrize("workload", ["cfg3"])          # (cfg2's N > 1 branch is the same code minus the gather)
-def test_bench_multi_rank_branch_runs_under_gloo(workload):
+@pytest.mark.parametrize("workload,ranks,frames", [("cfg3", 2, 3), ("cfg2", 8, 8), ("cfg3", 8, 11)])
+def test_bench_multi_rank_branch_runs_under_gloo(workload, ranks, frames):
     """bench.py's N > 1 branch (process group, barrier-bracketed timing, MAX over ranks, rank 0 prints one JSON line; for cfg3 the
-    round-by-round overlapped all_gather) executed for real: 2 processes under torch.distributed.run, CPU tensors, gloo."""
+    round-by-round overlapped all_gather) executed for real under torch.distributed.run, CPU tensors, gloo: 2 ranks, and the 8 ranks of
+    one MI355X node for both workloads (cfg3 with a ragged last round: 11 frames over 8 ranks).  `rccl_ranks_seen` is what the process
+    group itself reports (one all-reduce over all ranks): the field the driver's SCALE record can check N against."""
     import json
     import subprocess
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
-           "--device", "cpu", "--size", "8", "--workload", workload, "--frames", "3"]
-    env = dict(os.environ, OMP_NUM_THREADS="2")
-    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "1", "--warmup", "0",
+           "--device", "cpu", "--size", "8", "--workload", workload, "--frames", str(frames)]
+    env = dict(os.environ, OMP_NUM_THREADS="1" if ranks > 2 else "2")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout.decode()[-2000:]
     d = json.loads(lines[0])
-    assert d["ranks"] == 2 and d["steps"] == 1 and d["value"] > 0 and d["unit"] == "frames/s"
+    assert d["ranks"] == ranks and d["steps"] == 1 and d["value"] > 0 and d["unit"] == "frames/s"
+    seen = d["rccl_ranks_seen"]
+    assert seen["ranks"] == ranks and seen["world_size"] == ranks and seen["backend"] == "gloo"
+    assert seen["sum_of_local_device_indices"] == ranks * (ranks - 1) // 2          # every LOCAL_RANK 0..N-1 took part exactly once
     if workload == "cfg3":
-        assert d["scaling"] == "strong" and d["config"]["frames_per_step"] == 3 and d["config"]["gathered"] == [3, 3, 8, 8]
+        assert d["scaling"] == "strong" and d["config"]["frames_per_step"] == frames and d["config"]["gathered"] == [frames, 3, 8, 8]
     else:
-        assert d["scaling"] == "weak" and d["config"]["frames_per_step"] == 2
+        assert d["scaling"] == "weak" and d["config"]["frames_per_step"] == ranks

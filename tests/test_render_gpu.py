@@ -16,10 +16,16 @@ RENDER = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN,
 TOL = dict(rgb_coarse=2e-5, depth_coarse=1e-4, acc_coarse=2e-5, weights_max=1e-3, rgb_fine=1e-3, depth_fine=5e-3, acc_fine=1e-3)
 
 
-MLP_MODES = ("half", "split", "f32")      # the three matrix-core modes of the MLP (include/havatar.h: HAV_MLP_SPLIT_F16 / _SPLIT_BF16 / _F32)
+MLP_MODES = ("half", "split", "f32", "mx")      # the matrix-core modes of the MLP (include/havatar.h: HAV_MLP_SPLIT_F16 / _SPLIT_BF16 / _F32 / _SPLIT_F16_MX)
+SPLIT_MODES = ["split", "half", "mx"]           # the modes with a fine-pass cache
 
 
-PREC = {"f32": 0, "split": 1, "half": 2}
+def _mode(mlp):
+    from havatar_amd.render import MLP_MODES as table
+    return table[mlp]
+
+
+PREC = {"f32": 0, "split": 1, "half": 2, "mx": 3}
 FINE_KEYS = ("weights_max", "rgb_fine", "depth_fine", "acc_fine")
 
 
@@ -30,7 +36,7 @@ def expected_variant(cfg, kw, mlp, coarse_outputs, cache=None):
     prec = PREC[mlp]
     rm = 0 if not random else (2 if (kw or prec == 0) else 1)
     if cache is None:
-        cache = prec in (1, 2)
+        cache = prec in (1, 2, 3)
     cache = cache and prec != 0 and cfg["S_f"] > 0
     cm = 0 if not cache else (2 if not coarse_outputs else (0 if prec == 2 else 1))
     return "hav_march_blk_kernel<%d, %d, %d>" % (rm, prec, cm)
@@ -50,7 +56,7 @@ def test_hip_vs_reference_golden(name, mlp, coarse_outputs):
     assert o["variant"] == expected_variant(cfg, kw, mlp, coarse_outputs), o["variant"]
     assert not o["fp16_fallback"], "the fixtures are far inside the fp16 range: the guard must not trip"
     declined = o["variant"].endswith(", 2>")          # (without a cache kernel the library hands the coarse maps out anyway)
-    assert declined == (not coarse_outputs and mlp in ("half", "split"))
+    assert declined == (not coarse_outputs and mlp in SPLIT_MODES)
     for k in OUT_KEYS:
         if declined and k not in FINE_KEYS:
             assert o[k] is None, k
@@ -112,6 +118,30 @@ def test_split_and_f32_mlp_modes_agree():
     assert linf(a["rgb_fine"], b["rgb_fine"]) <= 1e-3 and linf(a["acc_fine"], b["acc_fine"]) <= 1e-3
 
 
+def test_arithmetic_modes_of_the_dense_layers_against_fp64_products():
+    """Each mode's OWN matrix routine (hav_debug_mlp_layer: the code the march kernel runs) on one dense layer against the fp64 product.
+    Dense random inputs: the fp32 accumulation of 48 / 128 terms dominates -- every mode within 1.5x the exact-fp32 chain.  One-hot inputs
+    with zero biases (a single product per output, every k position, full-mantissa operands): the mode's product error itself --
+    fp32 MFMA: <= 2^-24 (the final rounding); bf16 x 3 and fp16 x 2 + MX ("mx", the 24-bit modes): <= 2^-21.5 at worst, the same rms; fp16 x 2
+    alone drops the lo.lo / hi.tail / tail.hi terms and is measurably worse -- the MX correction terms are what closes that gap (they are NOT visible
+    through the rendered maps, where 80 compositing steps and the fp32 accumulation hide the last three bits)."""
+    from helpers import mlp_layer_errors
+    err = mlp_layer_errors()
+    for k in sorted(err):
+        print("layer %d %-12s %-5s  max %.3e (2^%.1f)  rms %.3e" % (k + (err[k][0], np.log2(max(err[k][0], 1e-30)), err[k][1])))
+    for layer in (1, 2):
+        base = err[(layer, "random", "f32")]
+        for mode in ("split", "half", "mx"):
+            assert err[(layer, "random", mode)][0] <= 1.5 * base[0] + 1e-8 and err[(layer, "random", mode)][1] <= 1.5 * base[1] + 1e-9, (layer, mode, err[(layer, "random", mode)], base)
+        for kind in ("onehot", "onehot_small"):
+            assert err[(layer, kind, "f32")][0] <= 2.0 ** -24 * 1.001, (layer, kind)
+            assert err[(layer, kind, "split")][0] <= 2.0 ** -21.7, (layer, kind, err[(layer, kind, "split")])      # hi + mid + lo exact; ml / lm / ll dropped, six roundings
+        assert err[(layer, "onehot", "mx")][0] <= 2.0 ** -21.3, err[(layer, "onehot", "mx")]
+        assert err[(layer, "onehot", "mx")][1] <= 1.25 * err[(layer, "onehot", "split")][1], (err[(layer, "onehot", "mx")], err[(layer, "onehot", "split")])
+        assert err[(layer, "onehot", "half")][0] >= 1.5 * err[(layer, "onehot", "mx")][0]          # the correction terms are doing something
+        assert err[(layer, "onehot_small", "mx")][0] <= 0.25 * err[(layer, "onehot_small", "half")][0]      # exact tails repair the subnormal lo parts
+
+
 @pytest.mark.parametrize("kernel", ["blk", "pair"])
 def test_pair_kernel_still_matches(kernel):
     """HAV_FLAG_PAIR_KERNEL forces the ray-pair kernel (used when S_c > 67): same results within the path tolerance."""
@@ -160,7 +190,7 @@ def test_full_occupancy_runs_are_bitwise_identical(mlp, perturb, coarse_outputs)
     dev = torch.device("cuda:0")
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
     rm = RayMarcher(sc["nerf_scale"], sc["nerf_trans"], sc["skin_scale"], sc["skin_trans"])
-    rm.mlp_mode = {"f32": _lib.HAV_MLP_F32, "split": _lib.HAV_MLP_SPLIT_BF16, "half": _lib.HAV_MLP_SPLIT_F16}[mlp]
+    rm.mlp_mode = _mode(mlp)
     rm.set_mlp(*[t(sc["mlp"][k]) for k in ("W1", "b1", "W2", "b2", "Wa", "ba", "Wf", "bf", "Wc", "bc")])
     rm.set_triplane(t(sc["planes"]))
     rays = t(synth.camera_rays(N, N))[None]
@@ -283,7 +313,7 @@ def test_bad_arguments_raise():
 
 
 @pytest.mark.parametrize("coarse_outputs", [True, False])
-@pytest.mark.parametrize("mlp", ["half", "split"])
+@pytest.mark.parametrize("mlp", SPLIT_MODES)
 @pytest.mark.parametrize("name", [n for n in RENDER if "coarse_only" not in n])
 def test_fine_pass_cache_matches_reference_and_the_recompute_path(name, mlp, coarse_outputs):
     """HavRenderParams.workspace: the fine pass re-uses the coarse pass's field values for the even coarse samples the merged list
@@ -317,11 +347,12 @@ def test_fine_pass_cache_is_the_default_with_jitter_and_needs_a_workspace(monkey
     rm = RayMarcher(sc["nerf_scale"], sc["nerf_trans"], sc["skin_scale"], sc["skin_trans"])
     from havatar_amd import _lib
     monkeypatch.delenv("HAVATAR_MLP", raising=False)
-    # the library's default arithmetic is the bf16 triple split (24-bit operands: as wide as the reference's fp32); the production
-    # kernel of Trainer.forward(render_full_img=True) is therefore <1, 1, 2>
+    # the library's default arithmetic is fp16 x 2 + MX (full-width operands hi + lo + tail: not narrower than the reference's fp32); the
+    # production kernel of Trainer.forward(render_full_img=True) is therefore <1, 3, 2>
     fresh = RayMarcher(sc["nerf_scale"], sc["nerf_trans"], sc["skin_scale"], sc["skin_trans"])
-    assert fresh.mlp_mode == _lib.HAV_MLP_SPLIT_BF16
-    assert fresh.variant(64, 16, perturb=True, coarse_outputs=False).endswith("<1, 1, 2>")
+    assert fresh.mlp_mode == _lib.HAV_MLP_SPLIT_F16_MX
+    assert fresh.variant(64, 16, perturb=True, coarse_outputs=False).endswith("<1, 3, 2>")
+    assert fresh.variant(64, 16, perturb=True).endswith("<1, 3, 1>") and fresh.variant(64, 16, perturb=False, coarse_outputs=False).endswith("<0, 3, 2>")
     rm.mlp_mode = _lib.HAV_MLP_SPLIT_F16
     # fp16 mode (HAVATAR_MLP=half): the cache serves the fine-maps-only calls (with or without jitter); a call that also wants the coarse
     # maps evaluates every merged sample (the fp16 kernels that would do both are not dispatched).
@@ -340,7 +371,7 @@ def test_fine_pass_cache_is_the_default_with_jitter_and_needs_a_workspace(monkey
     assert rm.variant(64, 0, perturb=True).endswith(", 0>")        # no fine pass, nothing to cache
 
 
-@pytest.mark.parametrize("mlp", ["split", "half"])
+@pytest.mark.parametrize("mlp", SPLIT_MODES)
 def test_declined_coarse_outputs_leave_the_fine_maps_unchanged(mlp):
     """HavRenderOut with the three coarse pointers NULL (Trainer.forward(render_full_img=True) only uses the fine maps): the fine
     maps equal those of a call that asks for everything, in every kernel variant that accepts the request."""
@@ -351,7 +382,7 @@ def test_declined_coarse_outputs_leave_the_fine_maps_unchanged(mlp):
     dev = torch.device("cuda:0")
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
     rm = RayMarcher(sc["nerf_scale"], sc["nerf_trans"], sc["skin_scale"], sc["skin_trans"])
-    rm.mlp_mode = {"split": _lib.HAV_MLP_SPLIT_BF16, "half": _lib.HAV_MLP_SPLIT_F16}[mlp]
+    rm.mlp_mode = _mode(mlp)
     rm.set_mlp(*[t(sc["mlp"][k]) for k in ("W1", "b1", "W2", "b2", "Wa", "ba", "Wf", "bf", "Wc", "bc")])
     rm.set_triplane(t(sc["planes"]))
     args = (t(sc["rays"]), t(sc["bg"]), t(sc["inv_T"]), t(sc["vol"]), 64, 16)
@@ -367,7 +398,7 @@ def test_declined_coarse_outputs_leave_the_fine_maps_unchanged(mlp):
             assert (a_ - b_).abs().max().item() <= 2e-5
 
 
-@pytest.mark.parametrize("mlp", ["split", "half"])
+@pytest.mark.parametrize("mlp", SPLIT_MODES)
 @pytest.mark.parametrize("perturb", [False, True, "injected"])
 def test_production_variants_512_frame_24_launches(perturb, mlp):
     """The production kernels <0|1|2, 1, 2> (bf16 triple split: the default arithmetic) and <0|1|2, 2, 2> (fp16 double split) on the full
@@ -386,7 +417,7 @@ def test_production_variants_512_frame_24_launches(perturb, mlp):
     dev = torch.device("cuda:0")
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
     rm = RayMarcher(sc["nerf_scale"], sc["nerf_trans"], sc["skin_scale"], sc["skin_trans"])
-    rm.mlp_mode = {"split": _lib.HAV_MLP_SPLIT_BF16, "half": _lib.HAV_MLP_SPLIT_F16}[mlp]
+    rm.mlp_mode = _mode(mlp)
     rm.set_mlp(*[t(sc["mlp"][k]) for k in ("W1", "b1", "W2", "b2", "Wa", "ba", "Wf", "bf", "Wc", "bc")])
     rm.set_triplane(t(sc["planes"]))
     rays = t(synth.camera_rays(H, W))[None]
@@ -405,7 +436,7 @@ def test_production_variants_512_frame_24_launches(perturb, mlp):
         return out
 
     ref = [o.clone() if o is not None else None for o in launch()]
-    prec = {"split": 1, "half": 2}[mlp]
+    prec = PREC[mlp]
     want = "hav_march_blk_kernel<%d, %d, 2>" % ({False: 0, True: 1, "injected": 2}[perturb], prec)
     assert rm.last_variant == want
     report = []
@@ -462,7 +493,7 @@ def _sampled_rays_vs_oracle(out, rays, sc, H, W, jitter, kw):
         assert np.median(err) <= 1e-4, (k, np.median(err))
 
 
-@pytest.mark.parametrize("mlp", ["split", "half"])
+@pytest.mark.parametrize("mlp", SPLIT_MODES)
 def test_shipping_device_rng_kernels_vs_oracle_on_their_own_random_numbers(mlp):
     """<1, P, 2> -- what Trainer / bench.py launch: stratified jitter from the device streams -- is a different instantiation from
     <2, P, 2>, the one the reference fixtures go through (jitter injected as tensors).  The device stream is a pure function of
@@ -479,13 +510,13 @@ def test_shipping_device_rng_kernels_vs_oracle_on_their_own_random_numbers(mlp):
     dev = torch.device("cuda:0")
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
     rm = RayMarcher(sc["nerf_scale"], sc["nerf_trans"], sc["skin_scale"], sc["skin_trans"])
-    rm.mlp_mode = {"split": _lib.HAV_MLP_SPLIT_BF16, "half": _lib.HAV_MLP_SPLIT_F16}[mlp]
+    rm.mlp_mode = _mode(mlp)
     rm.set_mlp(*[t(sc["mlp"][k]) for k in ("W1", "b1", "W2", "b2", "Wa", "ba", "Wf", "bf", "Wc", "bc")])
     rm.set_triplane(t(sc["planes"]))
     rays = t(synth.camera_rays(H, W))[None]
     bg = torch.ones(1, H * W, 3, device=dev)
     args = (rays, bg, t(sc["inv_T"]), t(sc["vol"]), 64, 16)
-    prec = {"split": 1, "half": 2}[mlp]
+    prec = PREC[mlp]
     rm.rng_offset = 3
     dev_out = rm.render(*args, perturb=True, coarse_outputs=False)            # call counter 0 (fresh marcher) + offset 3
     assert rm.last_variant == "hav_march_blk_kernel<1, %d, 2>" % prec
@@ -502,7 +533,7 @@ def test_shipping_device_rng_kernels_vs_oracle_on_their_own_random_numbers(mlp):
         assert d.median().item() <= 1e-5 and (d > 1e-3).float().mean().item() <= 1e-2, (d.median().item(), (d > 1e-3).float().mean().item(), d.max().item())
 
 
-@pytest.mark.parametrize("mlp", ["split", "half"])
+@pytest.mark.parametrize("mlp", SPLIT_MODES)
 @pytest.mark.parametrize("jitter", [False, True])
 def test_full_frame_512_fine_maps_only_cache_kernels_vs_oracle(jitter, mlp):
     """BASELINE config 2 size through the PRODUCTION kernel families (fine-pass cache, coarse maps declined; bf16 triple split = the
@@ -523,7 +554,7 @@ def test_full_frame_512_fine_maps_only_cache_kernels_vs_oracle(jitter, mlp):
     dev = torch.device("cuda:0")
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
     rm = RayMarcher(sc["nerf_scale"], sc["nerf_trans"], sc["skin_scale"], sc["skin_trans"])
-    rm.mlp_mode = {"split": _lib.HAV_MLP_SPLIT_BF16, "half": _lib.HAV_MLP_SPLIT_F16}[mlp]
+    rm.mlp_mode = _mode(mlp)
     rm.flags |= _lib.HAV_FLAG_FINE_CACHE
     rm.set_mlp(*[t(sc["mlp"][k]) for k in ("W1", "b1", "W2", "b2", "Wa", "ba", "Wf", "bf", "Wc", "bc")])
     rm.set_triplane(t(sc["planes"]))
@@ -536,14 +567,14 @@ def test_full_frame_512_fine_maps_only_cache_kernels_vs_oracle(jitter, mlp):
     out = rm.render(rays, bg, t(sc["inv_T"]), t(sc["vol"]), 64, 16, perturb=jitter, coarse_outputs=False,
                     **{k: v.to(dev) for k, v in kw.items()})
     torch.cuda.synchronize()
-    assert rm.last_variant == "hav_march_blk_kernel<%d, %d, 2>" % (2 if jitter else 0, {"split": 1, "half": 2}[mlp])
+    assert rm.last_variant == "hav_march_blk_kernel<%d, %d, 2>" % (2 if jitter else 0, PREC[mlp])
     assert out[0] is None and all(torch.isfinite(o).all() for o in out[3:7])
     _sampled_rays_vs_oracle(out, rays, sc, H, W, jitter, kw)
 
 
 @pytest.mark.parametrize("recipe", ["primary", "stress"])
 @pytest.mark.parametrize("jitter", [False, True])
-@pytest.mark.parametrize("mlp", ["split", "half"])
+@pytest.mark.parametrize("mlp", SPLIT_MODES)
 def test_full_frame_512_production_kernels_vs_the_reference(mlp, jitter, recipe):
     """BASELINE config 2 at its real size against the REFERENCE ITSELF (not the oracle): the whole 512 x 512 frame is rendered by the
     production kernels (<0|2, 1|2, 2>: fine-pass cache, coarse maps declined; then once more with the coarse maps) and 2 064 of its rays --
@@ -563,7 +594,7 @@ def test_full_frame_512_production_kernels_vs_the_reference(mlp, jitter, recipe)
     dev = torch.device("cuda:0")
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
     rm = RayMarcher(sc["nerf_scale"], sc["nerf_trans"], sc["skin_scale"], sc["skin_trans"])
-    rm.mlp_mode = {"split": _lib.HAV_MLP_SPLIT_BF16, "half": _lib.HAV_MLP_SPLIT_F16}[mlp]
+    rm.mlp_mode = _mode(mlp)
     rm.flags |= _lib.HAV_FLAG_FINE_CACHE
     rm.set_mlp(*[t(sc["mlp"][k]) for k in ("W1", "b1", "W2", "b2", "Wa", "ba", "Wf", "bf", "Wc", "bc")])
     rm.set_triplane(t(sc["planes"]))
@@ -577,7 +608,7 @@ def test_full_frame_512_production_kernels_vs_the_reference(mlp, jitter, recipe)
         u_rand[idx] = torch.from_numpy(synth.uniform((n, 16), int(g["seed_u"])))
         kw = dict(t_rand=t_rand.to(dev), u_rand=u_rand.to(dev))
     key = "%s_%s_" % (recipe, "jit" if jitter else "det")
-    prec = {"split": 1, "half": 2}[mlp]
+    prec = PREC[mlp]
     sub = dict(sc)
     sub["rays"], sub["bg"] = rays[:, idx].cpu().numpy(), np.ones((1, n, 3), np.float32)
     okw = {"t_rand": synth.uniform((1, n, 64), int(g["seed_t"])), "u_rand": synth.uniform((n, 16), int(g["seed_u"]))} if jitter else {}

@@ -49,12 +49,13 @@ if "--calib" in sys.argv:
     print(json.dumps({"calib_kernel": "fba_vec_kernel<float, 4>", "read_bytes": 4 * x.numel() + 256, "write_bytes": 4 * x.numel()}))
     sys.exit(0)
 
+BRIEF = "--brief" in sys.argv          # bench.py's extra.ops: the five cfg4-size rows only
 rows = []
 k1 = torch.tensor([1., 3., 3., 1.], device=dev)
 k4 = (k1[None] * k1[:, None]); k4 = k4 / k4.sum()
 haar = torch.tensor([[1., -1.], [1., -1.]], device=dev) / 2 ** 0.5
 for name, shape in (("fused_bias_act [1,64,512,512]", (1, 64, 512, 512)), ("fused_bias_act [1,128,256,256]", (1, 128, 256, 256)),
-                    ("fused_bias_act [1,512,64,64]", (1, 512, 64, 64))):
+                    ("fused_bias_act [1,512,64,64]", (1, 512, 64, 64)))[:1 if BRIEF else 3]:
     b = torch.randn(shape[1], device=dev)
     e = b.new_empty(0)
     n_el = 1
@@ -78,7 +79,7 @@ for name, shape, k, up, dn, pad in (("upfirdn2d blur k4 [64,513,513]", (64, 513,
                                     ("upfirdn2d up2 k4 [12,512,512]", (12, 512, 512, 1), k4 * 4, 2, 1, (2, 1, 2, 1)),
                                     ("upfirdn2d up2 haar [3,512,512]", (3, 512, 512, 1), haar, 2, 1, (1, 0, 1, 0)),
                                     ("upfirdn2d down2 haar [3,1024,1024]", (3, 1024, 1024, 1), haar, 1, 2, (0, 0, 0, 0)),
-                                    ("upfirdn2d blur k4 [512,35,35]", (512, 35, 35, 1), k4, 1, 1, (2, 1, 2, 1))):
+                                    ("upfirdn2d blur k4 [512,35,35]", (512, 35, 35, 1), k4, 1, 1, (2, 1, 2, 1)))[:3 if BRIEF else 6]:
     y = upfirdn2d.upfirdn2d(torch.randn(shape, device=dev), k, up, up, dn, dn, *pad)
     n_in = 1
     for d in shape:
@@ -95,7 +96,7 @@ for name, shape, k, up, dn, pad in (("upfirdn2d blur k4 [64,513,513]", (64, 513,
 # compare with 4 x the per-band upfirdn2d rows above (+ a cat / three adds)
 bank = torch.stack([torch.tensor(q, device=dev) for q in ([[.5, .5], [.5, .5]], [[-.5, -.5], [.5, .5]], [[-.5, .5], [-.5, .5]], [[.5, -.5], [-.5, .5]])])
 for name, shape, inv in (("haar analysis, 4 bands, one pass [3,1024,1024]", (1, 3, 1024, 1024), False),
-                         ("haar synthesis, 4 bands, one pass [12,512,512]", (1, 12, 512, 512), True)):
+                         ("haar synthesis, 4 bands, one pass [12,512,512]", (1, 12, 512, 512), True))[:0 if BRIEF else 2]:
     n_in = 3 * 1024 * 1024
 
     def mkh(i):
@@ -107,4 +108,5 @@ for name, shape, inv in (("haar analysis, 4 bands, one pass [3,1024,1024]", (1, 
 print("# every launch on its own buffers, >= 1 GiB distinct per timed sequence (K launches): DRAM bandwidth, not Infinity Cache")
 for name, ms, by, K in rows:
     print("%-40s %8.1f us  %7.1f MB  %7.0f GB/s  %5.1f %% of 8 TB/s   (K=%d)" % (name, ms * 1e3, by / 1e6, by / ms / 1e6, 100 * by / ms / 1e6 / 8000, K))
-print(json.dumps([{"op": n, "us": round(ms * 1e3, 2), "bytes": by, "GBps": round(by / ms / 1e6, 1), "distinct_buffer_sets": K} for n, ms, by, K in rows]))
+print(json.dumps([{"op": n, "us": round(ms * 1e3, 2), "bytes": by, "GBps": round(by / ms / 1e6, 1), "frac_of_8TBps": round(by / ms / 1e6 / 8000, 4),
+                   "distinct_buffer_sets": K} for n, ms, by, K in rows]))

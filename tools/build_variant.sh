@@ -6,7 +6,7 @@ set -eu
 cd "$(dirname "$0")/.."
 name=$1; shift
 mkdir -p havatar_amd/lib/alt
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DHAV_FAST_BUILD "$@" -c havatar_amd/csrc/hav_render.hip -o havatar_amd/lib/alt/hav_render_$name.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DHAV_FAST_BUILD -Wno-unused-value "$@" -c havatar_amd/csrc/hav_render.hip -o havatar_amd/lib/alt/hav_render_$name.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o havatar_amd/lib/alt/libhavatar_$name.so havatar_amd/lib/alt/hav_render_$name.o havatar_amd/lib/hav_ops.o havatar_amd/lib/hav_train.o havatar_amd/lib/hav_mlp_train.o havatar_amd/lib/hav_conv.o
 rm -f havatar_amd/lib/alt/hav_render_$name.o
 echo havatar_amd/lib/alt/libhavatar_$name.so

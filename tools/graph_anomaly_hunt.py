@@ -67,6 +67,9 @@ for b in range(BUILDS):
                 events.append((b, k, since, loss.item(), bad[:6]))
                 nanparts = [n for n, v in parts.items() if torch.is_tensor(v) and not bool(torch.isfinite(v).all())]
                 wbad = sum(int(not bool(torch.isfinite(p_).all())) for p_ in trainer.parameters())
+                gbad = [n_ for n_, p_ in trainer.named_parameters() if p_.grad is not None and not bool(torch.isfinite(p_.grad).all())]
+                pbad = [n_ for n_, p_ in trainer.named_parameters() if not bool(torch.isfinite(p_).all())]
+                print("   non-finite gradients: %d %s | non-finite parameters: %s" % (len(gbad), gbad[:6], pbad[:6]), flush=True)
                 print("flagged: build %d step %d, %d replays since the last render, loss %g (non-finite parts: %s; %d non-finite parameters), %d tensors: %s" % (
                     b, k, since, loss.item(), nanparts, wbad, len(bad), bad[:6]), flush=True)
                 if wbad:

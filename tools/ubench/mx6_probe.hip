@@ -268,6 +268,75 @@ static void test_rate(const char* name)
     CK(hipFree(dO)); CK(hipFree(dC));
 }
 
+// ---------------------------------------------------------------- T4: does the scaled instruction read its operands after issue?
+// (tools/ubench/mfma_war.hip found that v_mfma_f32_32x32x16_f16 does not; the compiler assumes the same here and lets the very next VALU
+// instruction recycle an operand register.)  Every wave runs `iters` rounds of: operands into FIXED registers, the matrix instruction, NOPS
+// wait states, a v_mov that overwrites one operand register (WHICH: 0 nothing | 1 A's first | 2 A's last | 3 B's first | 4 B's last |
+// 5 the scale register), a long drain, restore.  A result that differs from WHICH = 0 means the instruction was still reading.
+template <int WHICH, int NOPS>
+__global__ void __launch_bounds__(512) war_kernel(float* out, int iters)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned a[6], b[6];
+    for (int i = 0; i < 6; ++i) { a[i] = 0x11111111u * (i + 1) ^ (lane * 0x01010101u); b[i] = 0x0f0f0f0fu * (i + 2) ^ (lane * 0x00110011u); }
+    a[0] &= 0x1f7df7dfu; b[0] &= 0x1f7df7dfu;
+    const unsigned sc = 0x7f7f7f7fu;
+    v16f acc;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#define WAR_NOP(n) (n == 0 ? "" : n == 1 ? "s_nop 0\n\t" : n == 2 ? "s_nop 1\n\t" : n == 4 ? "s_nop 3\n\t" : n == 8 ? "s_nop 7\n\t" : "s_nop 15\n\t")
+    for (int it = 0; it < iters; ++it) {
+#define WAR_BODY(nops, clobber)                                                                                                                \
+        asm volatile("v_mov_b32 v100, %1\n\tv_mov_b32 v101, %2\n\tv_mov_b32 v102, %3\n\tv_mov_b32 v103, %4\n\tv_mov_b32 v104, %5\n\tv_mov_b32 v105, %6\n\t"   \
+                     "v_mov_b32 v108, %7\n\tv_mov_b32 v109, %8\n\tv_mov_b32 v110, %9\n\tv_mov_b32 v111, %10\n\tv_mov_b32 v112, %11\n\tv_mov_b32 v113, %12\n\t" \
+                     "v_mov_b32 v116, %13\n\ts_nop 7\n\t"                                                                                        \
+                     "v_mfma_scale_f32_32x32x64_f8f6f4 %0, v[100:105], v[108:113], %0, v116, v116 op_sel_hi:[0,0,0] cbsz:2 blgp:2\n\t"           \
+                     nops clobber "s_nop 15\n\ts_nop 15\n\ts_nop 15"                                                                            \
+                     : "+v"(acc) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]),  \
+                       "v"(b[4]), "v"(b[5]), "v"(sc)                                                                                            \
+                     : "v100", "v101", "v102", "v103", "v104", "v105", "v108", "v109", "v110", "v111", "v112", "v113", "v116")
+#define WAR_N(clobber) do { if (NOPS == 0) WAR_BODY("", clobber); else if (NOPS == 1) WAR_BODY("s_nop 0\n\t", clobber); else if (NOPS == 2) WAR_BODY("s_nop 1\n\t", clobber); \
+                            else if (NOPS == 4) WAR_BODY("s_nop 3\n\t", clobber); else if (NOPS == 8) WAR_BODY("s_nop 7\n\t", clobber); else WAR_BODY("s_nop 15\n\t", clobber); } while (0)
+        if (WHICH == 0) WAR_N("");
+        else if (WHICH == 1) WAR_N("v_mov_b32 v100, 0x12345678\n\t");
+        else if (WHICH == 2) WAR_N("v_mov_b32 v105, 0x12345678\n\t");
+        else if (WHICH == 3) WAR_N("v_mov_b32 v108, 0x12345678\n\t");
+        else if (WHICH == 4) WAR_N("v_mov_b32 v113, 0x12345678\n\t");
+        else WAR_N("v_mov_b32 v116, 0x75757575\n\t");
+        for (int r = 0; r < 16; ++r) acc[r] *= 0.5f;
+    }
+    for (int r = 0; r < 16; ++r) out[((size_t)blockIdx.x * 512 + threadIdx.x) * 16 + r] = acc[r];
+}
+template <int WHICH, int NOPS>
+static long war_run(std::vector<float>& ref, const char* what)
+{
+    const int blocks = 256, iters = 400;
+    float* d; CK(hipMalloc(&d, (size_t)blocks * 512 * 16 * 4));
+    hipLaunchKernelGGL((war_kernel<WHICH, NOPS>), dim3(blocks), dim3(512), 0, 0, d, iters);
+    CK(hipDeviceSynchronize());
+    std::vector<float> o((size_t)blocks * 512 * 16);
+    CK(hipMemcpy(o.data(), d, o.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipFree(d));
+    long bad = 0;
+    if (WHICH == 0 && ref.empty()) ref = o;
+    else for (size_t i = 0; i < o.size(); ++i) bad += memcmp(&o[i], &ref[i], 4) != 0;
+    printf("  overwrite %-22s after %2d wait state(s): %8ld of %zu results differ%s\n", what, NOPS, bad, o.size(), WHICH == 0 ? " (reference run / repeat)" : "");
+    return bad;
+}
+static void test_war()
+{
+    printf("== T4: operand registers of v_mfma_scale_f32_32x32x64_f8f6f4 overwritten behind the instruction (2 waves per SIMD, 256 workgroups x 400 rounds) ==\n");
+    std::vector<float> ref;
+    war_run<0, 0>(ref, "nothing"); war_run<0, 0>(ref, "nothing");
+    war_run<1, 0>(ref, "A, first register"); war_run<1, 1>(ref, "A, first register"); war_run<1, 2>(ref, "A, first register"); war_run<1, 4>(ref, "A, first register");
+    war_run<1, 8>(ref, "A, first register"); war_run<1, 16>(ref, "A, first register");
+    war_run<2, 0>(ref, "A, last register"); war_run<2, 1>(ref, "A, last register"); war_run<2, 2>(ref, "A, last register"); war_run<2, 4>(ref, "A, last register");
+    war_run<2, 8>(ref, "A, last register"); war_run<2, 16>(ref, "A, last register");
+    war_run<3, 0>(ref, "B, first register"); war_run<3, 2>(ref, "B, first register"); war_run<3, 4>(ref, "B, first register"); war_run<3, 8>(ref, "B, first register");
+    war_run<4, 0>(ref, "B, last register"); war_run<4, 2>(ref, "B, last register"); war_run<4, 4>(ref, "B, last register"); war_run<4, 8>(ref, "B, last register");
+    war_run<4, 16>(ref, "B, last register");
+    war_run<5, 0>(ref, "the scale register"); war_run<5, 2>(ref, "the scale register"); war_run<5, 8>(ref, "the scale register");
+}
+
 int main()
 {
     int bad = test_cvt();
@@ -280,6 +349,7 @@ int main()
     b = test_mfma<2, 3>(FP6, BF6); bad += b;
     printf("== T3: issue rate ==\n");
     test_rate<0>("f16 x16"); test_rate<1>("fp4 x fp6"); test_rate<2>("fp6 x fp6"); test_rate<3>("bf6 x bf6"); test_rate<5>("fp4 x bf6"); test_rate<6>("fp4 x fp4"); test_rate<4>("fp8 x fp8");
+    test_war();
     printf(bad ? "RESULT: %d tests disagree with the assumed semantics\n" : "RESULT: all assumptions hold\n", bad);
     return 0;
 }
