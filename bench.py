@@ -720,6 +720,7 @@ def main():
                                               "fused_bias_act are kernels of this library, stride-2 / 1x1 convolutions MIOpen; phase_ms.encoders_P3_inside_the_graph "
                                               "includes the upsampler in this workload"} if args.workload == "cfg4" else None),
                        "rays_per_frame": H * W, "num_coarse": S_C, "num_fine": S_F, "perturb": perturb, "hipgraph": bool(args.graph),
+                       "hipgraph_packet_capture": os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "runtime default"),          # "0": havatar_amd/__init__.py (ROCm graph-replay fault)
                        "parallelism": ("frames sharded, %d rank(s), one overlapped all_gather of finished frames per round" if args.workload == "cfg3"
                                        else "frames sharded, %d rank(s), no data-path collective") % world,
                        "exchange": (("RCCL all_gather_into_tensor from a side stream, %d-rank group%s" % (world, " (forced at N = 1)" if world == 1 else ""))

@@ -5,9 +5,24 @@ ray march).  Eagerly, PyTorch's launch overhead is a third of the encoders' wall
 `hipGraphLaunch` + the input copies.  The captured ray march reads its RNG call counter from device memory and advances it
 on the stream (HavRenderParams.rng_counter), so every replay draws fresh stratified jitter like the eager path.
 """
+import os
+
 import torch
 
 _WEIGHTS_EPOCH = [0]
+_WARNED = [False]
+
+
+def _check_runtime_workaround():
+    """Graph replays interleaved with eager launches need DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 on this ROCm stack (havatar_amd/__init__.py sets
+    it at import unless the caller chose otherwise).  A process that initialised HIP before importing this package, or that switched the
+    packet capture back on, is told once."""
+    import warnings
+    from . import HIPGRAPH_PACKET_CAPTURE_ENV, hipgraph_replays_safe
+    if not hipgraph_replays_safe() and not _WARNED[0]:
+        _WARNED[0] = True
+        warnings.warn("%s is not 0: on ROCm 7.0.x replays of a captured hipGraph can return stale results once a reduction kernel has been "
+                      "launched eagerly between replays (tools/repro_graph_reduce.py)" % HIPGRAPH_PACKET_CAPTURE_ENV, RuntimeWarning)
 
 
 def weights_epoch():
@@ -26,6 +41,7 @@ class GraphedForward:
     Weights must not change between capture and replay (re-capture after a training step / load_state_dict)."""
 
     def __init__(self, module, example_kwargs, warmup=3):
+        _check_runtime_workaround()
         self.module = module
         self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in example_kwargs.items()}
         dev = next(v.device for v in self.static.values() if torch.is_tensor(v))
@@ -63,14 +79,23 @@ class GraphedTrainStep:
         # branches (PyTorch warns: "AccumulateGrad node's stream does not match ... may break CUDA graph capture"), and on this stack
         # replays of such a graph were seen to run consecutive kernels of the main chain out of order (DESIGN.md 7,
         # profiles/r04_flake_bisect.txt): intermittent non-finite activations, gone with AMD_SERIALIZE_KERNEL=3 and with this.
+        _check_runtime_workaround()
         self.static = {k: v.clone() for k, v in example.items()}
         self.optimizer = optimizer
         optimizer.zero_grad(set_to_none=True)
-        self.graph = torch.cuda.CUDAGraph()
+        shape = os.environ.get("HAVATAR_GRAPH_SHAPE") == "1"          # development aid: print the captured graph's topology (tools/graph_shape.py)
+        self.graph = torch.cuda.CUDAGraph(keep_graph=True) if shape else torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, stream=stream, capture_error_mode="thread_local"):
             self.loss, self.aux = step_fn(**self.static)
             self.loss.backward()
             optimizer.step()
+        if shape:
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("graph_shape", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "graph_shape.py"))
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            print("GraphedTrainStep: captured graph", mod.describe(self.graph.raw_cuda_graph()), flush=True)
+            self.graph.instantiate()
 
     def matches(self, tensors):
         return tensors.keys() == self.static.keys() and all(tensors[k].shape == v.shape and tensors[k].dtype == v.dtype

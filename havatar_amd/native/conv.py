@@ -307,7 +307,10 @@ class _FusedConvBlock(torch.autograd.Function):
         # (x and W arrive contiguous: fused_block() makes them so OUTSIDE the node -- a .contiguous() in here, where grad mode is off, would
         # save a detached copy of a channels-last / sliced input and cut the second-order graph of the create_graph branch below)
         ax = absmax(x)          # one pass over x serves the forward and, in backward, the weight gradient
-        y = conv3x3(x, pack(W, scale), W.shape[0], s=s, d=d, noise=noise, noise_weight=nw, bias=bias, slope=slope, gain=gain, act=act, amax=ax)
+        # (HAVATAR_CONV_AUTOSCALE=0, the A/B switch of the range control, reaches this forward too: the words are then only kept for the
+        # weight gradient, whose range control is not optional -- gradients of 1e-6 lose their low parts without it)
+        y = conv3x3(x, pack(W, scale), W.shape[0], s=s, d=d, noise=noise, noise_weight=nw, bias=bias, slope=slope, gain=gain, act=act,
+                    amax=ax if _autoscale_default() else None)
         ctx.save_for_backward(x, W, s, d, noise, nw, bias, y, ax)
         ctx.cfg = (float(scale), float(slope), float(gain), bool(act))
         return y

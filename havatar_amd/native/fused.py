@@ -154,18 +154,27 @@ def torgb(x, weight, s, bias, skip, scale):
     Cout = weight.shape[0]
     if Cout not in (3, 12) or Cin > 1024 or (H * W) % 4 or weight.numel() != Cout * Cin:
         return None
-    x = _f32c(x, "x")
-    out = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device)
-    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
-    w2 = _f32c(weight.reshape(Cout, Cin), "weight")
-    s = _f32c(s, "s") if s is not None else None
-    bias = _f32c(bias.reshape(-1), "bias") if bias is not None else None
-    skip = _f32c(skip, "skip") if skip is not None else None
+    # any layout the ATen route took is taken here too: strided / channels-last / sliced operands are made contiguous (a copy only when
+    # needed); operands of another dtype or device, or not 16-byte aligned (the kernel's float4 loads), keep the caller's ATen route
+    ok = lambda t: t is None or (t.is_cuda and t.dtype == torch.float32 and t.device == x.device)
+    if not (ok(weight) and ok(s) and ok(bias) and ok(skip)):
+        return None
     if skip is not None and tuple(skip.shape) != (B, Cout, H, W):
         raise RuntimeError("torgb: skip must be [B,Cout,H,W]")
+    x = x.contiguous()
+    w2 = weight.reshape(Cout, Cin).contiguous()
+    s = s.contiguous() if s is not None else None
+    bias = bias.reshape(-1).contiguous() if bias is not None else None
+    skip = skip.contiguous() if skip is not None else None
+    if any(t is not None and t.data_ptr() % 16 for t in (x, skip)):
+        return None
+    out = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
     with torch.cuda.device(x.device):
         rc = _lib.lib().hav_torgb(p(out), p(x), p(w2), p(s), p(bias), p(skip), float(scale), B, Cout, Cin, H * W,
                                   C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc == -2:          # HAV_EUNSUP: a shape this build does not take -- not an error, the caller falls back
+        return None
     _lib.check(rc, "hav_torgb")
     return out
 

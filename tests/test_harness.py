@@ -442,12 +442,14 @@ def test_graphed_training_step_is_a_single_chain_and_replays_in_order(dataset, m
     """The captured optimisation step must not fork: GraphedTrainStep captures on the stream the eager warm-up steps ran on, so the
     parameters' AccumulateGrad nodes (bound to the stream they were created on) add no side branches.  With side branches, replays on
     this stack ran consecutive kernels of the main chain out of order (round 4: NaN losses in 13 % of the CLI test's runs).
-    Tripwires: (1) PyTorch's "AccumulateGrad node's stream does not match" warning does not appear; (2) the losses of 2 x 8 steps stay
+    Tripwires: (1) PyTorch's "AccumulateGrad node's stream does not match" warning does not appear; (2) the losses of 2 x 12 steps stay
     finite; (3) is-finite flags of every operand / result of the convolution wrappers, traced INSIDE the captured graph
-    (native/conv.py::_trace) -- a kernel that reads a half-written tensor shows up there long before the loss does.  Before the fix
-    60 % of such runs had replays with dozens of flagged tensors; since, 2 of 27 runs had ONE replay with ONE flagged tensor whose
-    producers and consumers were clean (a transient the trace itself may cause; open): at most one flagged replay with at
-    most two flagged tensors is tolerated here, anything like the old picture fails."""
+    (native/conv.py::_trace) -- a kernel that reads a half-written tensor shows up there long before the loss does: NO flag may be raised.
+    Round 4 tolerated one flagged replay here; round 5 root-caused that residue to the ROCm runtime (replays of a graph return stale results
+    once a reduction kernel was launched eagerly in between: tools/repro_graph_reduce.py) and havatar_amd switches the
+    responsible launch path off at import (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0): 0 flagged replays of 1 460 in profiles/r05_graph_anomaly_root_cause.txt."""
+    import havatar_amd
+    assert havatar_amd.hipgraph_replays_safe(), "the test process must run with %s=0" % havatar_amd.HIPGRAPH_PACKET_CAPTURE_ENV
     from havatar_amd.dataloader.dataloader import Loader
     from havatar_amd.harness import train
     from havatar_amd.model.nerf_trainer import Trainer
@@ -466,7 +468,7 @@ def test_graphed_training_step_is_a_single_chain_and_replays_in_order(dataset, m
         opt = train.make_optimizer(cfg, trainer, True)
         run = train.StepRunner(trainer, cfg, opt, torch.nn.functional.mse_loss, graph=True)
         inp, target, mask = train.step_inputs(idx, batch, "cuda")
-        for k in range(8):
+        for k in range(12):
             loss, _, _ = run(inp, target, mask)
             train.set_learning_rate(opt, 5e-4)
             assert np.isfinite(loss.item()), (run_no, k)
@@ -476,8 +478,7 @@ def test_graphed_training_step_is_a_single_chain_and_replays_in_order(dataset, m
                 bad = [n for n, f in flags if not bool(f)]
                 if bad:
                     flagged.append((run_no, k, bad[:5]))
-                    assert len(bad) <= 2, flagged
-            if k == 3:                                      # an eager inference render between replays, as train.main() does
+            if k % 4 == 3:                                  # an eager inference render between replays, as train.main() does
                 trainer.eval()
                 with torch.no_grad():
                     trainer(mode="validation", fidx=None, render_full_img=False, ray_batch=inp["ray_batch"][:1, :256].contiguous(),
@@ -485,9 +486,29 @@ def test_graphed_training_step_is_a_single_chain_and_replays_in_order(dataset, m
                             **{kk: inp[kk][:1] for kk in ("front_render_cond", "left_render_cond", "right_render_cond")})
                 trainer.train()
         assert run.graphed is not None
-    print("flagged replays:", flagged)
-    assert len(flagged) <= 1, flagged
+    assert not flagged, flagged
     assert not [w for w in recwarn.list if "AccumulateGrad node's stream does not match" in str(w.message)]
+
+
+@pytest.mark.gpu
+def test_hipgraph_replays_survive_eager_reductions_with_the_runtime_workaround():
+    """The ROCm runtime fault behind round 4's residue, outside this package (tools/repro_graph_reduce.py: PyTorch only): a captured graph of
+    element-wise ops, is-finite reductions and sums of ones, replayed 60 times with ONE eager torch.sum every fourth replay.  With the
+    setting havatar_amd applies at import (in-process, after `import torch`) every replay is right.  The same script without it is run for the
+    record only: the fault belongs to the runtime (56 of 60 replays wrong on ROCm 7.0.2), a fixed runtime makes that line read 0."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    def run(**env):
+        e = dict(os.environ, EAGER="sum", **env)
+        e.pop("DEBUG_CLR_GRAPH_PACKET_CAPTURE", None)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "repro_graph_reduce.py")], env=e, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        return [l for l in r.stdout.splitlines() if l.startswith("repro_graph_reduce:")][-1]
+    fixed = run(WORKAROUND="inprocess")
+    print(fixed)
+    print("without the workaround:", run())
+    assert " 0 of 60 replays" in fixed, fixed
 
 
 def test_reenactment_cli_shards_frames_across_ranks(tmp_path, dataset, gold, monkeypatch):

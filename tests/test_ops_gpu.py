@@ -1163,6 +1163,28 @@ def test_torgb_fused_kernel_matches_the_unfused_statement(B, Cin, Cout, H, with_
     assert fused.torgb(x, r(5, Cin), s, None, None, scale) is None          # a width the kernel does not take: the caller keeps ATen
 
 
+def test_torgb_takes_any_layout_the_aten_route_took():
+    """ADVICE (round 4): channels-last, sliced and expanded operands are made contiguous by the wrapper (the ATen ToRGB accepted any layout);
+    operands it cannot hand to the kernel -- another dtype -- return None (the caller falls back) instead of raising."""
+    from havatar_amd.native import fused
+    g = torch.Generator(device=DEV).manual_seed(77)
+    r = lambda *sh: torch.randn(*sh, device=DEV, generator=g)
+    B, Cin, Cout, H = 2, 64, 12, 32
+    x, W, s, bias, skip = r(B, Cin, H, H), r(Cout, Cin), 1.0 + 0.3 * r(B, Cin), 0.2 * r(1, Cout, 1, 1), r(B, Cout, H, H)
+    want = fused.torgb(x, W, s, bias, skip, 0.125)
+    x_cl = x.to(memory_format=torch.channels_last)
+    x_sl = torch.cat([x, x], dim=1)[:, :Cin]                     # a channel slice of a wider tensor
+    s_ex = r(B, Cin + 3)[:, 3:]                                  # a column slice: not contiguous, its data pointer 12 bytes off a 16-byte boundary
+    skip_t = skip.permute(0, 1, 3, 2).contiguous().permute(0, 1, 3, 2)
+    assert not x_cl.is_contiguous() and not x_sl.is_contiguous() and not s_ex.is_contiguous() and not skip_t.is_contiguous()
+    assert torch.equal(fused.torgb(x_cl, W, s, bias, skip, 0.125), want)
+    assert torch.equal(fused.torgb(x_sl, W, s, bias, skip_t, 0.125), want)
+    got = fused.torgb(x, W.t().contiguous().t(), s_ex, bias.expand(1, Cout, 1, 1), skip, 0.125)
+    assert torch.equal(got, fused.torgb(x, W, s_ex.contiguous(), bias, skip, 0.125))
+    assert fused.torgb(x, W, s.double(), bias, skip, 0.125) is None
+    assert fused.torgb(x.double(), W, s, bias, skip, 0.125) is None
+
+
 def test_torgb_module_takes_the_fused_kernel_and_equals_its_aten_route(monkeypatch):
     """model/styleUnet.py::ToRGB on HIP tensors without autograd goes through hav_torgb (with the wavelet-domain skip path in front of
     it) and gives what its ATen route gives."""

@@ -38,6 +38,33 @@ if os.environ.get("SENTINEL") == "1":
         return words
     conv._absmax = _absmax_sentinel
 
+KIND = os.environ.get("RENDER_KIND", "full")          # what runs between replays: full | encoders | toggle | alloc
+PROBE = os.environ.get("PROBE") == "1"          # PROBE=1: which blocks of the graph's PRIVATE memory pool change hands around an eager render?
+
+
+def pool_blocks():
+    """{address: (size, state)} of every block in a segment that belongs to a private (graph) pool"""
+    out = {}
+    for seg in torch.cuda.memory_snapshot():
+        if tuple(seg.get("segment_pool_id", (0, 0))) != (0, 0):
+            for blk in seg["blocks"]:
+                out[blk["address"]] = (blk["size"], blk["state"])
+    return out
+
+
+def pool_diff(tag, a, b):
+    gone = [k for k in a if k not in b]
+    new = [k for k in b if k not in a]
+    chg = [(k, a[k], b[k]) for k in a if k in b and a[k] != b[k]]
+    act = sum(1 for v in b.values() if v[1] == "active_allocated")
+    print("pool probe %s: %d blocks (%d allocated, %.1f MB); vs before: %d gone, %d new, %d changed state" % (
+        tag, len(b), act, sum(v[0] for v in b.values()) / 2 ** 20, len(gone), len(new), len(chg)), flush=True)
+    for k, x, y in chg[:12]:
+        print("     0x%x  %d B  %s -> %s" % (k, x[0], x[1], y[1]), flush=True)
+    for k in new[:6]:
+        print("     new 0x%x  %d B  %s" % (k, b[k][0], b[k][1]), flush=True)
+
+
 dev = torch.device("cuda:0")
 tmp = tempfile.mkdtemp()
 split = synth.write_dataset(tmp, n_frames=2, img_res=128)
@@ -45,7 +72,7 @@ cfg = CfgNode(synth.harness_config(perturb=True, noise_std=0.1))
 np.random.seed(3)
 tl = Loader(split_file=split, mode="train", batch_size=2, num_workers=0, down_sample=cfg.dataset.down_sample, options=cfg, white_bg=True, shuffle=False)
 idx, batch = next(iter(tl))
-events, replays, t0 = [], 0, time.time()
+events, replays, t0, snap = [], 0, time.time(), {}
 for b in range(BUILDS):
     torch.manual_seed(11 + b)
     trainer = synth.fill_state_dict(Trainer(cfg, len(tl.dataset))).to(dev).train()
@@ -59,6 +86,11 @@ for b in range(BUILDS):
             conv.nan_trace_reset(dev)
         loss, parts, _ = run(inp, target, mask)
         train.set_learning_rate(opt, 5e-4)
+        if PROBE and run.graphed is not None and k <= 8:
+            torch.cuda.synchronize()
+            now = pool_blocks()
+            pool_diff("after step %d (replay)" % k, snap if k > 2 else now, now)
+            snap = now
         if run.graphed is not None or (not GRAPH and k >= 2):
             replays += 1
             since = since + 1 if since >= 0 else -1
@@ -77,12 +109,30 @@ for b in range(BUILDS):
                     break
         if k % EVERY == EVERY - 1:
             n0 = len(conv._NAN_TRACE)
-            trainer.eval()
-            with torch.no_grad():
-                trainer(mode="validation", fidx=None, render_full_img=False, ray_batch=inp["ray_batch"][:1, :256].contiguous(),
-                        background_prior=inp["background_prior"][:1, :256].contiguous(), inv_head_T=inp["inv_head_T"][:1],
-                        **{kk: inp[kk][:1] for kk in ("front_render_cond", "left_render_cond", "right_render_cond")})
-            trainer.train()
+            if KIND == "alloc":            # no model call at all: eager allocations and a few ATen kernels only
+                junk = [torch.randn(1 << n, device=dev) for n in (8, 12, 16, 20, 24)]
+                junk = [j * 2 for j in junk]
+                del junk
+            elif KIND == "toggle":         # only the train / eval switch
+                trainer.eval(); trainer.train()
+            elif KIND == "encoders":       # the conditioning encoders only (no ray march)
+                trainer.eval()
+                with torch.no_grad():
+                    trainer.model_coarse.set_conditional_embedding(latents=trainer.latent_codes[0:1], cond_c=inp["inv_head_T"][:1].reshape(1, -1),
+                                                                   **{kk: inp[kk][:1] for kk in ("front_render_cond", "left_render_cond", "right_render_cond")})
+                trainer.train()
+            else:
+                trainer.eval()
+                with torch.no_grad():
+                    trainer(mode="validation", fidx=None, render_full_img=False, ray_batch=inp["ray_batch"][:1, :256].contiguous(),
+                            background_prior=inp["background_prior"][:1, :256].contiguous(), inv_head_T=inp["inv_head_T"][:1],
+                            **{kk: inp[kk][:1] for kk in ("front_render_cond", "left_render_cond", "right_render_cond")})
+                trainer.train()
+            if PROBE and k <= 8:
+                torch.cuda.synchronize()
+                now = pool_blocks()
+                pool_diff("after the eager render behind step %d" % k, snap, now)
+                snap = now
             del conv._NAN_TRACE[n0:]                      # (the eager render's own trace entries are not part of the step)
             since = 0
     del run, opt, trainer
