@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libhavatar_hip.so")
 
 HAV_F32, HAV_F16, HAV_BF16, HAV_F64 = 0, 1, 2, 3
 HAV_MLP_SPLIT_BF16, HAV_MLP_F32, HAV_MLP_SPLIT_F16, HAV_MLP_SPLIT_F16_MX = 0, 1, 2, 3
-ABI_VERSION = 5
+ABI_VERSION = 6
 HAV_FLAG_PAIR_KERNEL, HAV_FLAG_FINE_CACHE, HAV_FLAG_FINE_RECOMPUTE, HAV_FLAG_NO_FP16_GUARD = 1, 2, 4, 8
 HAV_STATUS_FP16_FALLBACK = 1
 
@@ -23,7 +23,7 @@ class HavRenderParams(C.Structure):
                 ("skin_scale", C.c_float * 3), ("skin_trans", C.c_float * 3),
                 ("seed", C.c_uint64), ("rng_offset", C.c_uint64), ("mlp_mode", C.c_int32), ("flags", C.c_int32),
                 ("rng_counter", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64),
-                ("dbg_zfine", C.c_void_p), ("status", C.c_void_p)]
+                ("dbg_zfine", C.c_void_p), ("status", C.c_void_p), ("grid_blocks", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class HavFieldParams(C.Structure):

@@ -2102,6 +2102,7 @@ static int march_grid_blocks(const HavRenderParams* p)
     int gridb = hav_num_cus();
     const long long needb = (nblk + MARCH_WAVES - 1) / MARCH_WAVES;
     if (needb < gridb) gridb = (int)((needb + 7) / 8 * 8);
+    if (p->grid_blocks > 0 && p->grid_blocks < gridb) gridb = (p->grid_blocks + 7) / 8 * 8;      // the caller leaves CUs to a concurrent stream (ABI 6)
     return gridb;
 }
 // 0 = exact f32 MFMA, 1 = bf16 triple split, 2 = fp16 double split, 3 = fp16 double split + MX correction terms
@@ -2209,6 +2210,7 @@ extern "C" int hav_render_rays(const HavRenderParams* p, const float* rays, cons
     if (p->plane_res < 2 || p->vol_res < 2) return HAV_EINVAL;
     if (p->S_c > 256 || p->S_f > 128) return HAV_EUNSUP;
     if ((p->flags & ~HAV_FLAGS_ALL) || ((p->flags & HAV_FLAG_FINE_CACHE) && (p->flags & HAV_FLAG_FINE_RECOMPUTE))) return HAV_EINVAL;
+    if (p->grid_blocks < 0 || p->reserved0 != 0) return HAV_EINVAL;
     if (p->mlp_mode != HAV_MLP_SPLIT_BF16 && p->mlp_mode != HAV_MLP_F32 && p->mlp_mode != HAV_MLP_SPLIT_F16 && p->mlp_mode != HAV_MLP_SPLIT_F16_MX)
         return HAV_EINVAL;
     // the coarse pass's composited outputs may be declined (all three NULL) when there is a fine pass: Trainer.forward then only

@@ -54,6 +54,7 @@ class RayMarcher:
         self.plane_res, self.plane_ch, self.vol_res = plane_res, plane_ch, vol_res
         self.blob = None
         self._blob_key = None
+        self.grid_blocks = 0          # > 0: the march runs on at most this many compute units (HavRenderParams.grid_blocks; tools/pipeline_probe.py)
         self.planes_cl = None
         self._planes_key = None
         self.rng_counter = None
@@ -144,6 +145,7 @@ class RayMarcher:
             p.skin_scale[i], p.skin_trans[i] = self.skin_scale[i], self.skin_trans[i]
         p.seed, p.rng_offset = self.seed, self.rng_offset
         p.mlp_mode, p.flags = self.mlp_mode, self.flags
+        p.grid_blocks = int(self.grid_blocks)
         if self._status is None or self._status.device != dev:
             self._status = torch.zeros(1, dtype=torch.int32, device=dev)
         p.status = self._status.data_ptr()

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define HAV_ABI_VERSION 5
+#define HAV_ABI_VERSION 6
 
 #define HAV_EINVAL   (-1) /* bad size / null pointer / inconsistent arguments            */
 #define HAV_EUNSUP   (-2) /* valid for the reference, not supported by this build        */
@@ -334,6 +334,12 @@ typedef struct HavRenderParams {
     uint64_t workspace_bytes;
     float*   dbg_zfine;    /* optional DEVICE [B*R, S_fp] (tests): the call also dumps the merged, sorted fine depths here  */
     uint32_t* status;      /* optional DEVICE word; the call ORs HAV_STATUS_* bits into it on the stream (the caller zeroes it) */
+    int32_t  grid_blocks;  /* ABI 6.  0 = one persistent workgroup per compute unit (the default).  > 0: at most this many (rounded up to
+                            * a multiple of 8, one share per XCD), which leaves compute units to kernels of another stream.  Results do
+                            * not depend on it (the blocks of 32 rays are dealt to fewer workgroups, nothing else changes).  Measured
+                            * (tools/pipeline_probe.py, profiles/r05_pipeline_probe.txt): 208 units 7.81 ms vs 256 units 7.01 ms -- the
+                            * kernel is power-limited -- and the next frame's encoders beside it are no faster than behind it.   */
+    int32_t  reserved0;    /* 0 */
 } HavRenderParams;
 
 /* HavRenderParams.flags */
