@@ -15,7 +15,7 @@ What the default run (N = 1) times, each as its own loop of W warm-up + K timed 
   * cpu_baseline: the whole frame on the host cores -- the oracle's ray march (OpenMP) + this repo's PyTorch-CPU statement of the
     tri-plane encoders.
   * roofline.power: socket power and shader clock sampled during a sustained replay of the headline loop (the kernel runs at the
-    socket power cap).
+    socket power cap, docs/history/DESIGN_r1-r4.md 3.13).
 
 Other workloads (not what the driver runs; same JSON contract):
   --workload cfg3 [--frames 64]   BASELINE configs[2]: a batch of 64 frames dealt round-robin to the ranks (8 per GPU on 8 GPUs), finished
@@ -61,7 +61,7 @@ MODE_OF_ENV = {"mx": "fp16x2+mx", "split": "bf16x3", "bf16": "bf16x3", "half": "
 # (fp16x2+mx: 132 fp16 products + 36 block-scaled 32x32x64 instructions of 131072 FLOP each, priced against the 16-bit peak like the rest)
 EXEC_FLOP_PER_TILE = {"fp16x2": 132 * 32768, "bf16x3": 264 * 32768, "f32": 352 * 4096, "fp16x2+mx": 132 * 32768 + 36 * 131072}
 EXEC_INSTR_PER_TILE = {"fp16x2": 132, "bf16x3": 264, "f32": 352, "fp16x2+mx": 168}
-# feature parking (fp16 cache kernels): the 48 parked tiles of the 80 evaluated per ray block also run fc_rgbFeat on
+# feature parking (fp16 cache kernels, docs/history/DESIGN_r1-r4.md 3.7): the 48 parked tiles of the 80 evaluated per ray block also run fc_rgbFeat on
 # the matrix cores, 8 chunks x 2 row tiles x 3 products = 48 more -> 132 + 48 * 48/80 = 160.8 per evaluated tile (= SQ_INSTS_MFMA)
 PARK_FLOP_PER_TILE = 48 * 32768
 CFG3_NOTE = ("cfg3: one step = a batch of %d frames dealt round-robin to %d rank(s) (%d per rank); each frame is the cfg2 workload below; the "

@@ -16,7 +16,7 @@ HEADERS = ["hav_common.h", os.path.join("..", "..", "include", "havatar.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
 BUILD_INFO = os.path.join(LIBDIR, "BUILD_INFO.json")
 # The kernels were validated -- parity suite, full-occupancy determinism stress (tools/stress_production.py, tools/stress_diag.py: a
-# rare run-to-run difference turned out to depend on the compiler's instruction selection) -- with exactly this
+# rare run-to-run difference turned out to depend on the compiler's instruction selection, docs/history/DESIGN_r1-r4.md 3.12) -- with exactly this
 # compiler.  A build with another one is recorded as untested in lib/BUILD_INFO.json and warned about; it is refused only when
 # HAVATAR_REQUIRE_TESTED_HIPCC=1.  (The .so built here with hipcc 7.2 runs on the GPU boxes' ROCm 7.0.2 runtime / HIP 7.0.51831 --
 # code objects are forward-compatible there; GPUTEST_r0*.json record that pairing.)

@@ -46,7 +46,7 @@ typedef float fl2_t __attribute__((ext_vector_type(2)));
 #define CV_TPT ((CV_TASKS + 255) / 256)  // per thread
 #define CV_WSHIFT 256.0f
 // Rounds 1-3 put 32 wait states behind the matrix instructions of a chunk, before the staging code of the next one, against an operand
-// hazard that does not exist (tools/ubench/mfma_war.hip).  Round 4 re-validated the kernels without them (every parity test
+// hazard that does not exist (docs/history/DESIGN_r1-r4.md 3.5; tools/ubench/mfma_war.hip).  Round 4 re-validated the kernels without them (every parity test
 // of tests/test_ops_gpu.py incl. test_conv3x3_full_occupancy_runs_are_bitwise_identical: profiles/r04_conv_nopad.txt) and dropped them; the
 // asm statement stays as a scheduling fence (it ties the accumulators), empty.  -DCV_MFMA_PAD='"s_nop 15\n\ts_nop 15"' brings them back.
 #ifndef CV_MFMA_PAD
@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(ConvArgs a)
                 acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh, acc[rr], 0, 0, 0);
             }
         }
-        // the matrix instructions keep reading their operand registers for a while after issue: wait them out before
+        // the matrix instructions keep reading their operand registers for a while after issue (docs/history/DESIGN_r1-r4.md 3.5): wait them out before
         // the conversion code below may recycle registers
         CV_T(pt2);
         asm volatile(CV_MFMA_PAD : "+v"(acc[0]), "+v"(acc[1]));
@@ -427,7 +427,7 @@ __global__ void __launch_bounds__(256, 1) conv3x3_il_kernel(ConvArgs a)
             if (k >= 15 && (k - 15) % 3 == 0 && (k - 15) / 3 < CV_TPT) stash1(Lw, (k - 15) / 3, vc, sc_);          // k = 15, 18, .., 33
             __builtin_amdgcn_sched_barrier(0);
         }
-        // the matrix instructions keep reading their operand registers for a while after issue: the fragment
+        // the matrix instructions keep reading their operand registers for a while after issue (docs/history/DESIGN_r1-r4.md 3.5): the fragment
         // registers stay allocated until here (no temporary may land in them), and the pipe drains before the next chunk's first writes
 #pragma unroll
         for (int t = 0; t < 9; ++t) { CV_KEEP4(Ac[t][0]); CV_KEEP4(Ac[t][1]); }
@@ -1028,7 +1028,7 @@ __global__ void __launch_bounds__(256, 2) gemm_split_kernel(GemmArgs a)
                 }
             }
         }
-        // the matrix instructions keep reading their operand registers after issue: wait them out before stash() may
+        // the matrix instructions keep reading their operand registers after issue (docs/history/DESIGN_r1-r4.md 3.5): wait them out before stash() may
         // recycle registers
         asm volatile(CV_MFMA_PAD : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));
         if (cc + 1 < NC) stash(buf ^ 1, sv, ssc);

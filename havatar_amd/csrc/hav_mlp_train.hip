@@ -139,7 +139,7 @@ struct TrainCtx {
 };
 
 // gfx950 / ROCm 7.2: v_mfma_f32_32x32x16_* keeps reading its A/B registers after issue and the compiler may let the next VALU
-// instruction recycle them (hav_render.hip).  Every batch of MFMAs here ends with FENCE: 32 wait states with the
+// instruction recycle them (hav_render.hip, docs/history/DESIGN_r1-r4.md 3.5).  Every batch of MFMAs here ends with FENCE: 32 wait states with the
 // operand registers still live, before any code that builds the next operands can run.
 #define MFMA_FENCE(accv) asm volatile("s_nop 15\n\ts_nop 15" : "+v"(accv))
 #define KEEP_ALIVE(frag_) asm volatile("" : : "v"((frag_).x), "v"((frag_).w))

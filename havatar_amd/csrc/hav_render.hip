@@ -28,7 +28,7 @@
 //    a partner wave's v_fma_f32 / v_max / v_cvt stream keeps 95 % of its pace beside a saturating MFMA stream, ~6 fillers fit behind
 //    each v_mfma_f32_32x32x16 of the same wave -- and only PACKED fp32 VALU (v_pk_fma/mul/add_f32) serialises with it.  (Rounds 1-3
 //    read "VALU does not overlap with MFMA" off microbenchmarks whose C fillers hipcc had packed into v_pk_fma_f32.)  What bounds the
-//    kernel is the socket power cap: it runs at 2.0-2.2 of 2.4 GHz, and cycle savings come back as lower clock.  The
+//    kernel is the socket power cap: it runs at 2.0-2.2 of 2.4 GHz, and cycle savings come back as lower clock (docs/history/DESIGN_r1-r4.md 3.13).  The
 //    matrix work -- the most power-hungry part -- was cut algebraically:
 //      - Layer 1's 128 tri-plane columns are folded into the planes once per frame: bilinear interpolation is linear,
 //        W1f (sum_tap w_tap texel_tap) = sum_tap w_tap (W1f texel_tap).  hav_triplane_prepare projects every texel
@@ -528,7 +528,7 @@ __device__ __forceinline__ float half_swap(float v, int h)
     return __shfl_xor(v, 32, 64);
 }
 // sigmoid with the reciprocal instruction (1 ulp) instead of the compiler's IEEE division sequence -- three of those interleaved per
-// sample is the pattern DESIGN.md 3.12 is about; rcp(inf) = 0 covers exp overflow (no Newton step: inf * 0 would poison it)
+// sample is the pattern docs/history/DESIGN_r1-r4.md 3.12 is about; rcp(inf) = 0 covers exp overflow (no Newton step: inf * 0 would poison it)
 __device__ __forceinline__ float sigmoid_rcp(float x) { return __builtin_amdgcn_rcpf(1.0f + expf(-x)); }
 // orders this wave's LDS traffic (the per-wave scratch is private to a wave: no workgroup barrier needed)
 __device__ __forceinline__ void wave_lds_sync()
@@ -1004,7 +1004,7 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a_in, const LaneCtx
     // (the OFFSET is made opaque, not the pointer: a pointer that has been through an asm statement loses its LDS address space and
     // every read through it becomes a FLAT load -- slower, and FLAT accesses complete out of order with the other memory counters)
     int sb_off = 0;
-    asm volatile("" : "+v"(sb_off));          // (in an SGPR instead, the surrounding code was allocated differently and the hazard of DESIGN.md 3.12 was 100x more frequent)
+    asm volatile("" : "+v"(sb_off));          // (in an SGPR instead, the surrounding code was allocated differently and the hazard of docs/history/DESIGN_r1-r4.md 3.12 was 100x more frequent)
     const float4* sBt = L.sB + sb_off;
     const int PR = a.p.plane_res, VR = a.p.vol_res;
     // ---- pts = o + d z; skinning field (model/Skinning_Field.py:77-95): half-wave h evaluates bone h ---------
@@ -2116,7 +2116,7 @@ static long long fine_cache_slot_floats(const HavRenderParams* p)
     return S_fp * (((mlp_prec(p) == 2) ? WS_H2_FLOATS / 2 : WS_H2_FLOATS) + 128 + 32)       // features (fp16 mode) or hidden units
            + (long long)((p->S_c + 3) & ~3) * 32;                                                // + the coarse weights of the block, [S_c][32]
 }
-// Would a workspace be used at all?  Measured on MI355X: with stratified jitter on (the production setting)
+// Would a workspace be used at all?  Measured on MI355X (docs/history/DESIGN_r1-r4.md 3.7): with stratified jitter on (the production setting)
 // skipping the repeated samples is worth 10-15 % of the kernel; with deterministic depths the coarse tiles are so coherent (all 32
 // rays at the same depth) that in bf16 mode the 13 GB of parking traffic per frame cancel the gain.  With feature parking (fp16
 // mode) the parking stream is half as large and the cache pays with deterministic depths as well.
@@ -2148,7 +2148,7 @@ extern "C" int64_t hav_render_workspace_bytes(const HavRenderParams* p)
 //   prec 0: exact fp32 MFMA, 1: bf16 triple split, 2: fp16 double split
 //   cm   0: every merged fine sample is evaluated, 1: fine-pass cache, 2: cache + fine maps only (coarse outputs declined)
 // fp16 + cache + coarse outputs (<., 2, 1>) does not exist: that combination carries 64 more live accumulators through the
-// feature projection of parked tiles and ran into the MFMA operand hazard of DESIGN.md 3.5 under 240-280 spilled VGPRs; a
+// feature projection of parked tiles and ran into the MFMA operand hazard of docs/history/DESIGN_r1-r4.md 3.5 under 240-280 spilled VGPRs; a
 // caller that wants the coarse maps in fp16 mode gets every merged sample evaluated instead.
 struct MarchVariant { bool blk; int rm, prec, cm; bool guard; };
 static MarchVariant pick_variant(const HavRenderParams* p, bool no_coarse_out, bool injected)

@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(256) field_inputs_kernel(FieldArgs a)
         part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 4, 64);
         const float w0 = __shfl(part, 0, 64), w1 = __shfl(part, 8, 64);
         // :87.  The two quotients as one reciprocal + Newton step (<= 1 ulp from w / s), exactly as the inference kernel forms them
-        // (hav_render.hip HAV_FAST_DIV, DESIGN.md 3.12: the compiler's interleaved IEEE division sequences are not trusted on gfx950)
+        // (hav_render.hip HAV_FAST_DIV, docs/history/DESIGN_r1-r4.md 3.12: the compiler's interleaved IEEE division sequences are not trusted on gfx950)
         const float s = (w0 + w1) + 1e-8f;
         float rs = __builtin_amdgcn_rcpf(s);
         rs = rs * (2.0f - s * rs);

@@ -1,10 +1,10 @@
 """Static checks on the compiler's output for gfx950 (no GPU needed: hipcc cross-compiles here) -- the code-generation accidents that cost
-this project real time in round 3, as regression tests:
+this project real time in round 3 (docs/history/DESIGN_r1-r4.md 3.11, 3.12), as regression tests:
   * no FLAT instruction in any kernel: a pointer that has been through an empty asm statement loses its address space, its accesses become
     flat_load / flat_store, which are slower and complete out of order with the other memory counters;
   * the production march kernels keep scratch out of their per-tile sample loops (and spill at most a handful of per-block values);
   * no instruction touches a matrix-instruction RESULT inside 11 wait states (tools/mfma_war_check.py): the compiler pads that for its own
-    instructions but not for inline asm (the in-place relu), DESIGN.md 3.5.  (The script's other check -- early writes of an A / B OPERAND --
+    instructions but not for inline asm (the in-place relu), docs/history/DESIGN_r1-r4.md 3.5.  (The script's other check -- early writes of an A / B OPERAND --
     is informational since round 3: tools/ubench/mfma_war.hip shows that gfx950 does not read operands after issue.)"""
 import os
 import re

@@ -821,7 +821,7 @@ def test_downsampling_convlayer_takes_the_stride2_kernel_and_matches_the_aten_ro
 
 def test_conv3x3_full_occupancy_runs_are_bitwise_identical():
     """The interleaved kernel hangs VALU / LDS / memory work between its MFMAs; the matrix instructions keep reading their operand
-    registers after issue, and a compiler that recycles such a register shows up as run-to-run differences once every
+    registers after issue (docs/history/DESIGN_r1-r4.md 3.5), and a compiler that recycles such a register shows up as run-to-run differences once every
     SIMD is busy -- never on small maps.  20 launches of a 1024 -> 512 @ 64^2 convolution (all fused terms) and of a 256 -> 256 @ 128^2
     one must agree bit for bit, and so must the plain 64 x 128 kernel (Cout = 64)."""
     from havatar_amd.native import conv

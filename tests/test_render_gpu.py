@@ -177,7 +177,7 @@ def test_bitwise_reproducible_and_ray_order_invariant():
 def test_full_occupancy_runs_are_bitwise_identical(mlp, perturb, coarse_outputs):
     """Eight launches of a 256x256 frame (every CU busy, thousands of tiles per SIMD) give bit-identical outputs, for every
     kernel variant the dispatcher can pick (arithmetic mode x jitter x with / without the coarse maps; the jitter stream is
-    rewound between launches).  Regression test for the gfx950 MFMA operand WAR hazard: an unprotected operand
+    rewound between launches).  Regression test for the gfx950 MFMA operand WAR hazard (docs/history/DESIGN_r1-r4.md 3.5): an unprotected operand
     shows up as ~0.4-1 % of the rays differing from run to run, in columns 16-31 of a tile.  tools/stress_determinism.py is the
     long version (512x512, 60 launches per variant)."""
     import torch
@@ -324,7 +324,7 @@ def test_fine_pass_cache_matches_reference_and_the_recompute_path(name, mlp, coa
     from havatar_amd import _lib
     g, sc, cfg, kw = load_render_fixture(name)
     if mlp == "half" and coarse_outputs:
-        pytest.skip("fp16 mode has no cache kernel that also carries the coarse maps (DESIGN.md 3.5): nothing to compare")
+        pytest.skip("fp16 mode has no cache kernel that also carries the coarse maps (docs/history/DESIGN_r1-r4.md 3.5): nothing to compare")
     o = hip_render(sc, dbg_zfine=True, mlp=mlp, coarse_outputs=coarse_outputs, flags=_lib.HAV_FLAG_FINE_CACHE, **cfg, **kw)
     r = hip_render(sc, dbg_zfine=True, mlp=mlp, coarse_outputs=coarse_outputs, flags=_lib.HAV_FLAG_FINE_RECOMPUTE, **cfg, **kw)
     assert o["variant"] == expected_variant(cfg, kw, mlp, coarse_outputs, cache=True), o["variant"]
@@ -355,7 +355,7 @@ def test_fine_pass_cache_is_the_default_with_jitter_and_needs_a_workspace(monkey
     assert fresh.variant(64, 16, perturb=True).endswith("<1, 3, 1>") and fresh.variant(64, 16, perturb=False, coarse_outputs=False).endswith("<0, 3, 2>")
     rm.mlp_mode = _lib.HAV_MLP_SPLIT_F16
     # fp16 mode (HAVATAR_MLP=half): the cache serves the fine-maps-only calls (with or without jitter); a call that also wants the coarse
-    # maps evaluates every merged sample (the fp16 kernels that would do both are not dispatched).
+    # maps evaluates every merged sample (the fp16 kernels that would do both are not dispatched, docs/history/DESIGN_r1-r4.md 3.5).
     # bf16 mode: the cache serves every call with a fine pass, with the coarse maps (<., 1, 1>) or without (<., 1, 2>)
     assert rm.variant(64, 16, perturb=True).endswith("2, 0>") and rm.variant(64, 16, perturb=False).endswith("2, 0>")
     assert rm.variant(64, 16, perturb=True, coarse_outputs=False).endswith("<1, 2, 2>")      # production: jitter, cache, fine maps only
@@ -403,7 +403,7 @@ def test_declined_coarse_outputs_leave_the_fine_maps_unchanged(mlp):
 def test_production_variants_512_frame_24_launches(perturb, mlp):
     """The production kernels <0|1|2, 1, 2> (bf16 triple split: the default arithmetic) and <0|1|2, 2, 2> (fp16 double split) on the full
     512x512 frame (8192 ray blocks, every SIMD holds two waves for the whole launch), 24 launches each: ALL bitwise identical.
-    Rounds 1-3 tolerated one differing launch (<= 32 rays of one block): the rare event of DESIGN.md 3.12, which round 3 traced to the
+    Rounds 1-3 tolerated one differing launch (<= 32 rays of one block): the rare event of docs/history/DESIGN_r1-r4.md 3.12, which round 3 traced to the
     compiler's IEEE division sequence in the skinning blend and removed (0 differing outputs in 41 000 launches of the shipped build:
     profiles/r03_stress_root_cause.txt).  The cause is gone, so the alarm is exact now; the failure message still says how many rays of
     how many blocks differ (<= 32 rays of one block = that fault class; thousands of rays = an unprotected matrix-core operand hazard).

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""How often does a replay of the graphed optimisation step flag a non-finite tensor (DESIGN.md 7 / 8.3)?
+"""How often does a replay of the graphed optimisation step flag a non-finite tensor (DESIGN.md 7.2)?
 
 In ONE process: BUILDS times a fresh Trainer + optimiser + StepRunner (2 eager steps, capture), then STEPS replays each with an eager
 inference render every RENDER_EVERY steps (what train.main() does between steps, and where round 4 saw its two events: the second replay

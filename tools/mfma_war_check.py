@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Static check of the gfx950 MFMA operand hazard of DESIGN.md 3.5 on compiler output: for every v_mfma in a kernel, list the instructions
+"""Static check of the gfx950 MFMA operand hazard of docs/history/DESIGN_r1-r4.md 3.5 on compiler output: for every v_mfma in a kernel, list the instructions
 that WRITE one of its A / B source registers before the matrix instruction can have finished reading them -- i.e. before the next
 v_mfma issues (it waits for the pipe) or WAIT wait states of s_nop have passed.  usage: mfma_war_check.py file.s kernel_symbol [WAIT]"""
 import re, sys

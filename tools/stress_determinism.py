@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Run-to-run determinism stress of the march kernel (the symptom of the gfx950 MFMA operand hazard of DESIGN.md 3.5 is a
+"""Run-to-run determinism stress of the march kernel (the symptom of the gfx950 MFMA operand hazard of docs/history/DESIGN_r1-r4.md 3.5 is a
 fraction of rays that differ from launch to launch): N launches per variant, every output compared bitwise with the first launch."""
 import os
 import sys

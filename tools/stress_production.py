@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """400 launches of the 512x512 frame on each of the two production variants (fine maps only, with / without jitter), every
-output compared bitwise with the first launch."""
+output compared bitwise with the first launch (docs/history/DESIGN_r1-r4.md 3.5)."""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch

@@ -1,5 +1,5 @@
-// Does v_mfma_f32_32x32x16_f16 on gfx950 still read its A / B operand registers after it has issued?  (DESIGN.md 3.5 inferred it from a
-// run-to-run difference whose signature -- columns 16-31 of a tile -- round 3 traced to something else)
+// Does v_mfma_f32_32x32x16_f16 on gfx950 still read its A / B operand registers after it has issued?  (docs/history/DESIGN_r1-r4.md 3.5 inferred it from a
+// run-to-run difference whose signature -- columns 16-31 of a tile -- round 3 traced to something else, docs/history/DESIGN_r1-r4.md 3.12.)
 // Every wave runs ITER matrix instructions; right behind each one (same asm block, no wait states) a VALU instruction overwrites one
 // register of the B operand (mode 1), of the A operand (mode 2), or nothing (mode 0); the operands are restored behind a long wait before
 // the next round.  If the matrix instruction reads its operands late, the accumulators of modes 1 / 2 differ from mode 0.

@@ -1,5 +1,5 @@
 // Probe of gfx950's block-scaled 6-/4-bit matrix path, which the march kernel's "fp16 x 2 + MX correction" arithmetic mode rests on
-// (DESIGN.md 3.14):
+// (DESIGN.md 3.3):
 //   T1  v_cvt_scalef32_pk32_{fp6,bf6}_f16 / v_cvt_scalef32_2xpk16_{fp6,bf6}_f32: element order inside the 6 result dwords, rounding,
 //       saturation, and the direction of the scale (divide or multiply);
 //   T2  v_mfma_scale_f32_32x32x64_f8f6f4 with A in {fp4, fp6, bf6} and B in {fp6, bf6}: which (lane, slot) of an operand is which

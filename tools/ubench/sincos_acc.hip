@@ -1,6 +1,6 @@
 // Accuracy of v_sin_f32 / v_cos_f32 (inputs in revolutions) after an exact-ish Cody-Waite reduction, against the polynomial
 // pe_pair of hav_render.hip, for the positional-encoding angles x = p * 2^k, |p| <= 1.6, k = 0..7.  Reference: double sin/cos of the
-// fp32 angle (what torch.sin rounds from).  Decides whether the hardware transcendentals can replace the polynomials.
+// fp32 angle (what torch.sin rounds from).  Decides whether the hardware transcendentals can replace the polynomials (docs/history/DESIGN_r1-r4.md 3.4).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
