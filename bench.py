@@ -11,7 +11,8 @@ What the default run (N = 1) times, each as its own loop of W warm-up + K timed 
   * cfg2 in every arithmetic mode of the radiance MLP -- bf16x3 (every operand hi + mid + lo bf16 = 24 bits, six products), exact fp32
     MFMA, and the 22-bit fp16 double split.  `value` is the FASTEST MODE THAT IS NOT NARROWER THAN THE REFERENCE'S fp32; the fp16
     double split is reported under modes.fp16x2 and is never the headline.
-  * extra.cfg4 (BASELINE configs[3]: the frame + SWGAN_unet 512 -> 1024) and extra.cfg5 (configs[4]: train_avatar.py's step).
+  * extra.cfg4 (BASELINE configs[3]: the frame + SWGAN_unet 512 -> 1024), extra.cfg5 (configs[4]: train_avatar.py's step), extra.cfg3
+    (configs[2] on one GPU: B = 1 / 2 / 4 frames per hipGraph replay).
   * cpu_baseline: the whole frame on the host cores -- the oracle's ray march (OpenMP) + this repo's PyTorch-CPU statement of the
     tri-plane encoders.
   * roofline.power: socket power and shader clock sampled during a sustained replay of the headline loop (the kernel runs at the
@@ -378,6 +379,9 @@ def main():
     ap.add_argument("--workload", choices=["cfg2", "cfg3", "cfg4", "cfg5"], default="cfg2")
     ap.add_argument("--extras", type=int, default=1, help="N = 1, cfg2: also time every arithmetic mode, cfg4 and cfg5 (extra.*) in this run")
     ap.add_argument("--frames", type=int, default=64, help="cfg3: frames per batch (one step = one batch)")
+    ap.add_argument("--frame-batch", type=int, default=0,
+                    help="cfg3: frames per hipGraph replay (the encoders see a batch, the march B x R rays in one launch).  0 = at N = 1 time "
+                         "B = 1, 2 and 4 and report the fastest (config.frames_per_replay holds all three); at N > 1: 4")
     ap.add_argument("--force-collective", type=int, default=0,
                     help="cfg3 at N=1: create a 1-rank RCCL group and send every finished frame through the side-stream all_gather "
                          "(the exchange step's HIP branch on one GPU)")
@@ -466,16 +470,19 @@ def main():
     data = dict(ray_batch=rays, background_prior=bg, inv_head_T=poses[0], front_render_cond=front, left_render_cond=left,
                 right_render_cond=right, mode="validation", fidx=0, render_full_img=True)
 
-    def make_render():
-        """The frame as a callable pose -> (render, mask, ...) in the marcher's CURRENT arithmetic mode (re-captured per mode)."""
+    def make_render(fb=1):
+        """The frame as a callable pose -> (render, mask, ...) in the marcher's CURRENT arithmetic mode (re-captured per mode).
+        fb > 1: `fb` frames per call -- poses [fb,4,3] -> render [fb,67,H,W] (every frame of the batch with its own pose; the synthetic
+        condition images are the same for all frames, as in the one-frame loop)."""
+        d = data if fb == 1 else {k: (v.expand(fb, *v.shape[1:]).contiguous() if torch.is_tensor(v) else v) for k, v in data.items()}
         if args.graph:
             from havatar_amd.graph import GraphedForward
-            frame = GraphedForward(tr, data)                   # the whole frame = one hipGraph launch (+ the pose copy)
+            frame = GraphedForward(tr, d)                      # the whole frame = one hipGraph launch (+ the pose copy)
             return lambda pose: frame(inv_head_T=pose)
 
         def eager(pose):
             with torch.no_grad():
-                return tr(**{**data, "inv_head_T": pose})
+                return tr(**{**d, "inv_head_T": pose})
         return eager
 
     def timed_loop(step, frames_per_step):
@@ -524,22 +531,51 @@ def main():
     gather = None
     out = None
     loops = {}
+    frames_per_replay = None
     for mode in mode_list:
         set_mode(mode)
         render = make_render()
         if args.workload == "cfg3":
             # one step = one batch of --frames frames: this rank renders frames rank, rank + N, ...; the finished RGB frame of round r is
-            # all-gathered (RCCL over xGMI) while round r + 1 renders; every rank ends the step holding the whole batch
+            # all-gathered (RCCL over xGMI) while round r + 1 renders; every rank ends the step holding the whole batch.  Throughput
+            # mode: FB of this rank's frames per hipGraph replay (avatarHD_reenactment.py:149-170 is a loop over independent frames and
+            # model/nerf_model.py:58-86 takes a batch), each still handed to the exchange as its own round.
             from havatar_amd.frames import OverlappedFrameGather
             gather = OverlappedFrameGather(args.frames, (3, H, W), device=dev, force_collective=bool(args.force_collective))
             batch_poses = {k: t(synth.frame_pose(k % 64))[None] for k in range(rank, args.frames, world)}
 
-            def step(i, render=render):
-                for r in range(gather.rounds):
-                    k = gather.my_frame(r)
-                    gather.submit(r, None if k is None else render(batch_poses[k])[0][0, :3])
-                return gather.finalize()
+            def make_step(fb, render1=render):
+                render_fb = make_render(fb) if fb > 1 else None
+
+                def step(i):
+                    r = 0
+                    while r < gather.rounds:
+                        ks = [gather.my_frame(r + b) for b in range(fb) if r + b < gather.rounds]
+                        if fb > 1 and len(ks) == fb and None not in ks:
+                            out = render_fb(torch.cat([batch_poses[k] for k in ks]))[0]
+                            for b in range(fb):
+                                gather.submit(r + b, out[b, :3])
+                            r += fb
+                        else:                                   # ragged tail of the batch: one frame per replay
+                            k = gather.my_frame(r)
+                            gather.submit(r, None if k is None else render1(batch_poses[k])[0][0, :3])
+                            r += 1
+                    return gather.finalize()
+                return step
+            fbs = [args.frame_batch] if args.frame_batch > 0 else ([1, 2, 4] if (world == 1 and not cpu) else [1 if cpu else 4])
             frames_per_step = args.frames
+            frames_per_replay = {}
+            best = None
+            for fb in fbs:
+                st = make_step(fb)
+                dt_, fps_, out_ = timed_loop(st, frames_per_step)
+                frames_per_replay[str(fb)] = {"frames_per_s": round(fps_, 3), "ms_per_frame": round(1e3 * dt_ / (args.steps * args.frames) * world, 3)}
+                if best is None or fps_ > best[1]:
+                    best = (dt_, fps_, out_, st, fb)
+            dt, fps, out, step = best[:4]
+            frames_per_replay["used"] = best[4]
+            loops[mode] = {"dt": dt, "fps": fps, "render": render, "step": step, "frames_per_step": frames_per_step}
+            continue
         elif args.workload == "cfg4":
             upsample = make_upsampler(args, render, poses, dev)
 
@@ -585,6 +621,9 @@ def main():
     n_ev = max(3, min(args.steps, 10))
     kern_ms, variants = {}, {}
     with torch.no_grad():
+        # (the last timed replay may have been a batched one: the planes of ONE frame for the per-phase timings below)
+        tr.model_coarse.set_conditional_embedding(front_render_cond=front, left_render_cond=left, right_render_cond=right,
+                                                  latents=tr.latent_codes[0:1], cond_c=poses[0].view(1, -1))
         for mode in mode_list:
             set_mode(mode)
             m.set_mlp(*[t_.detach() for t_ in tr.model_coarse.mlp_tensors()])
@@ -719,7 +758,7 @@ def main():
                                               "(avatarHD_reenactment.py:153-160): its 3x3 / up-sampling convolutions, Haar transforms, upfirdn2d and "
                                               "fused_bias_act are kernels of this library, stride-2 / 1x1 convolutions MIOpen; phase_ms.encoders_P3_inside_the_graph "
                                               "includes the upsampler in this workload"} if args.workload == "cfg4" else None),
-                       "rays_per_frame": H * W, "num_coarse": S_C, "num_fine": S_F, "perturb": perturb, "hipgraph": bool(args.graph),
+                       "rays_per_frame": H * W, "num_coarse": S_C, "num_fine": S_F, "perturb": perturb, "hipgraph": bool(args.graph), "frames_per_replay": frames_per_replay,
                        "hipgraph_packet_capture": os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "runtime default"),          # "0": havatar_amd/__init__.py (ROCm graph-replay fault)
                        "parallelism": ("frames sharded, %d rank(s), one overlapped all_gather of finished frames per round" if args.workload == "cfg3"
                                        else "frames sharded, %d rank(s), no data-path collective") % world,
@@ -783,6 +822,29 @@ def main():
                                         "what": "BASELINE configs[3]: the cfg2 frame + SWGAN_unet on render[:, 3:] (avatarHD_reenactment.py:153-160), both hipGraphs"}
             except Exception as e:          # an extra must never cost the headline line
                 res["extra"]["cfg4"] = {"error": repr(e)[:300]}
+            # BASELINE configs[2] at N = 1 (its exchange degenerates to a frame copy): a batch of 16 frames per step, B = 1 / 2 / 4 frames per
+            # hipGraph replay (throughput mode: the encoders see a batch, the march B x R rays per launch); bench.py --workload cfg3 is the full loop
+            try:
+                set_mode(head)
+                c3 = {}
+                n3 = 16
+                for fb in (1, 2, 4):
+                    rfb = loops[head]["render"] if fb == 1 else make_render(fb)
+                    pz = [torch.cat([poses[(j + b) % len(poses)] for b in range(fb)]) for j in range(0, n3, fb)]
+
+                    def step3(i, rfb=rfb, pz=pz):
+                        o = None
+                        for pp in pz:
+                            o = rfb(pp)
+                        return o
+                    dt3, fps3, _ = timed_loop(step3, n3)
+                    c3[str(fb)] = {"frames_per_s": round(fps3, 3), "ms_per_frame": round(1e3 * dt3 / (args.steps * n3), 3)}
+                    del rfb
+                res["extra"]["cfg3"] = {"frames_per_replay": c3, "frames_per_step": n3, "arithmetic_mode": head, "n_gpus": 1,
+                                        "what": "BASELINE configs[2] on ONE GPU: frames per second over a sequence of frames with B frames per hipGraph replay "
+                                                "(tests/test_frames_gpu.py::test_batched_frames_equal_the_frames_rendered_one_at_a_time: march bit-exact, frame <= 1e-3)"}
+            except Exception as e:
+                res["extra"]["cfg3"] = {"error": repr(e)[:300]}
             try:
                 r5 = run_cfg5(args, emit=False)
                 res["extra"]["cfg5"] = {"steps_per_s": r5["value"], "ms_per_step": r5["ms_per_step"], "dtype": r5["dtype"], "roofline": r5["roofline"],

@@ -7,6 +7,9 @@ test-mode frame (B=1) -> `Trainer(**inp)` (validation mode, full image) -> `SWGA
 -> clip(x*255, 0, 255) uint8 -> `<savedir>/rgb/<fidx>_<view:02d>.png`.
 What is different by design: the frame is one hipGraph launch per stage when shapes are static (HAVATAR_GRAPH=0 disables), and
 with more than one process (torchrun) the frames of the split are dealt round-robin to the ranks (no data-path collective).
+Throughput mode: HAVATAR_FRAME_BATCH=B (default 1 = the reference's sequence) renders B of this rank's frames per call -- the encoders
+and the upsampler see a batch, the march takes B x R rays in one launch; files and pixels are those of the one-frame loop (frames of a batch
+differ from the same frames rendered alone by the encoders' rounding, 1e-4 on the render; a ragged last batch is rendered at its own size).
 """
 import argparse
 import os
@@ -66,13 +69,15 @@ def frame_inputs(idx, batch, device, size=None, cache=None):
     generated on the device (hav_gen_rays) and the white background prior is a cached constant."""
     if "camera" in batch:
         from ..render import gen_rays
-        cam = batch["camera"][0]
+        n = batch["camera"].shape[0]
         cache = cache if cache is not None else {}
-        if "rays" not in cache:
-            cache["rays"] = torch.empty(1, size * size, 8, device=device)
-            cache["bg"] = torch.ones(1, size * size, 3, device=device)
-        rays_dev = gen_rays(size, size, cam[0:4], cam[4:16], float(cam[16]), float(cam[17]), device, out=cache["rays"])
-        ray_batch, bg = rays_dev, cache["bg"]
+        if ("rays", n) not in cache:
+            cache[("rays", n)] = torch.empty(n, size * size, 8, device=device)
+            cache[("bg", n)] = torch.ones(n, size * size, 3, device=device)
+        for b in range(n):
+            cam = batch["camera"][b]
+            gen_rays(size, size, cam[0:4], cam[4:16], float(cam[16]), float(cam[17]), device, out=cache[("rays", n)][b:b + 1])
+        ray_batch, bg = cache[("rays", n)], cache[("bg", n)]
     else:
         rays = batch["mv_rays"]
         ray_batch, bg = rays[..., :-3].to(device), rays[..., -3:].to(device)
@@ -120,10 +125,11 @@ def main(argv=None, device=None, style=None):
     val_loader.dataset.device_rays = device.type == "cuda" and os.environ.get("HAVATAR_DEVICE_RAYS", "1") != "0"
     ray_cache = {}
     # this rank's frames only, read ahead by worker processes (the reference reads every frame in the main process)
-    frames = torch.utils.data.DataLoader(torch.utils.data.Subset(val_loader.dataset, mine), batch_size=1, shuffle=False,
+    fbatch = max(1, int(os.environ.get("HAVATAR_FRAME_BATCH", "1")))
+    frames = torch.utils.data.DataLoader(torch.utils.data.Subset(val_loader.dataset, mine), batch_size=fbatch, shuffle=False,
                                          num_workers=int(os.environ.get("HAVATAR_WORKERS", 4)), pin_memory=device.type == "cuda")
     use_graph = device.type == "cuda" and os.environ.get("HAVATAR_GRAPH", "1") != "0"
-    graphed, graphed2, written = None, None, []
+    graphed, graphed2, written = {}, {}, []            # hipGraphs per batch size (the last batch of a split may be ragged)
     writers = ThreadPoolExecutor(max_workers=int(os.environ.get("HAVATAR_PNG_THREADS", 12)))    # PNG deflate off the critical path (a 1024^2 frame is ~70 ms of zlib on one core)
     pending, ring, in_flight = [], [None, None], None
     t_first = t_loop = None
@@ -133,42 +139,48 @@ def main(argv=None, device=None, style=None):
                 t_first = time.perf_counter()
             elif t_loop is None:
                 t_loop = time.perf_counter()             # steady state starts after the first frame (solver search, graph capture)
-            name, k = str(int(val_batch["fidx"][0])), int(val_batch["vidx"][0])
+            n = int(val_batch["fidx"].shape[0])
             inp = frame_inputs(idx, val_batch, device, size=val_loader.dataset.img_h, cache=ray_cache)
+            styles = [style if n == 1 else style.expand(n, -1)]
             if use_graph:
                 tens = {k_: v for k_, v in inp.items() if torch.is_tensor(v) and k_ != "fidx"}
-                if graphed is None:
+                if n not in graphed:
                     fixed = {k_: v for k_, v in inp.items() if k_ not in tens}
-                    graphed = GraphedForward(lambda **kw: nerf_render(**kw, **fixed), tens)
-                render, _, _ = graphed(**tens)
+                    graphed[n] = GraphedForward(lambda fixed=fixed, **kw: nerf_render(**kw, **fixed), tens)
+                render, _, _ = graphed[n](**tens)
                 cond = {"condition_img": render[:, 3:].contiguous()}
-                if graphed2 is None:
-                    graphed2 = GraphedForward(lambda condition_img: img_trans(styles=[style], condition_img=condition_img), cond)
-                gen_img = graphed2(**cond)
+                if n not in graphed2:
+                    graphed2[n] = GraphedForward(lambda condition_img, styles=styles: img_trans(styles=styles, condition_img=condition_img), cond)
+                gen_imgs = graphed2[n](**cond)
             else:
                 render, _, _ = nerf_render(**inp)
-                gen_img = img_trans(styles=[style], condition_img=render[:, 3:])
-            path = os.path.join(args.savedir, "rgb", f"{name}_{k:02d}.png")
-            written.append(path)
-            if device.type != "cuda":
-                pending.append(writers.submit(imgio.imwrite_rgb, path, to_png_array(gen_img)))
-                continue
-            # two-slot read-back ring: frame n's uint8 image is copied to pinned memory asynchronously and handed to the PNG
-            # threads while frame n+1 is being prepared and launched, so the GPU does not idle during host work
-            slot = len(written) & 1
-            if ring[slot] is None:
-                H2, W2 = gen_img.shape[-2:]
-                ring[slot] = (torch.empty(H2, W2, 3, dtype=torch.uint8, device=device), torch.empty(H2, W2, 3, dtype=torch.uint8).pin_memory(),
-                              torch.cuda.Event())
-            dev_u8, host_u8, ev = ring[slot]
-            dev_u8.copy_((gen_img[0].permute(1, 2, 0) * 255).clamp_(0, 255))          # float -> uint8 truncation, as to_png_array
-            host_u8.copy_(dev_u8, non_blocking=True)
-            ev.record()
-            if in_flight is not None:                                                  # finish the PREVIOUS frame now
-                p_path, p_slot = in_flight
-                ring[p_slot][2].synchronize()
-                pending.append(writers.submit(imgio.imwrite_rgb, p_path, ring[p_slot][1].numpy().copy()))
-            in_flight = (path, slot)
+                gen_imgs = img_trans(styles=styles, condition_img=render[:, 3:])
+            for b in range(n):
+                gen_img = gen_imgs[b:b + 1]
+                name, k = str(int(val_batch["fidx"][b])), int(val_batch["vidx"][0][b])          # ("vidx" is a one-element list per item: collated to [tensor[n]])
+                path = os.path.join(args.savedir, "rgb", f"{name}_{k:02d}.png")
+                written.append(path)
+                if device.type != "cuda":
+                    pending.append(writers.submit(imgio.imwrite_rgb, path, to_png_array(gen_img)))
+                    continue
+                # two-slot read-back ring: frame n's uint8 image is copied to pinned memory asynchronously and handed to the PNG
+                # threads while frame n+1 is being prepared and launched, so the GPU does not idle during host work
+                slot = len(written) & 1
+                if ring[slot] is None:
+                    H2, W2 = gen_img.shape[-2:]
+                    ring[slot] = (torch.empty(H2, W2, 3, dtype=torch.uint8, device=device), torch.empty(H2, W2, 3, dtype=torch.uint8).pin_memory(),
+                                  torch.cuda.Event())
+                dev_u8, host_u8, ev = ring[slot]
+                if in_flight is not None and in_flight[1] == slot:                         # (batched frames: the slot's previous image must have left)
+                    ring[slot][2].synchronize()
+                dev_u8.copy_((gen_img[0].permute(1, 2, 0) * 255).clamp_(0, 255))          # float -> uint8 truncation, as to_png_array
+                host_u8.copy_(dev_u8, non_blocking=True)
+                ev.record()
+                if in_flight is not None:                                                  # finish the PREVIOUS frame now
+                    p_path, p_slot = in_flight
+                    ring[p_slot][2].synchronize()
+                    pending.append(writers.submit(imgio.imwrite_rgb, p_path, ring[p_slot][1].numpy().copy()))
+                in_flight = (path, slot)
     if in_flight is not None:
         p_path, p_slot = in_flight
         ring[p_slot][2].synchronize()

@@ -95,6 +95,10 @@ class Trainer(torch.nn.Module):
         B = ray_batch.shape[0]
         latent_code = self.latent_codes[data["fidx"]] if data["mode"] == "train" else self.latent_codes[0:1]
         latent_code_loss = torch.square(latent_code - self.latent_codes.mean(dim=0, keepdims=True).detach()).mean()
+        if data["mode"] != "train" and B > 1:
+            # batched inference (B frames per call: frames.py / bench.py --workload cfg3 --batch): the one validation code serves every frame
+            # of the batch.  (The reference only ever calls this with B = 1 -- its cat([latent, cond_c]) does not broadcast.)
+            latent_code = latent_code.expand(B, -1)
         rgb_coarse, _, acc_coarse, weights, rgb_fine, _, acc_fine = self.nerf_forward(
             ray_batch=ray_batch, background_prior=background_prior, latent_code=latent_code, inv_head_T=data["inv_head_T"],
             front_render_cond=data["front_render_cond"], left_render_cond=data["left_render_cond"],

@@ -21,7 +21,7 @@ class HavRenderParams(C.Structure):
                 ("skin_scale", C.c_float * 3), ("skin_trans", C.c_float * 3),
                 ("seed", C.c_uint64), ("rng_offset", C.c_uint64), ("mlp_mode", C.c_int32), ("flags", C.c_int32),
                 ("rng_counter", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64),
-                ("dbg_zfine", C.c_void_p), ("status", C.c_void_p)]
+                ("dbg_zfine", C.c_void_p), ("status", C.c_void_p), ("grid_blocks", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class HavMlpWeights(C.Structure):

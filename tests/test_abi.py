@@ -68,7 +68,7 @@ def test_struct_layouts_match_header(tmp_path):
             assert got == int(val), (name, field, m.__module__, got, int(val))
             seen += 1
     assert seen > 60
-    assert ctypes.sizeof(_lib.HavRenderParams) == 152
+    assert ctypes.sizeof(_lib.HavRenderParams) == 160          # ABI 6: + grid_blocks, reserved0
 
 
 def test_product_never_imports_oracle():

@@ -134,3 +134,51 @@ def test_gather_frames_one_rank_rccl(nccl_one_rank):
     for r, x in enumerate(xs):
         g.submit(r, x)
     assert torch.equal(g.finalize(), torch.stack(xs, 0))
+
+
+@pytest.mark.parametrize("B", [2, 4])
+def test_batched_frames_equal_the_frames_rendered_one_at_a_time(B):
+    """Throughput mode of BASELINE config 3 (bench.py --workload cfg3 --frame-batch B, HAVATAR_FRAME_BATCH of the reenactment CLI): B frames
+    per call -- the encoders (model/nerf_model.py:58-86 take a batch) see B condition sets, the march B x R rays in one launch.  Every frame
+    has its own pose AND its own condition images.  (1) The march itself is bit-exact: given the planes of the one-frame calls, frame b of
+    the batched launch equals the one-frame launch.  (2) The whole frame: the encoders' kernels pick other tilings at B > 1 (their
+    results move by rounding, <= 3e-5 on the planes), the rendered frame stays within 1e-3 of the one rendered alone (measured 1e-4)."""
+    dev = torch.device("cuda", 0)
+    S = 64
+    tr, data, pose = _trainer(S, dev)
+    scale = lambda k: 1.0 - 0.07 * k
+    one = lambda k: {**data, "inv_head_T": pose(k), **{c: data[c] * scale(k) for c in ("front_render_cond", "left_render_cond", "right_render_cond")}}
+    singles, planes = [], []
+    with torch.no_grad():
+        for k in range(B):
+            render, mask, _ = tr(**one(k))
+            singles.append((render.clone(), mask.clone()))
+            planes.append(tr.model_coarse.triPlane_embeddings.clone())
+        rep = lambda x: x.expand(B, *x.shape[1:]).contiguous()
+        batch = {**data, "ray_batch": rep(data["ray_batch"]), "background_prior": rep(data["background_prior"]),
+                 "inv_head_T": torch.cat([pose(k) for k in range(B)]),
+                 **{c: torch.cat([data[c] * scale(k) for k in range(B)]) for c in ("front_render_cond", "left_render_cond", "right_render_cond")}}
+        render_b, mask_b, _ = tr(**batch)
+        planes_b = tr.model_coarse.triPlane_embeddings.clone()
+    assert render_b.shape == (B,) + tuple(singles[0][0].shape[1:])
+    for k in range(B):
+        assert float((planes_b[:, k] - planes[k][:, 0]).abs().max()) <= 3e-5 * float(planes[k].abs().max()) + 1e-6
+        assert float((render_b[k:k + 1] - singles[k][0]).abs().max()) <= 1e-3
+        assert float((mask_b[k:k + 1] - singles[k][1]).abs().max()) <= 1e-3
+        assert float((singles[k][0] - singles[(k + 1) % B][0]).abs().max()) > 1e-2          # the frames really differ
+    # (1) the march alone, on the one-frame planes stacked into a batch
+    m = tr._hip_marcher()
+    rd = batch["ray_batch"][..., 3:6]
+    rays = torch.cat((batch["ray_batch"], rd / rd.norm(p=2, dim=-1).unsqueeze(-1)), dim=-1)
+    vol = tr.headpose_skin_net.current_volume().detach()
+    with torch.no_grad():
+        m.set_mlp(*[x.detach() for x in tr.model_coarse.mlp_tensors()])
+        m.set_triplane(torch.cat(planes, dim=1))
+        out_b = [o.clone() if o is not None else None for o in m.render(rays, batch["background_prior"], batch["inv_head_T"], vol, 64, 16, perturb=False)]
+        for k in range(B):
+            m.set_triplane(planes[k])
+            out_1 = m.render(rays[k:k + 1], batch["background_prior"][k:k + 1], batch["inv_head_T"][k:k + 1], vol, 64, 16, perturb=False)
+            for a, b in zip(out_b, out_1):
+                assert (a is None) == (b is None)
+                if a is not None:
+                    assert torch.equal(a[k:k + 1], b)

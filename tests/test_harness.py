@@ -100,6 +100,16 @@ def test_reenactment_cli_cpu(tmp_path, dataset, gold):
         _png_close(img, gold["h1_png_%d" % k], max_lsb=1, max_frac=0.01)
 
 
+def test_reenactment_cli_cpu_batched_frames(tmp_path, dataset, gold, monkeypatch):
+    """Throughput mode of the CLI (HAVATAR_FRAME_BATCH=2: both frames of the split in ONE call of the renderer and of the upsampler):
+    same file names, same pixels as the reference's one-frame sequence."""
+    monkeypatch.setenv("HAVATAR_FRAME_BATCH", "2")
+    monkeypatch.setenv("HAVATAR_WORKERS", "0")
+    imgs = _run_reenact(tmp_path, dataset, "cpu")
+    for k, img in enumerate(imgs):
+        _png_close(img, gold["h1_png_%d" % k], max_lsb=1, max_frac=0.01)
+
+
 def test_reenactment_style_vector_matches_reference_rng(gold):
     """avatarHD_reenactment.py:147 draws the style AFTER both constructors consumed the seeded RNG: same stream here."""
     from havatar_amd.harness import reenact
@@ -328,6 +338,16 @@ def test_reenactment_cli_gpu(tmp_path, dataset, gold):
             assert (mask.cpu().numpy() - gold["h1_mask_%d" % k]).__abs__().max() <= 1e-3
             gen = img_trans(styles=[style], condition_img=render[:, 3:])
             assert (gen.cpu().numpy() - gold["h1_gen_%d" % k]).__abs__().max() <= 5e-3
+
+
+@pytest.mark.gpu
+def test_reenactment_cli_gpu_batched_frames(tmp_path, dataset, gold, monkeypatch):
+    """H1 in throughput mode on the device (HAVATAR_FRAME_BATCH=2: one hipGraph replay per stage for both frames; device-side ray
+    generation for a batch): the PNGs of the one-frame sequence, within the same 2 LSB of the reference's."""
+    monkeypatch.setenv("HAVATAR_FRAME_BATCH", "2")
+    imgs = _run_reenact(tmp_path, dataset, "cuda")
+    for k, img in enumerate(imgs):
+        _png_close(img, gold["h1_png_%d" % k], max_lsb=2, max_frac=0.05)
 
 
 @pytest.mark.gpu
