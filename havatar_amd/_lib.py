@@ -99,6 +99,10 @@ def lib():
     L.hav_field_inputs_fwd.restype = i32
     L.hav_field_inputs_bwd.argtypes = [vp, vp, vp, C.POINTER(HavFieldParams), vp, vp, vp, vp, vp]
     L.hav_field_inputs_bwd.restype = i32
+    L.hav_field_inputs_bwd_fixed.argtypes = [vp, vp, vp, vp, vp, C.POINTER(HavFieldParams), vp, vp, vp, vp, vp]
+    L.hav_field_inputs_bwd_fixed.restype = i32
+    L.hav_field_inputs_bwd_fixed_scratch_bytes.argtypes = [C.POINTER(HavFieldParams)]
+    L.hav_field_inputs_bwd_fixed_scratch_bytes.restype = i64
     L.hav_composite_fwd.argtypes = [vp] * 9 + [i64, i32, i32, i32, vp]
     L.hav_composite_fwd.restype = i32
     L.hav_composite_bwd.argtypes = [vp] * 10 + [i64, i32, i32, i32, vp]
@@ -136,6 +140,10 @@ def lib():
     L.hav_conv3x3_pack_t.restype = i32
     L.hav_conv3x3_wgrad_mod.argtypes = [vp, vp, vp, vp, f32, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     L.hav_conv3x3_wgrad_mod.restype = i32
+    L.hav_conv3x3s2_wgrad.argtypes = [vp, vp, vp, vp, f32, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    L.hav_conv3x3s2_wgrad.restype = i32
+    L.hav_conv3x3s2_wgrad_scratch_bytes.argtypes = [i32] * 5
+    L.hav_conv3x3s2_wgrad_scratch_bytes.restype = i64
     L.hav_conv_block_bwd.argtypes = [vp] * 11 + [f32, f32, i32, i32, i32, i32, i64, vp]
     L.hav_conv_block_bwd.restype = i32
     L.hav_mod_input_bwd.argtypes = [vp, vp, vp, vp, i32, i32, i64, vp]

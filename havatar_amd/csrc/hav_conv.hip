@@ -1287,8 +1287,9 @@ __global__ void __launch_bounds__(256, 2) conv3x3_wgrad_kernel(WgradArgs a)
     }
 }
 
+// transpose: the partials are [o][i]; write gw as [i][o][3][3] (the stride-2 kernel below, called with the operands of a transposed convolution)
 __global__ void __launch_bounds__(256) conv3x3_wgrad_reduce_kernel(float* __restrict__ gw, const float* __restrict__ partial, int ks, int Cout, int Cin,
-                                                                   float out_mul)
+                                                                   float out_mul, int transpose)
 {
     const int64_t n = (int64_t)Cout * Cin;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
@@ -1299,8 +1300,9 @@ __global__ void __launch_bounds__(256) conv3x3_wgrad_reduce_kernel(float* __rest
             for (int k = 0; k < ks; ++k) s += partial[((int64_t)k * 9 + t) * n + e];
             v[t] = s;
         }
+        const int64_t d = transpose ? ((e % Cin) * Cout + e / Cin) : e;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) gw[e * 9 + t] = v[t] * out_mul;
+        for (int t = 0; t < 9; ++t) gw[d * 9 + t] = v[t] * out_mul;
     }
 }
 
@@ -1347,7 +1349,221 @@ static int wgrad_launch(float* gw, const float* g, const float* x, const float* 
     const int64_t n = (int64_t)Cout * Cin;
     int64_t blocks = (n + 255) / 256;
     if (blocks > (int64_t)hav_num_cus() * 8) blocks = (int64_t)hav_num_cus() * 8;
-    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gw, (const float*)scratch, ks, Cout, Cin, out_mul);
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gw, (const float*)scratch, ks, Cout, Cin, out_mul, 0);
+    HAV_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the STRIDE-2 3x3 layers (training): one contraction serves both re-sampling layers of the StyleGAN blocks --
+//
+//   out[m, n, ky, kx] = sum_{b, y, x} S[b, m, y, x] * L[b, n, 2 y + ky, 2 x + kx]          S: [B,M,H,W]   L: [B,N,2H+1,2W+1]
+//
+//   * the down-sampling ConvLayer (Blur -> conv 3x3 stride 2 padding 0, reference model/styleUnet.py:326-368): S = the gradient at the
+//     layer's output, L = the blurred input -> gw[Cout][Cin][3][3];
+//   * the up-sampling StyledConv (conv_transpose2d stride 2, model/styleUnet.py:214-231): S = the modulated input s * x (ss = s), L = the
+//     gradient at the transposed convolution's output -> [Cin][Cout][3][3], written transposed as the parameter's [Cout][Cin][3][3].
+// MIOpen's route for these was igemm_wrw / CK fp32 kernels + NHWC transposes (3.7 ms of a 24 ms step).  Same scheme as conv3x3_wgrad_kernel
+// above: M = S channels (64 per workgroup), N = L channels (32), K = pixels of S, one 16-pixel row segment per step; what changes is the N
+// operand's staging -- a step needs L rows 2y .. 2y+2 (two NEW rows per step: a ring of eight slots) and, per row, the 33 columns
+// 2 x0 .. 2 x0 + 32 de-interleaved into even / odd / even-shifted copies (kx = 0 / 1 / 2), again so that every MFMA operand is one 16-byte
+// LDS read.  Both operands under the power-of-two range control (S or L is gradient-sized).
+struct WgradS2Args {
+    float* partial; const float* s; const float* l; const unsigned int* s_amax; const unsigned int* l_amax;
+    const float* ss;          // optional [B, M]: the S operand is ss[b, m] * S
+    int B, M, N, H, W, strips;
+};
+
+__global__ void __launch_bounds__(256, 2) conv3x3s2_wgrad_kernel(WgradS2Args a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t xs[8][32 * WG_XI];
+    __shared__ __attribute__((aligned(16))) uint32_t gs[2][64 * WG_GO];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 31, h = lane >> 5;
+    const int mo = wave & 1, tg = wave >> 1;
+    const int i0 = blockIdx.x * 32, o0 = blockIdx.y * 64;
+    const int H = a.H, W = a.W, M = a.M, N = a.N, LH = 2 * H + 1, LW = 2 * W + 1;
+    const int sw = W / 16;
+    const int eg = a.s_amax ? amax_pow2(a.s_amax, lane, a.ss ? wave_absmax(a.ss, a.B * M, lane) : 1.0f) : 0;
+    const int ex = a.l_amax ? amax_pow2(a.l_amax, lane, 1.0f) : 0;
+    const float g_sc = pow2f(eg), x_sc = pow2f(ex);
+    const float out_g = pow2f(-eg), out_x = pow2f(-ex);
+    const int g_o = tid >> 2, g_q = tid & 3;          // S staging: thread = (channel, 4 pixels)
+    const int x_i = tid >> 3, x_p = tid & 7;          // L staging: thread = (channel, S-pixel pair = 4 L columns + 1)
+    f32x16 acc[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    auto split2 = [](float v0, float v1, uint32_t& hi, uint32_t& lo) {
+        const fl2_t f = {v0, v1};
+        const h2_t hh = __builtin_convertvector(f, h2_t);
+        const h2_t ll = __builtin_convertvector(f - __builtin_convertvector(hh, fl2_t), h2_t);
+        hi = __builtin_bit_cast(uint32_t, hh); lo = __builtin_bit_cast(uint32_t, ll);
+    };
+    // L row `row` (always inside the map: rows 0 .. 2H) of strip (b, x0), columns 2 x0 + 4 x_p .. + 4: e0 o0 e1 o1 (+ e2 = the next thread's e0)
+    struct LR { float e0, o0, e1, o1, er; };
+    auto fetch_l = [&](int b, int x0, int row) {
+        const float* src = a.l + (((int64_t)b * N + i0 + x_i) * LH + row) * LW + 2 * x0 + 4 * x_p;
+        LR r;
+        r.e0 = src[0]; r.o0 = src[1]; r.e1 = src[2]; r.o1 = src[3];
+        r.er = (x_p == 7) ? src[4] : 0.f;          // column 2 x0 + 32 <= 2 W: always there
+        return r;
+    };
+    auto stash_l = [&](int row, const LR& r) {
+        uint32_t* dst = xs[row & 7] + x_i * WG_XI;
+        float e2 = __shfl_down(r.e0, 1, 64);
+        if (x_p == 7) e2 = r.er;
+        uint32_t hi, lo;
+        split2(r.e0 * x_sc, r.e1 * x_sc, hi, lo); dst[0 * 16 + x_p] = hi; dst[0 * 16 + 8 + x_p] = lo;          // kx = 0: element j = L[2 (x0 + j)]
+        split2(r.o0 * x_sc, r.o1 * x_sc, hi, lo); dst[1 * 16 + x_p] = hi; dst[1 * 16 + 8 + x_p] = lo;          // kx = 1: L[2 (x0 + j) + 1]
+        split2(r.e1 * x_sc, e2 * x_sc, hi, lo);   dst[2 * 16 + x_p] = hi; dst[2 * 16 + 8 + x_p] = lo;          // kx = 2: L[2 (x0 + j) + 2]
+    };
+    auto fetch_g = [&](int b, int x0, int row) {
+        return *reinterpret_cast<const float4*>(a.s + (((int64_t)b * M + o0 + g_o) * H + row) * W + x0 + 4 * g_q);
+    };
+    auto stash_g = [&](int buf, const float4& v, float sc) {
+        uint32_t* dst = gs[buf] + g_o * WG_GO + 2 * g_q;
+        uint32_t h0, l0, h1, l1;
+        split2(v.x * sc, v.y * sc, h0, l0);
+        split2(v.z * sc, v.w * sc, h1, l1);
+        dst[0] = h0; dst[1] = h1; dst[8] = l0; dst[9] = l1;
+    };
+
+    for (int s = blockIdx.z; s < a.strips; s += gridDim.z) {
+        const int b = s / sw, x0 = (s - b * sw) * 16;
+        const float sc = a.ss ? g_sc * a.ss[(int64_t)b * M + o0 + g_o] : g_sc;
+        __syncthreads();          // the previous strip's last step is done with the ring
+        stash_l(0, fetch_l(b, x0, 0));
+        stash_l(1, fetch_l(b, x0, 1));
+        stash_l(2, fetch_l(b, x0, 2));
+        stash_g(0, fetch_g(b, x0, 0), sc);
+        __syncthreads();
+        for (int y = 0; y < H; ++y) {
+            const bool more = y + 1 < H;
+            LR n1 = {0.f, 0.f, 0.f, 0.f, 0.f}, n2 = {0.f, 0.f, 0.f, 0.f, 0.f};
+            float4 ng = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (more) { n1 = fetch_l(b, x0, 2 * y + 3); n2 = fetch_l(b, x0, 2 * y + 4); ng = fetch_g(b, x0, y + 1); }
+            const uint32_t* G = gs[y & 1] + (32 * mo + j) * WG_GO + 4 * h;
+            const f16x8_t gh = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(G));
+            const f16x8_t gl = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(G + 8));
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const int t = tg * 5 + q;          // tap (wave-uniform); tg = 1 has four (t = 5..8)
+                if (t < 9) {
+                    const int ky = t / 3, kx = t - 3 * ky;
+                    const uint32_t* X = xs[(2 * y + ky) & 7] + j * WG_XI + kx * 16 + 4 * h;
+                    const f16x8_t xh = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(X));
+                    const f16x8_t xl = __builtin_bit_cast(f16x8_t, *reinterpret_cast<const uint4*>(X + 8));
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl, xh, acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xl, acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, xh, acc[q], 0, 0, 0);
+                }
+            }
+            asm volatile(CV_MFMA_PAD : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]));
+            if (more) { stash_l(2 * y + 3, n1); stash_l(2 * y + 4, n2); stash_g((y + 1) & 1, ng, sc); }          // slots of rows 2y-5 .. 2y-4: long done
+            __syncthreads();
+        }
+    }
+    float* pp = a.partial + (int64_t)blockIdx.z * 9 * M * N;          // partial[z][t][m][n], lane j = n
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const int t = tg * 5 + q;
+        if (t < 9) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = o0 + 32 * mo + (r & 3) + 8 * (r >> 2) + 4 * h;
+                pp[((int64_t)t * M + o) * N + i0 + j] = acc[q][r] * out_g * out_x;
+            }
+        }
+    }
+}
+
+// The same contraction for SMALL maps (the 4^2 -> 8^2 and 8^2 -> 16^2 up-sampling layers: W < 16, K = B H W <= 128 pixels, 512 x 512 x 9
+// outputs): nothing for the matrix cores to chew on -- MIOpen's route was a 173 us CK kernel per layer -- so plain fp32 FMAs: a workgroup
+// owns 16 x 16 (m, n) pairs, stages its S rows (modulation folded in) and L rows in LDS once, thread (m, n) accumulates the nine taps over
+// all pixels in a fixed order (bit-reproducible, fp32-exact products: no range control needed).
+struct WgradS2SmallArgs { float* gw; const float* s; const float* l; const float* ss; float out_mul; int transpose, B, M, N, H, W, lstride; };
+__global__ void __launch_bounds__(256) conv3x3s2_wgrad_small_kernel(WgradS2SmallArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    const int B = a.B, M = a.M, N = a.N, H = a.H, W = a.W, HW = H * W, LH = 2 * H + 1, LW = 2 * W + 1, LHW = LH * LW;
+    float* sS = wsm;                          // [16][B * HW]
+    float* sL = wsm + 16 * B * HW;            // [16][lstride]  (lstride = B * LHW made odd: the 16 n of a wave hit 16 banks)
+    const int tid = threadIdx.x, m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+    for (int i = tid; i < 16 * B * HW; i += 256) {
+        const int mi = i / (B * HW), r = i - mi * (B * HW), b = r / HW, p = r - b * HW;
+        float v = a.s[((int64_t)b * M + m0 + mi) * HW + p];
+        if (a.ss) v *= a.ss[(int64_t)b * M + m0 + mi];
+        sS[i] = v;
+    }
+    for (int i = tid; i < 16 * B * LHW; i += 256) {
+        const int ni = i / (B * LHW), r = i - ni * (B * LHW), b = r / LHW, p = r - b * LHW;
+        sL[ni * a.lstride + r] = a.l[((int64_t)b * N + n0 + ni) * LHW + p];
+    }
+    __syncthreads();
+    const int mi = tid >> 4, ni = tid & 15;
+    float acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+    for (int b = 0; b < B; ++b)
+        for (int y = 0; y < H; ++y) {
+            const float* srow = sS + mi * (B * HW) + b * HW + y * W;
+            const float* lrow = sL + ni * a.lstride + b * LHW + (2 * y) * LW;
+            for (int x = 0; x < W; ++x) {
+                const float sv = srow[x];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = fmaf(sv, lrow[ky * LW + 2 * x + kx], acc[ky * 3 + kx]);
+            }
+        }
+    const int64_t d = a.transpose ? ((int64_t)(n0 + ni) * M + m0 + mi) : ((int64_t)(m0 + mi) * N + n0 + ni);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) a.gw[d * 9 + t] = acc[t] * a.out_mul;
+}
+
+static bool wgrad_s2_shape_ok(int B, int M, int N, int H, int W)
+{
+    return B >= 1 && H >= 1 && M >= 64 && N >= 32 && W >= 16 && !(M % 64) && !(N % 32) && !(W % 16);
+}
+static int wgrad_s2_small_lstride(int B, int H, int W) { return (B * (2 * H + 1) * (2 * W + 1)) | 1; }
+static bool wgrad_s2_small_ok(int B, int M, int N, int H, int W)
+{
+    if (B < 1 || H < 1 || W < 1 || W >= 16 || (M % 16) || (N % 16)) return false;
+    return (int64_t)(16 * B * H * W + 16 * wgrad_s2_small_lstride(B, H, W)) * 4 <= 64 * 1024;
+}
+extern "C" int64_t hav_conv3x3s2_wgrad_scratch_bytes(int B, int M, int N, int H, int W)
+{
+    if (!wgrad_s2_shape_ok(B, M, N, H, W)) return 0;          // (0 as well for the small-map kernel, which needs none, and for unsupported shapes)
+    return (int64_t)wgrad_ksplit(B, N, M, H, W) * 9 * M * N * 4;
+}
+extern "C" int hav_conv3x3s2_wgrad(float* gw, const float* S, const float* L, const float* ss, float out_mul, int transpose_out, void* scratch,
+                                   const void* s_amax, const void* l_amax, int B, int M, int N, int H, int W, void* stream)
+{
+    if (!gw || !S || !L || B < 1 || H < 1) return HAV_EINVAL;
+    if (wgrad_s2_small_ok(B, M, N, H, W)) {
+        WgradS2SmallArgs q;
+        q.gw = gw; q.s = S; q.l = L; q.ss = ss; q.out_mul = out_mul; q.transpose = transpose_out ? 1 : 0;
+        q.B = B; q.M = M; q.N = N; q.H = H; q.W = W; q.lstride = wgrad_s2_small_lstride(B, H, W);
+        const size_t lds = (size_t)(16 * B * H * W + 16 * q.lstride) * 4;
+        hipLaunchKernelGGL(conv3x3s2_wgrad_small_kernel, dim3((unsigned)(N / 16), (unsigned)(M / 16)), dim3(256), lds, (hipStream_t)stream, q);
+        HAV_LAUNCH_CHECK();
+        return 0;
+    }
+    if (!scratch) return HAV_EINVAL;
+    if (!wgrad_s2_shape_ok(B, M, N, H, W)) return HAV_EUNSUP;
+    if (((uintptr_t)S & 15) != 0) return HAV_EUNSUP;          // float4 loads of S rows (W % 16 == 0 keeps every row aligned)
+    WgradS2Args a;
+    a.partial = (float*)scratch; a.s = S; a.l = L; a.s_amax = (const unsigned int*)s_amax; a.l_amax = (const unsigned int*)l_amax; a.ss = ss;
+    a.B = B; a.M = M; a.N = N; a.H = H; a.W = W; a.strips = B * (W / 16);
+    const int ks = wgrad_ksplit(B, N, M, H, W);
+    hipLaunchKernelGGL(conv3x3s2_wgrad_kernel, dim3((unsigned)(N / 32), (unsigned)(M / 64), (unsigned)ks), dim3(256), 0, (hipStream_t)stream, a);
+    HAV_LAUNCH_CHECK();
+    const int64_t n = (int64_t)M * N;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > (int64_t)hav_num_cus() * 8) blocks = (int64_t)hav_num_cus() * 8;
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gw, (const float*)scratch, ks, M, N, out_mul,
+                       transpose_out ? 1 : 0);
     HAV_LAUNCH_CHECK();
     return 0;
 }

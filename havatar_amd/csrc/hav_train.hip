@@ -35,7 +35,26 @@ struct FieldArgs {
     float ss[3], st[3], bs[3], bt[3];
     int64_t n, n_per_b;
     int B, H, W, C, D;
+    // MODE 4 (bit-reproducible scatter): 64-bit fixed-point accumulators, the words of hav_absmax(dX), the buffered volume taps
+    long long* fplanes; const unsigned int* dx_amax; float* vval; int* vidx32; unsigned int* vmax; int fixbits;
 };
+
+// Bit-reproducible scatter (MODE 4, hav_field_inputs_bwd_fixed): float atomics make the sums depend on the order the atomics land in; integer
+// addition is associative, so every contribution v is added as llrint(v * 2^(fixbits - e)) into a 64-bit accumulator with 2^e > max |v|
+// (planes: |w g| <= max |dX|, known from hav_absmax(dX); volume: the taps are buffered, their maximum found on the way, and scattered by a
+// second small kernel).  fixbits = min(40, 61 - log2(number of contributions)): no sum can leave the 63 bits; a contribution keeps >= 2^-40
+// of the largest one, finer than the fp32 sum it replaces.  fixed_to_float_kernel turns the accumulators into the fp32 gradients.
+__device__ __forceinline__ int fold_max_exp(const unsigned int* words, int nwords, int lane)
+{
+    unsigned int mb = 0;
+    for (int i = lane; i < nwords; i += 64) mb = words[i] > mb ? words[i] : mb;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const unsigned int t = (unsigned int)__shfl_xor((int)mb, o, 64); mb = t > mb ? t : mb; }
+    const int be = (int)((mb >> 23) & 0xFFu);          // biased exponent of the maximum: max < 2^(be - 126)
+    const int e = be - 126;
+    return e < -80 ? -80 : (e > 100 ? 100 : e);        // (an all-zero gradient, or one beyond 2^100: the scales below stay normal floats)
+}
+__device__ __forceinline__ long long to_fixed(float v, float scale) { return __float2ll_rn(v * scale); }
 
 // bilinear taps of F.grid_sample(align_corners=True, padding_mode='zeros'); weights of out-of-range taps are zeroed
 __device__ __forceinline__ void plane_taps(float u, float v, int H, int W, int (&idx)[4], float (&w)[4], float& wx0, float& wx1,
@@ -59,6 +78,7 @@ __device__ __forceinline__ void plane_taps(float u, float v, int H, int W, int (
 // the other one consecutive bilinear cells share an edge.  Everything about a tap but its channel is wave-uniform (lane = channel), so
 // the texel ids live in SGPRs (readfirstlane), the match of old against new taps is scalar code with uniform branches, and a row of
 // atomics is only issued when a texel leaves the 2 x 2 window (or the run ends).  Sums are re-associated, not changed otherwise.
+// MODE 4: MODE 2's walk with 64-bit fixed-point sums and integer atomics (see above): the result does not depend on the order of anything.
 #define FI_RUN 16
 template <int MODE>
 __global__ void __launch_bounds__(256) field_inputs_kernel(FieldArgs a)
@@ -67,12 +87,16 @@ __global__ void __launch_bounds__(256) field_inputs_kernel(FieldArgs a)
     const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const int C = a.C, H = a.H, W = a.W, D = a.D, XW = 2 * C + PE_DIM;
     const size_t plane_sz = (size_t)a.B * H * W * C, vol_sz = (size_t)D * D * D;
-    constexpr int RUN = MODE == 2 ? FI_RUN : 1;
+    constexpr int RUN = (MODE == 2 || MODE == 4) ? FI_RUN : 1;
+    constexpr bool WIN = MODE == 2 || MODE == 4;          // tap windows in registers
+    const float pscale = MODE == 4 ? __uint_as_float((unsigned int)(127 + a.fixbits - fold_max_exp(a.dx_amax, 256, lane)) << 23) : 0.f;
+    float vmax_w = 0.f;
     const int64_t nruns = (a.n + RUN - 1) / RUN;
     for (int64_t run = wave0; run < nruns; run += nwaves) {
     // MODE 2: the window of each plane -- row ids (texel row of dplanes in units of C floats, -1 = empty) and this lane's pending sums
     int wkey[2][4] = {{-1, -1, -1, -1}, {-1, -1, -1, -1}};
     float wacc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    long long facc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};          // (MODE 4)
     for (int qi = 0; qi < RUN; ++qi) {
         const int64_t i = run * RUN + qi;
         if (i >= a.n) break;
@@ -115,15 +139,15 @@ __global__ void __launch_bounds__(256) field_inputs_kernel(FieldArgs a)
             const float* pl = a.planes + p * plane_sz + (size_t)b * H * W * C;
             // MODE 2 (C <= 64): exactly one trip for every lane (idle lanes take channel C - 1 with a zero gradient), so that the window
             // bookkeeping below stays wave-uniform
-            for (int c0 = lane; MODE == 2 ? c0 == lane : c0 < C; c0 += 64) {
-                const int c = MODE == 2 ? min(c0, C - 1) : c0;
+            for (int c0 = lane; WIN ? c0 == lane : c0 < C; c0 += 64) {
+                const int c = WIN ? min(c0, C - 1) : c0;
                 float t[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) t[k] = valid[k] ? pl[(size_t)idx[k] * C + c] : 0.f;
                 if (MODE == 0) {
                     a.X[i * XW + 2 * c + p] = ((t[0] * w[0] + t[1] * w[1]) + t[2] * w[2]) + t[3] * w[3];
                 } else {
-                    const float g = (MODE == 2 && lane >= C) ? 0.f : a.dX[i * XW + 2 * c + p];
+                    const float g = (WIN && lane >= C) ? 0.f : a.dX[i * XW + 2 * c + p];
                     if (a.dplanes && MODE == 1) {
                         float* dpl = a.dplanes + p * plane_sz + (size_t)b * H * W * C;
 #pragma unroll
@@ -152,6 +176,27 @@ __global__ void __launch_bounds__(256) field_inputs_kernel(FieldArgs a)
 #pragma unroll
                         for (int k = 0; k < 4; ++k) { wkey[p][k] = nkey[k]; wacc[p][k] = nacc[k]; }
                     }
+                    if (a.fplanes && MODE == 4) {          // the same window walk on integers
+                        int nkey[4]; long long nacc[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            nkey[k] = __builtin_amdgcn_readfirstlane(valid[k] ? b * H * W + idx[k] : -1);
+                            nacc[k] = to_fixed(w[k] * g, pscale);
+                        }
+                        long long* dp0 = a.fplanes + p * plane_sz;
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) {
+                            const int ok = wkey[p][o];
+                            if (ok < 0) continue;
+                            if (ok == nkey[0]) nacc[0] += facc[p][o];
+                            else if (ok == nkey[1]) nacc[1] += facc[p][o];
+                            else if (ok == nkey[2]) nacc[2] += facc[p][o];
+                            else if (ok == nkey[3]) nacc[3] += facc[p][o];
+                            else if (lane < C && facc[p][o] != 0) atomicAdd(reinterpret_cast<unsigned long long*>(dp0 + (size_t)ok * C + lane), (unsigned long long)facc[p][o]);
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { wkey[p][k] = nkey[k]; facc[p][k] = nacc[k]; }
+                    }
                     const float ggx = g * ((t[1] - t[0]) * wy0 + (t[3] - t[2]) * wy1);
                     const float ggy = g * ((t[2] - t[0]) * wx0 + (t[3] - t[1]) * wx1);
                     if (p == 0) dqx += ggx; else dqz += ggx;
@@ -166,7 +211,7 @@ __global__ void __launch_bounds__(256) field_inputs_kernel(FieldArgs a)
         const float arg = r6 >= 3 ? coord * freq + 1.57079632679489661923f : coord * freq;
         if (MODE == 0) {
             if (lane < PE_DIM) a.X[i * XW + 2 * C + lane] = sinf(arg);
-        } else if (a.dvol) {
+        } else if (a.dvol || (MODE == 4 && a.vval)) {
             // d loss / d p' : plane coordinates (through the box warp) + the encoding
             float dx = dqx * (0.5f * (float)(W - 1)) * a.bs[0], dy = dqy * (0.5f * (float)(H - 1)) * a.bs[1], dz = dqz * (0.5f * (float)(W - 1)) * a.bs[2];
             if (lane < PE_DIM) {
@@ -178,7 +223,14 @@ __global__ void __launch_bounds__(256) field_inputs_kernel(FieldArgs a)
             const float dh0 = dx * px + dy * py + dz * pz, dh1 = dx * p1x + dy * p1y + dz * p1z;
             const float mix = dh0 * h0 + dh1 * h1;
             const float dw = ((bone ? dh1 : dh0) - mix) * rs;
-            if (vin && tw * dw != 0.f) atomicAdd(a.dvol + vidx, tw * dw);   // clamped (border) coordinates: half the taps weigh 0
+            if (MODE == 4) {          // buffered: [n][16] values + voxel ids; the scatter (and its scale) come afterwards
+                if (lane < 16) {
+                    const float cv = vin ? tw * dw : 0.f;
+                    a.vval[i * 16 + lane] = cv;
+                    a.vidx32[i * 16 + lane] = vin ? (int)vidx : -1;
+                    vmax_w = fmaxf(vmax_w, fabsf(cv));
+                }
+            } else if (vin && tw * dw != 0.f) atomicAdd(a.dvol + vidx, tw * dw);   // clamped (border) coordinates: half the taps weigh 0
         }
     }
     if (MODE == 2 && a.dplanes) {          // end of the run: whatever is still in the windows
@@ -188,7 +240,45 @@ __global__ void __launch_bounds__(256) field_inputs_kernel(FieldArgs a)
             for (int o = 0; o < 4; ++o)
                 if (wkey[p][o] >= 0 && lane < C) atomicAdd(a.dplanes + p * plane_sz + (size_t)wkey[p][o] * C + lane, wacc[p][o]);
     }
+    if (MODE == 4 && a.fplanes) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+                if (wkey[p][o] >= 0 && lane < C && facc[p][o] != 0)
+                    atomicAdd(reinterpret_cast<unsigned long long*>(a.fplanes + p * plane_sz + (size_t)wkey[p][o] * C + lane), (unsigned long long)facc[p][o]);
     }
+    }
+    if (MODE == 4 && a.vmax) {          // max |volume tap| of this wave (a maximum does not depend on the order either)
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) vmax_w = fmaxf(vmax_w, __shfl_xor(vmax_w, o, 64));
+        if (lane == 0 && vmax_w > 0.f) atomicMax(a.vmax, __float_as_uint(vmax_w));
+    }
+}
+
+// volume taps of MODE 4 -> 64-bit fixed-point accumulators (scale from the maximum the first kernel left in *vmax)
+__global__ void __launch_bounds__(256) vol_fixed_scatter_kernel(long long* __restrict__ fvol, const float* __restrict__ vval, const int* __restrict__ vidx,
+                                                                int64_t n16, const unsigned int* __restrict__ vmax, int fixbits)
+{
+    const int e = fold_max_exp(vmax, 1, threadIdx.x & 63);
+    const float scale = __uint_as_float((unsigned int)(127 + fixbits - e) << 23);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) {
+        const int id = vidx[i];
+        const float v = vval[i];
+        if (id >= 0 && v != 0.f) atomicAdd(reinterpret_cast<unsigned long long*>(fvol + id), (unsigned long long)to_fixed(v, scale));
+    }
+}
+// out = acc * 2^(e - fixbits): e from the words of hav_absmax (nwords = 256) or from one maximum word (nwords = 1)
+__global__ void __launch_bounds__(256) fixed_to_float_kernel(float* __restrict__ out, const long long* __restrict__ acc, int64_t n,
+                                                             const unsigned int* __restrict__ words, int nwords, int fixbits)
+{
+    const int e = fold_max_exp(words, nwords, threadIdx.x & 63);
+    // two exact power-of-two factors (their product may not be a normal float)
+    const int sh = e - fixbits;
+    const int s1 = sh / 2, s2 = sh - s1;
+    const float f1 = __uint_as_float((unsigned int)(127 + s1) << 23), f2 = __uint_as_float((unsigned int)(127 + s2) << 23);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = ((float)acc[i] * f1) * f2;
 }
 
 static int field_check(const HavFieldParams* p, const void* pts, const void* invT, const void* vol, const void* planes)
@@ -243,6 +333,59 @@ extern "C" int hav_field_inputs_bwd(float* dplanes_cl, float* dvol, const float*
     else
         hipLaunchKernelGGL(field_inputs_kernel<1>, dim3(field_blocks(p->n)), dim3(256), 0, (hipStream_t)stream, a);
     HAV_LAUNCH_CHECK();
+    return 0;
+}
+
+static int fixed_bits(int64_t n)
+{
+    int lg = 0;
+    while (((int64_t)1 << lg) < n * 4) ++lg;          // <= 4 n contributions can meet in one accumulator (merged runs count once each)
+    const int fb = 61 - lg;
+    return fb > 40 ? 40 : (fb < 8 ? 8 : fb);
+}
+extern "C" int64_t hav_field_inputs_bwd_fixed_scratch_bytes(const HavFieldParams* p)
+{
+    if (!p || p->n < 0) return 0;
+    const int64_t planes = 2LL * p->B * p->H * p->W * p->C, vol = 2LL * p->D * p->D * p->D;
+    // [planes] + [vol] 64-bit accumulators | [n][16] tap values | [n][16] voxel ids | 1 maximum word (+ pad)
+    return (planes + vol) * 8 + p->n * 16 * 8 + 256;
+}
+// Bit-reproducible form of hav_field_inputs_bwd (ABI 6): same gradients, summed as 64-bit fixed-point integers (see fold_max_exp above), so two
+// runs on the same inputs give the same bits.  dx_amax: the words of hav_absmax(dX).  scratch: hav_field_inputs_bwd_fixed_scratch_bytes()
+// bytes, zeroed by this call.  C <= 64 (the tap-merging walk).
+extern "C" int hav_field_inputs_bwd_fixed(float* dplanes_cl, float* dvol, const float* dX, const void* dx_amax, void* scratch, const HavFieldParams* p,
+                                          const float* pts, const float* inv_T, const float* vol, const float* planes_cl, void* stream)
+{
+    int rc = field_check(p, pts, inv_T, vol, planes_cl);
+    if (rc || !dX || !dx_amax || !scratch || (!dplanes_cl && !dvol)) return rc ? rc : HAV_EINVAL;
+    if (p->C > 64) return HAV_EUNSUP;
+    if (p->n == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n_pl = 2LL * p->B * p->H * p->W * p->C, n_vol = 2LL * p->D * p->D * p->D;
+    long long* fpl = (long long*)scratch;
+    long long* fvol = fpl + n_pl;
+    float* vval = (float*)(fvol + n_vol);
+    int* vidx = (int*)(vval + p->n * 16);
+    unsigned int* vmax = (unsigned int*)(vidx + p->n * 16);
+    hipError_t me = hipMemsetAsync(fpl, 0, (size_t)(n_pl + n_vol) * 8, st);
+    if (me == hipSuccess) me = hipMemsetAsync(vmax, 0, 256, st);
+    if (me != hipSuccess) return (int)me;
+    FieldArgs a = field_args(p, pts, inv_T, vol, planes_cl);
+    a.dX = dX; a.fplanes = dplanes_cl ? fpl : nullptr; a.dx_amax = (const unsigned int*)dx_amax; a.fixbits = fixed_bits(p->n);
+    a.vval = dvol ? vval : nullptr; a.vidx32 = vidx; a.vmax = dvol ? vmax : nullptr;
+    hipLaunchKernelGGL(field_inputs_kernel<4>, dim3(field_blocks((p->n + FI_RUN - 1) / FI_RUN)), dim3(256), 0, st, a);
+    HAV_LAUNCH_CHECK();
+    const unsigned cb = (unsigned)hav_num_cus() * 8;
+    if (dvol) {
+        hipLaunchKernelGGL(vol_fixed_scatter_kernel, dim3(cb), dim3(256), 0, st, fvol, (const float*)vval, (const int*)vidx, p->n * 16, (const unsigned int*)vmax, a.fixbits);
+        HAV_LAUNCH_CHECK();
+        hipLaunchKernelGGL(fixed_to_float_kernel, dim3(cb), dim3(256), 0, st, dvol, (const long long*)fvol, n_vol, (const unsigned int*)vmax, 1, a.fixbits);
+        HAV_LAUNCH_CHECK();
+    }
+    if (dplanes_cl) {
+        hipLaunchKernelGGL(fixed_to_float_kernel, dim3(cb), dim3(256), 0, st, dplanes_cl, (const long long*)fpl, n_pl, (const unsigned int*)dx_amax, 256, a.fixbits);
+        HAV_LAUNCH_CHECK();
+    }
     return 0;
 }
 

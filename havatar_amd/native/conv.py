@@ -235,6 +235,42 @@ def wgrad3x3(g, x, xs=None, out_mul=1.0, g_amax=None, x_amax=None):
     return gw
 
 
+def wgrad_s2_eligible(S, L):
+    """S [B,M,H,W], L [B,N,2H+1,2W+1]: shapes hav_conv3x3s2_wgrad takes (HAVATAR_S2_WGRAD=0 keeps ATen's convolution_backward)."""
+    if not (S.is_cuda and S.dtype == torch.float32 and L.dtype == torch.float32 and S.dim() == 4 and L.dim() == 4):
+        return False
+    B, M, H, W = S.shape
+    N = L.shape[1]
+    if L.shape[0] != B or tuple(L.shape[2:]) != (2 * H + 1, 2 * W + 1) or os.environ.get("HAVATAR_S2_WGRAD", "1") == "0":
+        return False
+    if W < 16:          # the small-map kernel (4^2 / 8^2 layers): plain fp32, its operand rows must fit in LDS
+        return M % 16 == 0 and N % 16 == 0 and (16 * B * H * W + 16 * ((B * (2 * H + 1) * (2 * W + 1)) | 1)) * 4 <= 64 * 1024
+    return M % 64 == 0 and N % 32 == 0 and W % 16 == 0
+
+
+def wgrad3x3s2(S, L, ss=None, out_mul=1.0, transpose=False, s_amax=None, l_amax=None):
+    """out[m,n,ky,kx] = out_mul * sum_{b,y,x} ss[b,m] * S[b,m,y,x] * L[b,n,2y+ky,2x+kx] (hav_conv3x3s2_wgrad, include/havatar.h): the weight
+    gradient of both stride-2 layers of the StyleGAN blocks -- the down-sampling ConvLayer (S = dL/dy, L = the blurred input -> [Cout,Cin,3,3])
+    and the up-sampling StyledConv's transposed convolution (S = x, ss = its modulation, L = dL/d(conv_transpose2d output), transpose=True ->
+    the parameter's [Cout,Cin,3,3]).  Both operands under the power-of-two range control."""
+    S, L = S.contiguous(), L.contiguous()
+    B, M, H, W = S.shape
+    N = L.shape[1]
+    lib = _lib.lib()
+    out = torch.empty((N, M, 3, 3) if transpose else (M, N, 3, 3), dtype=torch.float32, device=S.device)
+    nscr = int(lib.hav_conv3x3s2_wgrad_scratch_bytes(B, M, N, H, W))
+    scratch = torch.empty(nscr, dtype=torch.uint8, device=S.device) if nscr else None
+    ss = _c(ss)
+    with torch.cuda.device(S.device):
+        st = _stream(S.device)
+        if W >= 16:          # (the small-map kernel multiplies in fp32: no range control)
+            s_amax = _absmax(S, st) if s_amax is None else s_amax
+            l_amax = _absmax(L, st) if l_amax is None else l_amax
+        _lib.check(lib.hav_conv3x3s2_wgrad(_p(out), _p(S), _p(L), _p(ss), float(out_mul), int(bool(transpose)), _p(scratch), _p(s_amax), _p(l_amax),
+                                           B, M, N, H, W, st), "hav_conv3x3s2_wgrad")
+    return out
+
+
 class _Conv3x3Split(torch.autograd.Function):
     """conv2d(x, w, stride 1, padding 1) for training: the forward runs on hav_conv3x3_split (split-fp16 MFMA, fp32-class results,
     ~2x MIOpen's fp32 Winograd on the encoder shapes), and so does the data gradient, which is the same kind of convolution with
@@ -465,8 +501,11 @@ class _S2ConvBlock(torch.autograd.Function):
                     p = fpad if len(fpad) == 4 else (fpad[0], fpad[1], fpad[0], fpad[1])
                     gx = _ufd(gx, fir.flip(0, 1), pad=(kw - 1 - p[0], kw - 1 - p[1], kh - 1 - p[2], kh - 1 - p[3]))
         if want_w:
-            _, gW, _ = torch.ops.aten.convolution_backward(gc, xb, W, None, [2, 2], [padding, padding], [1, 1], False, [0, 0], 1, [False, True, False])
-            gW = gW * scale
+            if padding == 0 and wgrad_s2_eligible(gc, xb):
+                gW = wgrad3x3s2(gc, xb, out_mul=scale)          # split-fp16 MFMA kernel (MIOpen: fp32 igemm_wrw + NHWC transposes)
+            else:
+                _, gW, _ = torch.ops.aten.convolution_backward(gc, xb, W, None, [2, 2], [padding, padding], [1, 1], False, [0, 0], 1, [False, True, False])
+                gW = gW * scale
         if gb is not None and bias.shape != gb.shape:
             gb = gb.view(bias.shape)
         _trace("S2ConvBlock.bwd g,gc,gx,gW,gb", g, gc, gx, gW, gb)
@@ -627,9 +666,14 @@ class _UpConvBlock(torch.autograd.Function):
                     with torch.cuda.device(dev):
                         _lib.check(L.hav_mod_input_bwd(_p(gx), _p(gs), _p(x), _p(s), B, Cin, H * Wd, _stream(dev)), "hav_mod_input_bwd")
             if want_w:
-                xs = x * s.view(B, Cin, 1, 1) if s is not None else x
-                _, gwt, _ = torch.ops.aten.convolution_backward(gv, xs, wt, None, [2, 2], [0, 0], [1, 1], True, [0, 0], 1, [False, True, False])
-                gW = gwt.transpose(0, 1) * scale
+                if wgrad_s2_eligible(x, gv):
+                    # d/dW of conv_transpose2d(s * x, W^T, stride 2) = the same contraction with x in the small-map role: one kernel, the
+                    # modulation folded in, the parameter's [Cout,Cin,3,3] layout written directly
+                    gW = wgrad3x3s2(x, gv, ss=s, out_mul=scale, transpose=True)
+                else:
+                    xs = x * s.view(B, Cin, 1, 1) if s is not None else x
+                    _, gwt, _ = torch.ops.aten.convolution_backward(gv, xs, wt, None, [2, 2], [0, 0], [1, 1], True, [0, 0], 1, [False, True, False])
+                    gW = gwt.transpose(0, 1) * scale
         if gnw is not None and nw.shape != gnw.shape:
             gnw = gnw.view(nw.shape)
         if gb is not None and bias.shape != gb.shape:

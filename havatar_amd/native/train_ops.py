@@ -2,6 +2,7 @@
 radiance MLP in predict_and_render_radiance -- skinning field + box warp + tri-plane gather + positional encoding on one side,
 volume_render_radiance_field on the other.  HIP float32 tensors only; there is no fallback in here."""
 import ctypes as C
+import os
 
 import torch
 from torch.autograd import Function
@@ -37,6 +38,11 @@ def _field_params(pts, planes_cl, vol, boxes):
     return p
 
 
+def deterministic():
+    """HAVATAR_DETERMINISTIC=1: the training-side scatters sum in 64-bit fixed point (bit-reproducible gradients; ~1 ms per step)."""
+    return os.environ.get("HAVATAR_DETERMINISTIC", "0") == "1"
+
+
 class FieldInputs(Function):
     """X [B*N, 2C+48] = cat(triplane(boxwarp(p')), PE(p')),  p' = skinning_field(pts, inv_T, vol).  Gradients: planes_cl, vol."""
 
@@ -58,13 +64,24 @@ class FieldInputs(Function):
     def backward(ctx, dX):
         pts, inv_T, vol, planes_cl = ctx.saved_tensors
         p = _field_params(pts, planes_cl, vol, ctx.boxes)
-        dvol = torch.zeros_like(vol) if ctx.needs_input_grad[2] else None
-        dpl = torch.zeros_like(planes_cl) if ctx.needs_input_grad[3] else None
+        det = deterministic() and p.C <= 64
+        mk = torch.empty_like if det else torch.zeros_like          # (the fixed-point route writes every element itself)
+        dvol = mk(vol) if ctx.needs_input_grad[2] else None
+        dpl = mk(planes_cl) if ctx.needs_input_grad[3] else None
         if dvol is not None or dpl is not None:
             dX = dX.contiguous()
+            L = _lib.lib()
             with torch.cuda.device(pts.device):
-                rc = _lib.lib().hav_field_inputs_bwd(_p(dpl), _p(dvol), _p(dX), C.byref(p), _p(pts), _p(inv_T), _p(vol), _p(planes_cl),
-                                                     _stream())
+                if det:
+                    # HAVATAR_DETERMINISTIC=1: 64-bit fixed-point sums, integer atomics -- the same bits on every run (the float atomics of
+                    # the default route land in a different order every time)
+                    from .conv import absmax
+                    words = absmax(dX)
+                    scratch = torch.empty(int(L.hav_field_inputs_bwd_fixed_scratch_bytes(C.byref(p))), dtype=torch.uint8, device=pts.device)
+                    rc = L.hav_field_inputs_bwd_fixed(_p(dpl), _p(dvol), _p(dX), _p(words), _p(scratch), C.byref(p), _p(pts), _p(inv_T), _p(vol),
+                                                      _p(planes_cl), _stream())
+                else:
+                    rc = L.hav_field_inputs_bwd(_p(dpl), _p(dvol), _p(dX), C.byref(p), _p(pts), _p(inv_T), _p(vol), _p(planes_cl), _stream())
             _lib.check(rc, "hav_field_inputs_bwd")
             from .conv import _trace
             _trace("FieldInputs.bwd dX,dvol,dplanes,vol", dX, dvol, dpl, vol)          # (development aid; a no-op unless HAVATAR_NAN_TRACE)

@@ -162,6 +162,13 @@ int hav_field_inputs_fwd(float* X, const HavFieldParams* p, const float* pts, co
                          const float* planes_cl, void* stream);
 int hav_field_inputs_bwd(float* dplanes_cl, float* dvol, const float* dX, const HavFieldParams* p, const float* pts,
                          const float* inv_T, const float* vol, const float* planes_cl, void* stream);
+/* Bit-reproducible form of hav_field_inputs_bwd (ABI 6): the same gradients, summed as 64-bit fixed-point integers with integer atomics
+ * (integer addition is associative: the result does not depend on the order the atomics land in; float atomics do).  dx_amax: the
+ * HAV_ABSMAX_WORDS words of hav_absmax(dX) (the planes' scale; the volume taps are buffered and scaled by their own maximum).  scratch:
+ * hav_field_inputs_bwd_fixed_scratch_bytes(p) bytes (accumulators + buffered taps; zeroed by the call).  plane_ch <= 64. */
+int64_t hav_field_inputs_bwd_fixed_scratch_bytes(const HavFieldParams* p);
+int hav_field_inputs_bwd_fixed(float* dplanes_cl, float* dvol, const float* dX, const void* dx_amax, void* scratch, const HavFieldParams* p,
+                               const float* pts, const float* inv_T, const float* vol, const float* planes_cl, void* stream);
 int hav_composite_fwd(float* rgb, float* acc, float* weights, float* depth, const float* rf, const float* z, const float* rd,
                       const float* noise, const float* bg, int64_t n_rays, int S, int CH, int n_sigmoid, void* stream);
 int hav_composite_bwd(float* d_rf, const float* d_rgb, const float* d_acc, const float* d_weights, const float* d_depth,
@@ -228,6 +235,18 @@ int hav_conv3x3_wgrad(float* gw /*[Cout,Cin,3,3]*/, const float* g /*[B,Cout,H,W
  * ModulatedConv2d / EqualConv2d weight PARAMETER (out_mul = the layer's 1/sqrt(9 Cin) scale) given g = dL/d(conv output). */
 int hav_conv3x3_wgrad_mod(float* gw, const float* g, const float* x, const float* xs, float out_mul, void* scratch, const void* g_amax,
                           const void* x_amax, int B, int Cin, int Cout, int H, int W, void* stream);
+/* Weight gradient of the STRIDE-2 3x3 layers (training; ABI 6):  out[m,n,ky,kx] = out_mul * sum_{b,y,x} ss[b,m] * S[b,m,y,x] * L[b,n,2y+ky,2x+kx]
+ * with S [B,M,H,W], L [B,N,2H+1,2W+1] (M % 64 == 0, N % 32 == 0, W % 16 == 0), on the split-fp16 matrix path.  It is the weight gradient of
+ *   - the down-sampling ConvLayer (Blur -> EqualConv2d stride 2 padding 0 -> FusedLeakyReLU, reference model/styleUnet.py:326-368 under
+ *     autograd):  S = dL/d(conv output) [B,Cout,H,W], L = the blurred input [B,Cin,2H+1,2W+1]  ->  gw [Cout,Cin,3,3];
+ *   - the up-sampling StyledConv's transposed convolution (F.conv_transpose2d stride 2, model/styleUnet.py:214-231):  S = the layer's input
+ *     x [B,Cin,H,W] with ss = its modulation s [B,Cin], L = dL/d(conv_transpose2d output) [B,Cout,2H+1,2W+1], transpose_out = 1  ->
+ *     the parameter's layout [Cout,Cin,3,3].
+ * (the reference runs both through ATen's convolution_backward: MIOpen igemm_wrw + NHWC transposes).  ss NULL: plain S.  scratch:
+ * hav_conv3x3s2_wgrad_scratch_bytes() bytes; s_amax / l_amax: hav_absmax words of S / L or NULL (power-of-two range control). */
+int64_t hav_conv3x3s2_wgrad_scratch_bytes(int B, int M, int N, int H, int W);
+int hav_conv3x3s2_wgrad(float* gw, const float* S, const float* L, const float* ss, float out_mul, int transpose_out, void* scratch,
+                        const void* s_amax, const void* l_amax, int B, int M, int N, int H, int W, void* stream);
 /* Backward glue of one fused convolution block y = act(d * conv(s * x, W) + noise_weight * noise + bias) * gain under autograd (what
  * ATen runs as ~20 small launches per layer: reference model/styleUnet.py:165-310 + model/op/fused_act.py:20-52 under autograd):
  *   hav_conv_block_bwd   g = dL/dy, y = the block's output ->

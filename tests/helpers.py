@@ -149,3 +149,17 @@ def mlp_layer_errors(n_random=4096, seed=0):
                 e = np.abs(y - y64) / np.maximum(mag, 1e-30)
                 out[(layer, kind, name)] = (float(e.max()), float(np.sqrt((e ** 2).mean())))
     return out
+
+
+def report(line):
+    """Numbers a test measured on the way to its verdict (how many rays were in a loose class, their worst error): printed, and appended to
+    gpurun_out/test_reports.txt so that a run on the GPU box brings them back (gpurun_out/ is scratch; the round's copy is profiles/r05_test_reports.txt)."""
+    import os
+    print(line)
+    try:
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "test_reports.txt"), "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass

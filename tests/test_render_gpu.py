@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import GOLDEN, OUT_KEYS, hip_render, linf, load_render_fixture, pdf_floor_sensitive as _pdf_floor_sensitive
+from helpers import GOLDEN, OUT_KEYS, hip_render, linf, load_render_fixture, pdf_floor_sensitive as _pdf_floor_sensitive, report
 from havatar_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -452,7 +452,7 @@ def test_production_variants_512_frame_24_launches(perturb, mlp):
     assert not report, (want, "launches that differ from the first (launch, rays, ray blocks):", report)
 
 
-def _sampled_rays_vs_oracle(out, rays, sc, H, W, jitter, kw):
+def _sampled_rays_vs_oracle(out, rays, sc, H, W, jitter, kw, tag=""):
     """4096 pixels of a rendered H x W frame (`out` = RayMarcher.render's tuple, fine maps) against the oracle on the same inputs and the
     same random numbers (kw: t_rand [1,H*W,S_c], u_rand [H*W,S_f] as CPU tensors, or {}): 32 random columns in each of 128 image rows.
     EVERY sampled ray must meet its bar = the path tolerance + 3 x that ray's own conditioning, measured three ways on the oracle: fp32 vs
@@ -491,6 +491,10 @@ def _sampled_rays_vs_oracle(out, rays, sc, H, W, jitter, kw):
         assert not viol.any(), (k, int(viol.sum()), "rays beyond their bar; worst:", err[viol][:4], "conditioning there:", cond[viol][:4])
         assert (err[floor_rays] <= 1e-2).all() and floor_rays.mean() <= 0.02, (k, floor_rays.mean())
         assert np.median(err) <= 1e-4, (k, np.median(err))
+        # the loose class is reported, not just bounded: a regression inside it shows in these numbers
+        report("floor-class rays [512^2 oracle check, %s, %s, jitter %s]: %d of %d rays (%.2f %%), worst error %.2e, median %.2e; the other rays: worst %.2e" % (
+            tag, k, jitter, int(floor_rays.sum()), n, 100.0 * floor_rays.mean(), float(err[floor_rays].max()) if floor_rays.any() else 0.0,
+            float(np.median(err[floor_rays])) if floor_rays.any() else 0.0, float(err[~floor_rays].max())))
 
 
 @pytest.mark.parametrize("mlp", SPLIT_MODES)
@@ -524,7 +528,7 @@ def test_shipping_device_rng_kernels_vs_oracle_on_their_own_random_numbers(mlp):
     xi = torch.from_numpy(jitter_uniform(gr, np.arange(64, dtype=np.uint32)[None, :], 0, seed=rm.seed, call=3).astype(np.float32))     # STREAM_XI
     zeta = torch.from_numpy(jitter_uniform(gr, np.arange(16, dtype=np.uint32)[None, :], 1, seed=rm.seed, call=3).astype(np.float32))   # STREAM_ZETA
     kw = dict(t_rand=xi[None], u_rand=zeta)
-    _sampled_rays_vs_oracle(dev_out, rays, sc, H, W, True, kw)                # (a) the shipping binary against the oracle, directly
+    _sampled_rays_vs_oracle(dev_out, rays, sc, H, W, True, kw, tag="device RNG " + mlp)                # (a) the shipping binary against the oracle, directly
     inj_out = rm.render(*args, perturb=True, coarse_outputs=False, **{k: v.to(dev) for k, v in kw.items()})
     torch.cuda.synchronize()
     assert rm.last_variant == "hav_march_blk_kernel<2, %d, 2>" % prec
@@ -569,7 +573,7 @@ def test_full_frame_512_fine_maps_only_cache_kernels_vs_oracle(jitter, mlp):
     torch.cuda.synchronize()
     assert rm.last_variant == "hav_march_blk_kernel<%d, %d, 2>" % (2 if jitter else 0, PREC[mlp])
     assert out[0] is None and all(torch.isfinite(o).all() for o in out[3:7])
-    _sampled_rays_vs_oracle(out, rays, sc, H, W, jitter, kw)
+    _sampled_rays_vs_oracle(out, rays, sc, H, W, jitter, kw, tag=mlp)
 
 
 @pytest.mark.parametrize("recipe", ["primary", "stress"])
@@ -625,6 +629,10 @@ def test_full_frame_512_production_kernels_vs_the_reference(mlp, jitter, recipe)
             bar = TOL[k] + 3.0 * g[key + "cond_" + k].astype(np.float64) + slack * (6.0 if k == "depth_fine" else 1.0)     # (depths are ~6 at the far end)
             bar[floor_rays] = 10.0 * TOL[k]
             assert (err <= bar).all(), (k, coarse_outputs, int((err > bar).sum()), "rays beyond their bar; worst:", err[err > bar][:4], bar[err > bar][:4])
+            if not coarse_outputs:
+                report("floor-class rays [frame512 vs the reference, %s, %s, %s, %s]: %d of %d rays (%.2f %%), worst error %.2e (bar %.0e); the other rays: worst %.2e" % (
+                    recipe, "jittered" if jitter else "deterministic", mlp, k, int(floor_rays.sum()), n, 100.0 * floor_rays.mean(),
+                    float(err[floor_rays].max()) if floor_rays.any() else 0.0, 10.0 * TOL[k], float(err[~floor_rays].max())))
             assert np.median(err) <= 0.05 * TOL[k], (k, np.median(err))
         assert linf(got["weights_max"], g[key + "weights_max"]) <= TOL["weights_max"] + 3.0 * float(g[key + "cond_acc_fine"].max()) + float(slack.max())
         if coarse_outputs:          # the coarse maps are well conditioned: the fixtures' tight bars
