@@ -119,6 +119,22 @@ def set_learning_rate(optimizer, lr_new):
             g["lr"] = lr_new
 
 
+def enable_determinism(on=True):
+    """HAVATAR_DETERMINISTIC=1: a bit-reproducible optimisation step (the same weights, batch and seeds give the same bits in every gradient,
+    run after run; tools/step_determinism.py: 0 of 154 tensors differ, against 141 without).  Three switches: this library's field-input
+    scatter sums in 64-bit fixed point (native/train_ops.py::deterministic: the float atomics of the default route land in a different
+    order every time), MIOpen is restricted to deterministic solvers (torch.backends.cudnn.deterministic: the default solver of the 16^2
+    convolutions is what makes even the FORWARD differ between runs), ATen's index / scatter adds take their deterministic forms."""
+    if os.environ.get("HAVATAR_DET_MIOPEN", "1") != "0":          # (A/B: the parts one by one)
+        torch.backends.cudnn.deterministic = bool(on)
+    if os.environ.get("HAVATAR_DET_ATEN", "1") != "0":
+        torch.use_deterministic_algorithms(bool(on), warn_only=True)
+
+
+def deterministic_requested():
+    return os.environ.get("HAVATAR_DETERMINISTIC", "0") == "1"
+
+
 class StepRunner:
     """forward + backward + optimiser update of one batch; eager for the first `eager_steps` calls (solver selection, lazy
     optimiser state) and for odd batch shapes, one hipGraph replay otherwise."""
@@ -126,6 +142,8 @@ class StepRunner:
     def __init__(self, trainer, cfg, optimizer, rgb_loss_func, percep_loss_fn=None, graph=False, eager_steps=2):
         self.trainer, self.cfg, self.optimizer, self.rgb_loss_func, self.percep = trainer, cfg, optimizer, rgb_loss_func, percep_loss_fn
         self.graph, self.eager_left, self.graphed, self.side = graph, eager_steps, None, None
+        if deterministic_requested():
+            enable_determinism()
         if graph:
             dev = next(trainer.parameters()).device
             for g in optimizer.param_groups:          # capturable Adam reads a DEVICE tensor learning rate inside the graph
