@@ -162,15 +162,19 @@ extern "C" int hav_conv_profile_buffer(void* p) { return (int)hipMemcpyToSymbol(
 #define CV_T(v) do { } while (0)
 #endif
 
-template <bool HAS_S>      // modulated (s given) or plain: compile-time, so that neither variant carries the other's loads / multiplies
+// NARROW: maps 16 columns wide (the 16^2 layers of the generators; any W % 16 == 0 that is not a multiple of 32, H % 8 == 0): the tile is
+// 8 rows x 16 columns instead of 4 x 32 -- lane j of a 32-pixel MFMA column block is pixel (row j >> 4, column j & 15) of a row pair.
+template <bool HAS_S, bool NARROW = false>      // modulated (s given) or plain: compile-time, so that neither variant carries the other's loads / multiplies
 __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(ConvArgs a)
 {
+    constexpr int ROWS = NARROW ? 8 : CV_ROWS, COLS = NARROW ? 16 : CV_COLS, PC = COLS + 2, PIX = (ROWS + 2) * PC, TASKS = PIX * 8;
+    static_assert(PIX <= CV_PIX, "the narrow patch fits the wide one's LDS");
     __shared__ __attribute__((aligned(16))) uint32_t lds[2][CV_PIX * CV_REC];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
     const int wm = wave & 1, wn = wave >> 1;
-    const int bw = a.W / CV_COLS;
+    const int bw = a.W / COLS;
     const int px = blockIdx.x % bw, py = blockIdx.x / bw;
-    const int x0 = px * CV_COLS, y0 = py * CV_ROWS;
+    const int x0 = px * COLS, y0 = py * ROWS;
     const int mt = blockIdx.y * 2 + wm;          // this wave's 32-row tile of output channels
     const int b = blockIdx.z / a.ksplit, ks = blockIdx.z - b * a.ksplit;
     const int H = a.H, W = a.W, Cin = a.Cin, NCT = Cin / 16, MT = a.Cout / 32;
@@ -193,13 +197,13 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(ConvArgs a)
 #pragma unroll
     for (int q = 0; q < CV_TPT; ++q) {
         const int task = tid + 256 * q;
-        const int cp = task / CV_PIX, p = task - cp * CV_PIX;
-        const int pr = p / CV_PC, pc = p - pr * CV_PC;
+        const int cp = task / PIX, p = task - cp * PIX;
+        const int pr = p / PC, pc = p - pr * PC;
         const int gy = y0 + pr - 1, gx = x0 + pc - 1;
-        t_ok[q] = task < CV_TASKS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        t_ok[q] = task < TASKS && gy >= 0 && gy < H && gx >= 0 && gx < W;
         t_off[q] = (2 * cp) * H * W + gy * W + gx;
-        t_lds[q] = task < CV_TASKS ? p * CV_REC + cp : -1;
-        t_cp[q] = task < CV_TASKS ? 2 * cp : 0;          // idle slots of the last round must not index past s[Cin]
+        t_lds[q] = task < TASKS ? p * CV_REC + cp : -1;
+        t_cp[q] = task < TASKS ? 2 * cp : 0;          // idle slots of the last round must not index past s[Cin]
     }
     // fetch() only ISSUES the global loads of a chunk (raw values; the modulation factors ride along); every use of them -- scaling,
     // splitting, the LDS writes -- happens in stash(), after the chunk's MFMAs.  A multiply inside fetch() would put the load latency
@@ -250,7 +254,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(ConvArgs a)
             const f16x8_t ah = __builtin_bit_cast(f16x8_t, A[t][0]), al = __builtin_bit_cast(f16x8_t, A[t][1]);
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
-                const int p = (2 * wn + rr + ky) * CV_PC + j + kx;
+                const int p = NARROW ? (4 * wn + 2 * rr + (j >> 4) + ky) * PC + (j & 15) + kx : (2 * wn + rr + ky) * PC + j + kx;
                 const uint4 bh = *reinterpret_cast<const uint4*>(L + p * CV_REC + 4 * h);
                 const uint4 bl = *reinterpret_cast<const uint4*>(L + p * CV_REC + 8 + 4 * h);
                 const f16x8_t xh = __builtin_bit_cast(f16x8_t, bh), xl = __builtin_bit_cast(f16x8_t, bl);
@@ -284,7 +288,8 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(ConvArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
-                pp[(((int64_t)b * a.Cout + co) * H + y0 + 2 * wn + rr) * W + x0 + j] = acc[rr][r] * out_sc;
+                const int gy = NARROW ? y0 + 4 * wn + 2 * rr + (j >> 4) : y0 + 2 * wn + rr, gx = NARROW ? x0 + (j & 15) : x0 + j;
+                pp[(((int64_t)b * a.Cout + co) * H + gy) * W + gx] = acc[rr][r] * out_sc;
             }
         return;
     }
@@ -293,7 +298,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_split_kernel(ConvArgs a)
     const float nw = (a.noise && a.noise_weight) ? *a.noise_weight : 0.f;
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
-        const int gy = y0 + 2 * wn + rr, gx = x0 + j;
+        const int gy = NARROW ? y0 + 4 * wn + 2 * rr + (j >> 4) : y0 + 2 * wn + rr, gx = NARROW ? x0 + (j & 15) : x0 + j;
         const float nz = a.noise ? a.noise[(a.noise_batched ? (int64_t)b * H * W : 0) + (int64_t)gy * W + gx] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -567,10 +572,12 @@ static bool conv_interleaved(int Cout)
     static const int forced = [] { const char* e = getenv("HAVATAR_CONV_KERNEL"); return e ? atoi(e) : -1; }();
     return forced != 0 && (Cout % 128) == 0;
 }
+static bool conv_narrow(int H, int W) { return (W % CV_COLS) != 0 && (W % 16) == 0 && (H % 8) == 0; }          // 8 x 16 tiles (plain kernel only)
+static bool conv_shape_ok(int H, int W) { return ((H % CV_ROWS) == 0 && (W % CV_COLS) == 0) || conv_narrow(H, W); }
 static int conv_ksplit(int B, int Cin, int Cout, int H, int W)
 {
-    const bool il = conv_interleaved(Cout);
-    const int64_t tiles = (int64_t)B * (Cout / (il ? 128 : 64)) * (H / CV_ROWS) * (W / CV_COLS);
+    const bool il = conv_interleaved(Cout) && !conv_narrow(H, W);
+    const int64_t tiles = (int64_t)B * (Cout / (il ? 128 : 64)) * ((int64_t)H * W / (CV_ROWS * CV_COLS));
     int ks = 1;
     if (il) { while (tiles * ks < hav_num_cus() && ks < 8 && (Cin / 16) / (ks * 2) >= 2) ks *= 2; }
     else { while (tiles * ks < hav_num_cus() && ks < 4 && (Cin / 16) / (ks * 2) >= 4) ks *= 2; }
@@ -578,7 +585,7 @@ static int conv_ksplit(int B, int Cin, int Cout, int H, int W)
 }
 extern "C" int64_t hav_conv3x3_scratch_bytes(int B, int Cin, int Cout, int H, int W)
 {
-    if (B < 1 || Cin < 16 || Cout < 64 || H < 1 || W < 1 || (Cin % 16) || (Cout % 64) || (H % CV_ROWS) || (W % CV_COLS)) return 0;
+    if (B < 1 || Cin < 16 || Cout < 64 || H < 1 || W < 1 || (Cin % 16) || (Cout % 64) || !conv_shape_ok(H, W)) return 0;
     const int ks = conv_ksplit(B, Cin, Cout, H, W);
     return ks > 1 ? (int64_t)ks * B * Cout * H * W * 4 : 0;
 }
@@ -588,7 +595,7 @@ extern "C" int hav_conv3x3_split(float* y, const float* x, const void* packed, c
                                  int Cin, int Cout, int H, int W, void* scratch, const void* in_amax, void* stream)
 {
     if (!y || !x || !packed || B < 1 || Cin < 16 || Cout < 64 || H < 1 || W < 1) return HAV_EINVAL;
-    if ((Cin % 16) || (Cout % 64) || (H % CV_ROWS) || (W % CV_COLS)) return HAV_EUNSUP;
+    if ((Cin % 16) || (Cout % 64) || !conv_shape_ok(H, W)) return HAV_EUNSUP;
     ConvArgs a;
     a.in_amax = (const unsigned int*)in_amax;
     a.ksplit = scratch ? conv_ksplit(B, Cin, Cout, H, W) : 1;
@@ -596,14 +603,17 @@ extern "C" int hav_conv3x3_split(float* y, const float* x, const void* packed, c
     a.y = y; a.x = x; a.blob = (const uint4*)packed; a.s = s; a.d = d; a.noise = noise; a.noise_weight = noise_weight; a.bias = bias;
     a.slope = slope; a.gain = gain; a.act = act; a.noise_batched = noise_batched;
     a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
-    const bool il = conv_interleaved(Cout);
-    const dim3 grid((unsigned)((W / CV_COLS) * (H / CV_ROWS)), (unsigned)(Cout / (il ? 128 : 64)), (unsigned)(B * a.ksplit));
-    if (il) {
+    const bool narrow = conv_narrow(H, W), il = conv_interleaved(Cout) && !narrow;
+    const dim3 grid((unsigned)((int64_t)H * W / (CV_ROWS * CV_COLS)), (unsigned)(Cout / (il ? 128 : 64)), (unsigned)(B * a.ksplit));
+    if (narrow) {
+        if (s) hipLaunchKernelGGL((conv3x3_split_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((conv3x3_split_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    } else if (il) {
         if (s) hipLaunchKernelGGL(conv3x3_il_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
         else hipLaunchKernelGGL(conv3x3_il_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
     } else {
-        if (s) hipLaunchKernelGGL(conv3x3_split_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL(conv3x3_split_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+        if (s) hipLaunchKernelGGL((conv3x3_split_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((conv3x3_split_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, a);
     }
     HAV_LAUNCH_CHECK();
     if (a.partial) {

@@ -104,8 +104,9 @@ def eligible(x, weight, stride=1, padding=1):
         return False
     Cout, Cin, kh, kw = weight.shape
     B, Ci, H, W = x.shape
+    # tiles: 4 rows x 32 columns, or 8 x 16 for maps 16 (48, 80, ...) columns wide (the 16^2 layers)
     return (kh == 3 and kw == 3 and stride == 1 and padding == 1 and Ci == Cin and Cin % 16 == 0 and Cout % 64 == 0
-            and H % 4 == 0 and W % 32 == 0)
+            and ((H % 4 == 0 and W % 32 == 0) or (H % 8 == 0 and W % 16 == 0)))
 
 
 def pack(weight, wmul=1.0):

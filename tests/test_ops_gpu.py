@@ -500,7 +500,8 @@ def test_upsample3d_2x_matches_nn_upsample_and_its_autograd(shape):
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,Cin,Cout,H,W,full", [(1, 16, 64, 4, 32, True), (2, 48, 64, 8, 64, True), (1, 64, 128, 12, 32, False),
                                                  (1, 512, 512, 32, 32, True), (1, 256, 256, 128, 128, False),
-                                                 (1, 16, 128, 4, 32, True), (2, 48, 256, 64, 64, True), (1, 1024, 512, 64, 64, True)])
+                                                 (1, 16, 128, 4, 32, True), (2, 48, 256, 64, 64, True), (1, 1024, 512, 64, 64, True),
+                                                 (1, 512, 512, 16, 16, True), (2, 64, 64, 8, 16, True), (1, 32, 128, 24, 48, False)])          # 8 x 16 tiles: the 16^2 layers
 def test_conv3x3_split_matches_fp64_convolution(B, Cin, Cout, H, W, full):
     """hav_conv3x3_split (split-fp16 implicit GEMM + fused modulation / demodulation / noise / bias / leaky-ReLU) against the fp64
     statement of the same StyledConv / ConvLayer arithmetic (model/styleUnet.py:165-297,326-368,565-599); the fp32 F.conv2d route's
@@ -1067,7 +1068,7 @@ def test_demod_autograd_node_matches_the_aten_statement(B, Cin, Cout, k):
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,modulated,act", [(2, 64, 128, 32, True, True), (1, 128, 64, 64, True, True), (2, 64, 64, 32, False, True),
-                                                         (2, 128, 128, 32, False, False), (2, 64, 64, 32, "nodemod", True)])
+                                                         (2, 128, 128, 32, False, False), (2, 64, 64, 32, "nodemod", True), (2, 512, 512, 16, True, True)])
 def test_fused_conv_block_node_matches_fp64_autograd(B, Cin, Cout, H, modulated, act):
     """native/conv.py::_FusedConvBlock (a whole StyledConv / ConvLayer as one autograd node: hav_conv3x3_split forward, hav_conv_block_bwd +
     hav_conv3x3_pack_t + hav_mod_input_bwd + hav_conv3x3_wgrad_mod backward) against the unfused statement under fp64 autograd
