@@ -954,6 +954,379 @@ static int ufd_launch_up2_direct(float* out, const float* in, const float* k, co
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Row-streaming f32 kernels (minor == 1): blur, decimation by 2 and x2 up-sampling with a FIR of up to 4x4 taps as ROLLING WINDOWS.
+// A lane owns a strip of 4 output columns of one plane and the input columns its windows start in; a wave takes 64 neighbouring entries
+// of the flat (plane, strip) list -- its stores are whole KiB-long runs of a row -- and walks a segment of rows downwards: per input row
+// ONE 16-byte buffer load per owned vector (the columns shared with the right neighbour come out of that lane's registers through a DPP
+// wave shift; lane 63 and the last strip of a row fetch them with one more load in which every other lane is out of range), the row joins
+// a window of <= 4 rows in registers, every completed output row leaves as one 16-byte buffer store per lane.
+// * No branch around a memory instruction: rows outside the image are clamped and masked, columns are masked, loads and stores that must
+//   not happen get an offset beyond the buffer descriptor's range (the hardware drops them), the end of the tensor is covered by the same
+//   range check.  The compiler therefore counts the memory instructions in flight exactly (s_waitcnt vmcnt(2 D - 1)) and a wave computes
+//   row r while rows r + 1 .. r + D are on their way.
+// * Whole-line stores: with 63 producing lanes per wave (an earlier version) every store began and ended inside a 128-byte line that
+//   another wave completed later: 31 us instead of 28 for the 513^2 -> 512^2 blur.
+// * Segment borders are shifted per plane: all waves start together and walk at the same pace, with borders at the same rows in every
+//   plane they touch addresses that are equal modulo (rows per segment x pitch) at every step -- the same few channels (34 us).
+// * The launch is a flat list of single-wave workgroups, (strip group, segment) with the segment running fastest, dealt to the XCDs in
+//   contiguous eighths; rows per segment (33 / 17 / 9 / 5) = the longest that still gives the chip >= 9 waves per compute unit.
+// Tap order per output as in every other kernel here (i ascending, then j, one FMA chain from 0): bit-identical results.
+// Measured (tools/ufd_roll_ab.py, every launch on its own buffers): [64,513,513] -> 512^2 blur 34.2 -> 28.4 us (4.7 TB/s), 3x3 blur
+// 32.4 -> 28.0, x2 up-sampling [12,512,512] 18.8 -> 17.4; the decimating class stays on the LDS-tiled kernel (19.3 vs 20.3 us).
+typedef unsigned int ufd_u4 __attribute__((ext_vector_type(4)));
+#define UFD_OOB ((int)0x80000000)          // beyond every descriptor built here (tensors of < 2 GiB)
+
+__device__ __forceinline__ float ufd_lane_next(float x)          // the value lane + 1 holds (lane 63: unspecified)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+}
+
+struct UfdRollGeom {
+    int sxp, nseg;                    // strips per plane row, segments per plane
+    int64_t n_strips, n_waves;
+    unsigned in_bytes, out_bytes;
+};
+
+__device__ __forceinline__ int64_t ufd_roll_wave_index()
+{
+    // single-wave workgroups; workgroup b runs on XCD b % 8: every XCD gets a contiguous eighth of the wave list (grid is a multiple of 8)
+    return (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+}
+
+// up == 1, DOWN in {1, 2}, FIR <= KH x KW with KW > DOWN, 0 <= pad_x0 < in_w.  SEG output rows per segment, D rows in flight (a multiple of 4).
+template <int DOWN, int KH, int KW, int SEG, int D>
+__global__ void __launch_bounds__(64) ufd_roll_f32_kernel(float* __restrict__ out, const float* __restrict__ in, const float* __restrict__ k, UfdArgs a,
+                                                          UfdRollGeom g)
+{
+    constexpr int NV = DOWN, OWN = 4 * DOWN, NCOL = 3 * DOWN + KW, HALO = NCOL - OWN;
+    constexpr int NRT = (SEG - 1) * DOWN + KH;          // input rows a segment walks
+    constexpr int NIT = (NRT + D - 1) / D;
+    static_assert(HALO >= 1 && HALO <= 4 && KH <= 4 && (D & 3) == 0 && D >= 4, "window shape");
+    const int64_t wv = ufd_roll_wave_index();
+    if (wv >= g.n_waves) return;
+    const int lane = threadIdx.x;
+    const int sg = (int)(wv % g.nseg);
+    const int64_t f0 = (wv / g.nseg) * 64 + lane;
+    const bool live = f0 < g.n_strips;
+    const int64_t f = f0 < g.n_strips ? f0 : g.n_strips - 1;          // idle lanes shadow the last entry
+    const int t = (int)(f % g.sxp);
+    const int64_t m = f / g.sxp;
+    const int ox0 = 4 * t, ix0 = ox0 * DOWN - a.px0;                   // first output column, first owned input column
+    // Segment borders are shifted by a per-group number of rows.  Every wave starts at the same moment and walks at the same pace: with
+    // borders at multiples of SEG rows in every plane all of them would touch addresses that are equal modulo SEG x pitch at every
+    // step, i.e. the same few memory channels (measured: the launch then runs at 4.0 TB/s whatever SEG, D or the FIR size).
+    const int oy_s = sg * SEG - (int)(((((wv / g.nseg) * 64 + 31) / g.sxp) * 11) % SEG), iy_s = oy_s * DOWN - a.py0;
+    if (oy_s >= a.out_h || oy_s + SEG <= 0) return;
+    const int r_first = oy_s < 0 ? -oy_s * DOWN : 0;          // input rows before this one only feed output rows above the image
+    float kreg[KH * KW];          // flipped FIR, zero-extended to the compiled size (upfirdn2d_kernel.cu:136-137)
+#pragma unroll
+    for (int i = 0; i < KH; ++i)
+#pragma unroll
+        for (int j = 0; j < KW; ++j) kreg[i * KW + j] = (i < a.kh && j < a.kw) ? k[(a.kh - 1 - i) * a.kw + (a.kw - 1 - j)] : 0.f;
+    bool cok[OWN];
+#pragma unroll
+    for (int c = 0; c < OWN; ++c) cok[c] = ix0 + c >= 0 && ix0 + c < a.in_w;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, g.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, g.out_bytes, 0x00020000);
+    // A vector that starts left of column 0 reads the tail of the previous row (masked) -- except in row 0 of plane 0, where it would start
+    // before the tensor: that one vector is fetched element-wise here and swapped in when the row comes up.
+    const bool fixl = m == 0 && ix0 < 0;
+    float fix[OWN];
+#pragma unroll
+    for (int c = 0; c < OWN; ++c) fix[c] = 0.f;
+    if (fixl) {
+#pragma unroll
+        for (int c = 0; c < OWN; ++c) if (cok[c]) fix[c] = in[ix0 + c];
+    }
+    const int voff0 = (int)((m * (int64_t)a.in_h * a.in_w + ix0) * 4);          // row 0 of the lane's plane, first owned column
+    const int row_bytes = a.in_w * 4, orow_bytes = a.out_w * 4;
+    const int soff0 = (int)((m * (int64_t)a.out_h * a.out_w + ox0) * 4);
+    const bool st_vec = live && ox0 + 3 < a.out_w;
+    const int ragged = a.out_w & 3;                                             // the last strip of a row holds this many columns (0: a full one)
+    const bool st_rag = live && ragged != 0 && ox0 + 3 >= a.out_w && ox0 < a.out_w;
+
+    // the right neighbour's columns come from lane + 1, except for lane 63 and for the last strip of a plane row: those fetch them
+    // themselves (one more load per row in which every other lane is out of range)
+    const bool self_halo = lane == 63 || t == g.sxp - 1;
+    bool hok[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) hok[c] = c < HALO && ix0 + OWN + c >= 0 && ix0 + OWN + c < a.in_w;
+
+    float win[4][NCOL];          // row r of the segment lives in slot r & 3
+    ufd_u4 pre[D][NV + 1];       // rows r .. r + D - 1 in flight (+ the self-fetched neighbour columns)
+    auto request = [&](int slot, int r) {
+        int iy = iy_s + r;
+        iy = iy < 0 ? 0 : (iy >= a.in_h ? a.in_h - 1 : iy);          // rows outside the image are masked on arrival
+        int vo = voff0 + iy * row_bytes;
+        if (r >= NRT || r < r_first || (fixl && iy == 0)) vo = UFD_OOB;              // nothing to fetch: the range check answers with zeros
+#pragma unroll
+        for (int l = 0; l < NV; ++l) pre[slot][l] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo + 16 * l, 0, 0);
+        pre[slot][NV] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (self_halo && vo != UFD_OOB) ? vo + 16 * NV : UFD_OOB, 0, 0);
+    };
+    // the prologue issues the same sequence of memory instructions as one trip of the loop (its stores are out of range): the compiler's
+    // count of what is in flight at the loop header is then the same from both sides, and its waits inside the loop stay exact
+#pragma unroll
+    for (int p = 0; p < D; ++p) {
+        request(p, p);
+        if ((p + 4 - (KH - 1)) % DOWN != 0) continue;
+        const ufd_u4 z = {0u, 0u, 0u, 0u};
+        __builtin_amdgcn_raw_buffer_store_b128(z, wsrc, UFD_OOB, 0, 0);
+        if (ragged != 0) {
+            __builtin_amdgcn_raw_buffer_store_b32(0u, wsrc, UFD_OOB, 0, 0);
+            if (ragged > 1) __builtin_amdgcn_raw_buffer_store_b32(0u, wsrc, UFD_OOB, 0, 0);
+            if (ragged > 2) __builtin_amdgcn_raw_buffer_store_b32(0u, wsrc, UFD_OOB, 0, 0);
+        }
+    }
+#pragma unroll 1
+    for (int it = 0; it < NIT; ++it) {
+        const int r0 = it * D;
+#pragma unroll
+        for (int p = 0; p < D; ++p) {
+            const int r = r0 + p, w = p & 3;
+            const int iy = iy_s + r;
+            const bool rok = iy >= 0 && iy < a.in_h;          // wave-uniform
+            const bool usefix = fixl && iy == 0;
+            float raw[OWN];
+#pragma unroll
+            for (int l = 0; l < NV; ++l) {
+                raw[4 * l + 0] = __uint_as_float(pre[p][l].x); raw[4 * l + 1] = __uint_as_float(pre[p][l].y);
+                raw[4 * l + 2] = __uint_as_float(pre[p][l].z); raw[4 * l + 3] = __uint_as_float(pre[p][l].w);
+            }
+#pragma unroll
+            for (int c = 0; c < OWN; ++c) {
+                const float v = usefix ? fix[c] : raw[c];
+                win[w][c] = (rok && cok[c]) ? v : 0.f;
+            }
+            {
+                const float hs[4] = {__uint_as_float(pre[p][NV].x), __uint_as_float(pre[p][NV].y), __uint_as_float(pre[p][NV].z), __uint_as_float(pre[p][NV].w)};
+#pragma unroll
+                for (int c = 0; c < HALO; ++c) {
+                    const float nb = ufd_lane_next(win[w][c]);
+                    win[w][OWN + c] = self_halo ? ((rok && hok[c]) ? hs[c] : 0.f) : nb;
+                }
+            }
+            request(p, r + D);
+            if ((p + 4 - (KH - 1)) % DOWN != 0) continue;          // r0 is a multiple of 4 and DOWN divides 4: known at compile time
+            const int q = (r - (KH - 1)) / DOWN;                   // the output row whose last input row is r (negative in the first rows: dropped)
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < KH; ++i) {
+                const int sl = (p + 4 - (KH - 1) + i) & 3;          // slot of input row r - (KH - 1) + i
+#pragma unroll
+                for (int j = 0; j < KW; ++j)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[c] = fmaf(win[sl][c * DOWN + j], kreg[i * KW + j], acc[c]);
+            }
+            const bool row_ok = r >= KH - 1 && q < SEG && oy_s + q >= 0 && oy_s + q < a.out_h;          // wave-uniform
+            const int so = soff0 + (oy_s + q) * orow_bytes;
+            const ufd_u4 o = {__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]), __float_as_uint(acc[3])};
+            __builtin_amdgcn_raw_buffer_store_b128(o, wsrc, (row_ok && st_vec) ? so : UFD_OOB, 0, 0);
+            if (ragged != 0) {                                       // wave-uniform, the same in every row
+                const int sr = (row_ok && st_rag) ? so : UFD_OOB;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[0]), wsrc, sr, 0, 0);
+                if (ragged > 1) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[1]), wsrc, sr == UFD_OOB ? sr : sr + 4, 0, 0);
+                if (ragged > 2) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[2]), wsrc, sr == UFD_OOB ? sr : sr + 8, 0, 0);
+            }
+        }
+    }
+}
+
+static bool ufd_roll_geom(UfdRollGeom& g, const UfdArgs& a, int out_cols_per_strip, int nseg)
+{
+    g.sxp = (a.out_w + out_cols_per_strip - 1) / out_cols_per_strip;
+    g.nseg = nseg;
+    g.n_strips = a.major * g.sxp;
+    g.n_waves = (g.n_strips + 63) / 64 * g.nseg;
+    const int64_t ib = a.major * (int64_t)a.in_h * a.in_w * 4, ob = a.major * (int64_t)a.out_h * a.out_w * 4;
+    if (ib >= 0x7fff0000LL || ob >= 0x7fff0000LL) return false;
+    g.in_bytes = (unsigned)ib;
+    g.out_bytes = (unsigned)ob;
+    return true;
+}
+
+template <int DOWN, int KH, int KW, int SEG, int D>
+static int ufd_launch_roll(float* out, const float* in, const float* k, const UfdArgs& a, hipStream_t st)
+{
+    UfdRollGeom g;
+    if (!ufd_roll_geom(g, a, 4, (a.out_h + SEG - 1 + SEG - 1) / SEG)) return HAV_EUNSUP;          // + the rows the shifted borders add
+    const int64_t blocks = (g.n_waves + 7) / 8 * 8;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return HAV_EUNSUP;
+    hipLaunchKernelGGL((ufd_roll_f32_kernel<DOWN, KH, KW, SEG, D>), dim3((unsigned)blocks), dim3(64), 0, st, out, in, k, a, g);
+    HAV_LAUNCH_CHECK();
+    return 0;
+}
+
+// x2 up-sampling (up = 2, down = 1, FIR <= 4x4, 0 <= pad0 <= 4, EX = pad_x0 & 1): strip t produces the output columns 4 t .. 4 t + 3 (a wave
+// stores one contiguous KiB per output row); tap j of output c is real iff c + j - EX is even and then sits on input column
+// b + (c + j - EX) / 2, b = 2 t - pad_x0 / 2: 2 owned columns (one 8-byte load) and 2 - EX of the neighbour's.  Rows: input row a
+// completes the output rows 2 a + pad_y0 - 3 + q, q = 0, 1, which use rows a - 1 and a (tap i of q is real iff q + 1 + i is even).
+// A segment is SEG input rows.
+typedef unsigned int ufd_u2 __attribute__((ext_vector_type(2)));
+template <int EX, int SEG, int D>
+__global__ void __launch_bounds__(64) ufd_roll_up2_f32_kernel(float* __restrict__ out, const float* __restrict__ in, const float* __restrict__ k, UfdArgs a,
+                                                              UfdRollGeom g, int a_min, int a_max)
+{
+    constexpr int OWN = 2, HALO = 2 - EX, NCOL = OWN + HALO, NRT = SEG + 1, NIT = (NRT + D - 1) / D;
+    static_assert((D & 1) == 0, "two window slots");
+    const int64_t wv = ufd_roll_wave_index();
+    if (wv >= g.n_waves) return;
+    const int lane = threadIdx.x;
+    const int sg = (int)(wv % g.nseg);
+    const int64_t f0 = (wv / g.nseg) * 64 + lane;
+    const bool live = f0 < g.n_strips;
+    const int64_t f = f0 < g.n_strips ? f0 : g.n_strips - 1;
+    const int t = (int)(f % g.sxp);
+    const int64_t m = f / g.sxp;
+    const int ox0 = 4 * t, ix0 = 2 * t - (a.px0 >> 1);
+    const int iy_s = a_min + sg * SEG - (int)(((((wv / g.nseg) * 64 + 31) / g.sxp) * 11) % SEG);          // first input row of the segment's window (borders shifted per plane)
+    if (iy_s > a_max || iy_s + SEG <= a_min) return;
+    const int r_first = iy_s < a_min ? a_min - iy_s : 0;
+    const int oy_s = 2 * iy_s + a.py0 - 1;                   // the output row (rows iy_s, iy_s + 1; q = 0)
+    float kreg[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) kreg[i * 4 + j] = (i < a.kh && j < a.kw) ? k[(a.kh - 1 - i) * a.kw + (a.kw - 1 - j)] : 0.f;
+    bool cok[OWN], hok[2];
+#pragma unroll
+    for (int c = 0; c < OWN; ++c) cok[c] = ix0 + c >= 0 && ix0 + c < a.in_w;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) hok[c] = c < HALO && ix0 + OWN + c >= 0 && ix0 + OWN + c < a.in_w;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, g.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, g.out_bytes, 0x00020000);
+    const bool fixl = m == 0 && ix0 < 0;          // see ufd_roll_f32_kernel
+    float fix[OWN];
+#pragma unroll
+    for (int c = 0; c < OWN; ++c) fix[c] = 0.f;
+    if (fixl) {
+#pragma unroll
+        for (int c = 0; c < OWN; ++c) if (cok[c]) fix[c] = in[ix0 + c];
+    }
+    const int voff0 = (int)((m * (int64_t)a.in_h * a.in_w + ix0) * 4);
+    const int row_bytes = a.in_w * 4, orow_bytes = a.out_w * 4;
+    const int soff0 = (int)((m * (int64_t)a.out_h * a.out_w + ox0) * 4);
+    const bool st_vec = live && ox0 + 3 < a.out_w;
+    const int ragged = a.out_w & 3;
+    const bool st_rag = live && ragged != 0 && ox0 + 3 >= a.out_w && ox0 < a.out_w;
+    const bool self_halo = lane == 63 || t == g.sxp - 1;
+
+    float win[2][NCOL];          // row r of the segment lives in slot r & 1
+    ufd_u2 pre[D][2];
+    auto request = [&](int slot, int r) {
+        int iy = iy_s + r;
+        iy = iy < 0 ? 0 : (iy >= a.in_h ? a.in_h - 1 : iy);
+        int vo = voff0 + iy * row_bytes;
+        if (r >= NRT || r < r_first || (fixl && iy == 0)) vo = UFD_OOB;
+        pre[slot][0] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, vo, 0, 0);
+        pre[slot][1] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (self_halo && vo != UFD_OOB) ? vo + 4 * OWN : UFD_OOB, 0, 0);
+    };
+#pragma unroll
+    for (int p = 0; p < D; ++p) {          // same sequence of memory instructions as one trip of the loop (see ufd_roll_f32_kernel)
+        request(p, p);
+        const ufd_u4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            __builtin_amdgcn_raw_buffer_store_b128(z, wsrc, UFD_OOB, 0, 0);
+            if (ragged != 0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    if (c < ragged) __builtin_amdgcn_raw_buffer_store_b32(0u, wsrc, UFD_OOB, 0, 0);
+            }
+        }
+    }
+#pragma unroll 1
+    for (int it = 0; it < NIT; ++it) {
+        const int r0 = it * D;
+#pragma unroll
+        for (int p = 0; p < D; ++p) {
+            const int r = r0 + p, w = p & 1;
+            const int iy = iy_s + r;
+            const bool rok = iy >= 0 && iy < a.in_h;
+            const bool usefix = fixl && iy == 0;
+            const float raw[2] = {__uint_as_float(pre[p][0].x), __uint_as_float(pre[p][0].y)};
+#pragma unroll
+            for (int c = 0; c < OWN; ++c) {
+                const float v = usefix ? fix[c] : raw[c];
+                win[w][c] = (rok && cok[c]) ? v : 0.f;
+            }
+            {
+                const float hs[2] = {__uint_as_float(pre[p][1].x), __uint_as_float(pre[p][1].y)};
+#pragma unroll
+                for (int c = 0; c < HALO; ++c) {
+                    const float nb = ufd_lane_next(win[w][c]);
+                    win[w][OWN + c] = self_halo ? ((rok && hok[c]) ? hs[c] : 0.f) : nb;
+                }
+            }
+            request(p, r + D);
+            // rows r - 1 and r complete the output rows oy_s + 2 (r - 1) + q
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int oy = oy_s + 2 * (r - 1) + q;
+                const bool row_ok = r >= 1 && r < NRT && oy >= 0 && oy < a.out_h;          // wave-uniform
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (((q + 1 + i) & 1) != 0) continue;          // tap row i of this output row sits between two samples
+                    const int sl = (w + 1 + ((q + i - 1) >> 1)) & 1;          // q = 0: i = 1 -> row r - 1, i = 3 -> row r; q = 1: i = 0 -> r - 1, i = 2 -> r
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            if (((c + j + EX) & 1) != 0) continue;
+                            acc[c] = fmaf(win[sl][(c + j - EX) >> 1], kreg[i * 4 + j], acc[c]);
+                        }
+                }
+                const int so = soff0 + oy * orow_bytes;
+                const ufd_u4 v0 = {__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]), __float_as_uint(acc[3])};
+                __builtin_amdgcn_raw_buffer_store_b128(v0, wsrc, (row_ok && st_vec) ? so : UFD_OOB, 0, 0);
+                if (ragged != 0) {                                   // wave-uniform
+                    const int sr = (row_ok && st_rag) ? so : UFD_OOB;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        if (c < ragged) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[c]), wsrc, sr == UFD_OOB ? sr : sr + 4 * c, 0, 0);
+                }
+            }
+        }
+    }
+}
+
+template <int SEG, int D>
+static int ufd_launch_roll_up2(float* out, const float* in, const float* k, const UfdArgs& a, hipStream_t st)
+{
+    UfdRollGeom g;
+    const int a_min = -(a.py0 >> 1), a_max = (a.out_h - 1 - a.py0 + 1) >> 1;          // first window rows of output rows 0 and out_h - 1
+    if (!ufd_roll_geom(g, a, 4, (a_max - a_min + 1 + SEG - 1 + SEG - 1) / SEG)) return HAV_EUNSUP;
+    const int64_t blocks = (g.n_waves + 7) / 8 * 8;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return HAV_EUNSUP;
+    if (a.px0 & 1) hipLaunchKernelGGL((ufd_roll_up2_f32_kernel<1, SEG, D>), dim3((unsigned)blocks), dim3(64), 0, st, out, in, k, a, g, a_min, a_max);
+    else hipLaunchKernelGGL((ufd_roll_up2_f32_kernel<0, SEG, D>), dim3((unsigned)blocks), dim3(64), 0, st, out, in, k, a, g, a_min, a_max);
+    HAV_LAUNCH_CHECK();
+    return 0;
+}
+
+// kernel choice for A/B runs and the bit-identity tests: HAVATAR_UFD=legacy (read once) or hav_lab_upfirdn2d(mode, seg) at run time
+// (mode 1: row-streaming kernels for blur and x2 up-sampling, the default; 2: for decimation too; 0: the strip / tiled kernels; seg > 0
+// forces the rows per segment).  Not part of the ABI.
+static std::atomic<int> g_ufd_mode{-1}, g_ufd_seg{0};
+static int ufd_lab_mode()
+{
+    int m = g_ufd_mode.load(std::memory_order_relaxed);
+    if (m < 0) {
+        const char* e = getenv("HAVATAR_UFD");
+        m = (e && !strcmp(e, "legacy")) ? 0 : 1;
+        const char* sg = getenv("HAVATAR_UFD_SEG");
+        if (sg) g_ufd_seg.store(atoi(sg), std::memory_order_relaxed);
+        g_ufd_mode.store(m, std::memory_order_relaxed);
+    }
+    return m;
+}
+extern "C" void hav_lab_upfirdn2d(int mode, int seg)
+{
+    g_ufd_mode.store(mode, std::memory_order_relaxed);
+    g_ufd_seg.store(seg > 0 ? seg : 0, std::memory_order_relaxed);
+}
+
 template <typename T>
 static int ufd_launch(void* out_, const void* in_, const float* k, const UfdArgs& a, hipStream_t st)
 {
@@ -962,6 +1335,38 @@ static int ufd_launch(void* out_, const void* in_, const float* k, const UfdArgs
     if (a.minor == 1 && a.up_x == a.up_y && a.down_x == a.down_y) {
         const int up = a.up_x, dn = a.down_x, kh = a.kh, kw = a.kw;
         if constexpr (std::is_same<T, float>::value) {
+            // the row-streaming kernels take the three classes of the StyleGAN blocks; HAVATAR_UFD=legacy (read once) keeps the strip / tiled
+            // kernels below for A/B runs and for the bit-identity tests, HAVATAR_UFD_SEG forces the rows per segment
+            const int roll_mode = ufd_lab_mode(), roll_seg = g_ufd_seg.load(std::memory_order_relaxed);
+            if (roll_mode && a.out_w >= 64 && kh <= 4 && kw <= 4 && a.px0 >= 0 && a.py0 >= 0 && a.px0 <= 4 && a.py0 <= 4 && a.in_w > 8) {
+                // rows per segment: the longest segment that still gives the chip 9 waves per compute unit (fewer window rows re-read);
+                // small launches take the shortest one
+                auto pick = [&](int rows, int shortest) {
+                    if (roll_seg) return roll_seg;
+                    const int64_t grp = (a.major * ((a.out_w + 3) / 4) + 63) / 64, want = (int64_t)hav_num_cus() * 9;
+                    for (int sgm = 32; sgm > shortest; sgm >>= 1) if (grp * ((rows + sgm - 1) / sgm) >= want) return sgm;
+                    return shortest;
+                };
+#define UFD_ROLL(DN_, KH_, KW_)                                                                                                       \
+    do {                                                                                                                              \
+        const int sgm = pick(a.out_h, 8);                                                                                             \
+        if (sgm >= 32) return ufd_launch_roll<DN_, KH_, KW_, 33, 4>((float*)out, (const float*)in, k, a, st);                         \
+        if (sgm >= 16) return ufd_launch_roll<DN_, KH_, KW_, 17, 4>((float*)out, (const float*)in, k, a, st);                         \
+        return ufd_launch_roll<DN_, KH_, KW_, 9, 4>((float*)out, (const float*)in, k, a, st);                                         \
+    } while (0)
+                if (up == 1 && dn == 1 && (kh > 3 || kw > 3)) UFD_ROLL(1, 4, 4);
+                if (up == 1 && dn == 1 && kw >= 2) UFD_ROLL(1, 3, 3);
+                // decimation: the LDS-tiled kernel below is faster (19.3 vs 20.3 us at [64,513,513]); mode 2 takes the window kernel (tests)
+                if (up == 1 && dn == 2 && kw > 2 && roll_mode == 2) UFD_ROLL(2, 4, 4);
+#undef UFD_ROLL
+                if (up == 2 && dn == 1) {
+                    const int sgm = pick((a.out_h + 1) / 2, 4);
+                    if (sgm >= 32) return ufd_launch_roll_up2<33, 4>((float*)out, (const float*)in, k, a, st);
+                    if (sgm >= 16) return ufd_launch_roll_up2<17, 4>((float*)out, (const float*)in, k, a, st);
+                    if (sgm >= 8) return ufd_launch_roll_up2<9, 4>((float*)out, (const float*)in, k, a, st);
+                    return ufd_launch_roll_up2<5, 4>((float*)out, (const float*)in, k, a, st);
+                }
+            }
             // f32 blur (no re-sampling) on planes wide enough for 16-byte strips: the direct kernel.  Measured on MI355X with every launch
             // on its own buffers (tools/bench_ops.py): [64,513,513] 4x4 blur 37.4 -> 34.4 us = 3.9 TB/s, which is 82 % of what a plain
             // device copy of the same 135 MB reaches (28.3 us) and 71 % of this library's best streaming kernel at that size.  The

@@ -158,6 +158,44 @@ def test_upfirdn2d_decimating_direct_kernel_is_bit_identical_to_the_tiled_one(tm
         assert np.array_equal(outs["sr8"][key], outs["tiled"][key]), key
 
 
+@pytest.mark.parametrize("case", [
+    # (major, H, W, kh, kw, up, down, pad)
+    (5, 513, 513, 4, 4, 1, 1, (1, 1, 1, 1)), (3, 513, 513, 4, 4, 1, 1, (2, 1, 2, 1)), (2, 512, 512, 3, 3, 1, 1, (1, 1, 1, 1)),
+    (3, 70, 131, 4, 4, 1, 1, (2, 2, 2, 2)), (1, 40, 300, 4, 4, 1, 1, (0, 3, 0, 3)), (2, 37, 257, 4, 4, 1, 1, (4, 1, 4, 0)),
+    (2, 9, 66, 2, 4, 1, 1, (3, 2, 0, 1)), (1, 100, 65, 4, 3, 1, 1, (1, 2, 3, 2)), (3, 33, 70, 3, 3, 1, 1, (2, 2, 2, 2)), (2, 5, 80, 3, 2, 1, 1, (0, 1, 1, 1)),
+    (300, 35, 68, 4, 4, 1, 1, (2, 1, 2, 1)),
+    (3, 513, 513, 4, 4, 1, 2, (1, 1, 1, 1)), (2, 140, 259, 4, 4, 1, 2, (2, 1, 0, 3)), (2, 66, 300, 3, 4, 1, 2, (0, 0, 1, 1)), (1, 9, 128, 4, 4, 1, 2, (3, 3, 3, 3)),
+    (2, 512, 512, 4, 4, 1, 2, (1, 1, 1, 1)), (2, 131, 270, 4, 3, 1, 2, (4, 0, 4, 1)),
+    (12, 512, 512, 4, 4, 2, 1, (2, 1, 2, 1)), (3, 64, 64, 4, 4, 2, 1, (2, 1, 2, 1)), (2, 37, 50, 4, 4, 2, 1, (1, 2, 3, 0)), (1, 128, 96, 3, 4, 2, 1, (3, 2, 0, 5)),
+    (3, 512, 512, 2, 2, 2, 1, (1, 0, 1, 0)), (2, 33, 45, 4, 4, 2, 1, (4, 3, 4, 1)), (2, 40, 41, 2, 4, 2, 1, (0, 3, 2, 1)), (5, 17, 33, 4, 4, 2, 1, (0, 1, 1, 2)),
+])
+def test_upfirdn2d_row_streaming_kernels_are_bit_identical_to_the_tiled_ones(case):
+    """The rolling-window kernels (ufd_roll_f32_kernel / ufd_roll_up2_f32_kernel: default for blur and x2 up-sampling, mode 2 of the lab hook
+    for decimation) keep the tap order of the strip / tiled kernels: same bits for every rows-per-segment choice, at ragged sizes, every
+    padding parity, FIRs smaller than the compiled 4x4, the first vector of the tensor (left padding in row 0 of plane 0) and the last one."""
+    from havatar_amd import _lib
+    from havatar_amd.native import upfirdn2d as op
+    major, H, W, kh, kw, up, dn, pad = case
+    L = _lib.lib()
+    g = torch.Generator(device=DEV).manual_seed(H * 1000 + W)
+    x = torch.randn(major, H, W, 1, device=DEV, generator=g)
+    k = torch.randn(kh, kw, device=DEV, generator=g)
+    try:
+        L.hav_lab_upfirdn2d(0, 0)
+        ref = op.upfirdn2d(x, k, up, up, dn, dn, *pad)
+        for seg in (0, 4, 8, 16, 32):
+            L.hav_lab_upfirdn2d(2, seg)
+            y = op.upfirdn2d(x, k, up, up, dn, dn, *pad)
+            assert torch.equal(y, ref), (case, seg, float((y - ref).abs().max()))
+        # the tensor right at the start / end of an allocation: nothing is read or written outside it
+        big = torch.full((x.numel() + 64,), float("nan"), device=DEV)
+        big[32:32 + x.numel()] = x.reshape(-1)
+        y = op.upfirdn2d(big[32:32 + x.numel()].view_as(x), k, up, up, dn, dn, *pad)
+        assert torch.equal(y, ref)
+    finally:
+        L.hav_lab_upfirdn2d(1, 0)
+
+
 def test_upfirdn2d_half_precisions_and_errors():
     from oracle import oracle
     from havatar_amd.native import upfirdn2d as op

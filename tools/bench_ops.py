@@ -74,12 +74,15 @@ for name, shape in (("fused_bias_act [1,64,512,512]", (1, 64, 512, 512)), ("fuse
     ms, K = timed(mk_bwd, 12 * n_el)
     rows.append((name + " grad=1", ms, 12 * n_el, K))
     torch.cuda.empty_cache()
-for name, shape, k, up, dn, pad in (("upfirdn2d blur k4 [64,513,513]", (64, 513, 513, 1), k4, 1, 1, (2, 1, 2, 1)),
+# the blur behind the up-sampling StyledConv of SWGAN_unet's 512^2 level: conv_transpose2d 256^2 -> 513^2, Blur(pad = (1, 1)) -> 512^2
+# (model/styleUnet.py:186-194; rounds 1-4 timed this row with pad (2, 1) -> 513^2, which is now the last row of the full table)
+for name, shape, k, up, dn, pad in (("upfirdn2d blur k4 [64,513,513] pad (1,1)", (64, 513, 513, 1), k4, 1, 1, (1, 1, 1, 1)),
                                     ("upfirdn2d down2 k4 [64,513,513]", (64, 513, 513, 1), k4, 1, 2, (1, 1, 1, 1)),
                                     ("upfirdn2d up2 k4 [12,512,512]", (12, 512, 512, 1), k4 * 4, 2, 1, (2, 1, 2, 1)),
                                     ("upfirdn2d up2 haar [3,512,512]", (3, 512, 512, 1), haar, 2, 1, (1, 0, 1, 0)),
                                     ("upfirdn2d down2 haar [3,1024,1024]", (3, 1024, 1024, 1), haar, 1, 2, (0, 0, 0, 0)),
-                                    ("upfirdn2d blur k4 [512,35,35]", (512, 35, 35, 1), k4, 1, 1, (2, 1, 2, 1)))[:3 if BRIEF else 6]:
+                                    ("upfirdn2d blur k4 [512,35,35]", (512, 35, 35, 1), k4, 1, 1, (2, 1, 2, 1)),
+                                    ("upfirdn2d blur k4 [64,513,513] pad (2,1) -> 513^2", (64, 513, 513, 1), k4, 1, 1, (2, 1, 2, 1)))[:3 if BRIEF else 7]:
     y = upfirdn2d.upfirdn2d(torch.randn(shape, device=dev), k, up, up, dn, dn, *pad)
     n_in = 1
     for d in shape:
