@@ -256,6 +256,187 @@ __global__ void __launch_bounds__(256) field_inputs_kernel(FieldArgs a)
     }
 }
 
+// ---- the same field inputs, 16 queries of a wave at a time --------------------------------------------------------------------------
+// field_inputs_kernel walks its queries one after the other: the point -> the volume taps -> the plane taps -> (backward) the gradient
+// row are four dependent round trips to memory per query, 16 queries deep, and nothing else hides them but the other waves of the
+// compute unit.  Here a wave takes
+// a run of 16 consecutive queries through two stages:
+//   1. geometry, 4 lanes per query: the point, both bones' volume taps (4 taps per lane, all 16 queries' loads in flight together), the
+//      blended point, the bilinear taps of both planes -- per-query values that stay in the lanes 4 q .. 4 q + 3;
+//   2. channels, lane = channel: for 4 queries at a time every plane row (and gradient row) is requested before the first one is used --
+//      the tap ids, weights and validity bits of a query are wave-uniform and come out of lane 4 q with v_readlane --, then the queries
+//      are finished in order: X rows out (MODE 0), or the tap windows merged and flushed as rows of atomics exactly as field_inputs_kernel<2>
+//      does (MODE 2); the volume gradients leave at the end of the run from the geometry lanes (4 taps per lane).
+// The arithmetic per query is the other kernel's, statement for statement (same association of every sum).
+// Measured at config 5's size (0.92 M queries, tools/bench_field_inputs.py): forward 0.58 -> 0.27 ms per call; backward see hav_field_inputs_bwd.
+#define FR_RUN 16
+template <int MODE>
+__global__ void __launch_bounds__(256) field_inputs_run_kernel(FieldArgs a)
+{
+    const int lane = threadIdx.x & 63, sub = lane & 3, ql = lane >> 2;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int C = a.C, H = a.H, W = a.W, D = a.D, XW = 2 * C + PE_DIM;
+    const size_t plane_sz = (size_t)a.B * H * W * C;
+    const int vol_sz = D * D * D;
+    const int cc = lane < C ? lane : C - 1;
+    const bool con = lane < C;
+    const int f = lane / 6, r6 = lane - 6 * f, j = r6 >= 3 ? r6 - 3 : r6;
+    const float freq = (float)(1 << (f & 7));
+    const bool pe_on = lane < PE_DIM;
+    const int64_t nruns = (a.n + FR_RUN - 1) / FR_RUN;
+    for (int64_t run = wave0; run < nruns; run += nwaves) {
+        const int64_t i0 = run * FR_RUN;
+        // ---------------- stage 1: geometry of query i0 + ql in lanes 4 ql .. 4 ql + 3
+        const bool qok = i0 + ql < a.n;
+        const int64_t iq = qok ? i0 + ql : a.n - 1;
+        const int b = (int)(iq / a.n_per_b);
+        const float px = a.pts[iq * 3 + 0], py = a.pts[iq * 3 + 1], pz = a.pts[iq * 3 + 2];
+        const float* T = a.invT + (size_t)b * 12;
+        const float tx = px + T[9], ty = py + T[10], tz = pz + T[11];
+        const float p1x = tx * T[0] + ty * T[3] + tz * T[6], p1y = tx * T[1] + ty * T[4] + tz * T[7], p1z = tx * T[2] + ty * T[5] + tz * T[8];
+        const int bone = sub >> 1;
+        const float sx = bone ? p1x : px, sy = bone ? p1y : py, sz = bone ? p1z : pz;
+        float gx = ((sx * a.ss[0] + a.st[0]) + 1.f) * 0.5f * (float)(D - 1), gy = ((sy * a.ss[1] + a.st[1]) + 1.f) * 0.5f * (float)(D - 1),
+              gz = ((sz * a.ss[2] + a.st[2]) + 1.f) * 0.5f * (float)(D - 1);
+        gx = fminf(fmaxf(gx, 0.f), (float)(D - 1)); gy = fminf(fmaxf(gy, 0.f), (float)(D - 1)); gz = fminf(fmaxf(gz, 0.f), (float)(D - 1));
+        const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
+        float tw[4]; int vidx[4]; bool vin[4]; float pv[4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int tap = 4 * (sub & 1) + tt;
+            const int vx = (int)fx + (tap & 1), vy = (int)fy + ((tap >> 1) & 1), vz = (int)fz + (tap >> 2);
+            const float wx = (tap & 1) ? gx - fx : 1.f - (gx - fx), wy = (tap & 2) ? gy - fy : 1.f - (gy - fy), wz = (tap & 4) ? gz - fz : 1.f - (gz - fz);
+            vin[tt] = vx < D && vy < D && vz < D;
+            vidx[tt] = bone * vol_sz + (min(vz, D - 1) * D + min(vy, D - 1)) * D + min(vx, D - 1);
+            tw[tt] = vin[tt] ? wx * wy * wz : 0.f;
+            pv[tt] = a.vol[vidx[tt]];
+        }
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) pv[tt] = vin[tt] ? tw[tt] * pv[tt] : 0.f;
+        float part = (pv[0] + pv[1]) + (pv[2] + pv[3]);          // the butterfly of the other kernel: xor 1, xor 2 inside the lane, xor 4 across
+        part += __shfl_xor(part, 1, 64);
+        const float wo = __shfl_xor(part, 2, 64);
+        const float w0 = bone ? wo : part, w1 = bone ? part : wo;
+        const float s = (w0 + w1) + 1e-8f;
+        float rs = __builtin_amdgcn_rcpf(s);
+        rs = rs * (2.0f - s * rs);
+        const float h0 = w0 * rs, h1 = w1 * rs;
+        const float rx = h0 * px + h1 * p1x, ry = h0 * py + h1 * p1y, rz = h0 * pz + h1 * p1z;
+        const float qx = rx * a.bs[0] + a.bt[0], qy = ry * a.bs[1] + a.bt[1], qz = rz * a.bs[2] + a.bt[2];
+        int trow[2][4]; float twt[2][4], twx0[2], twx1[2], twy0[2], twy1[2];
+        int vmask = 0;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            int idx[4]; bool valid[4];
+            plane_taps(p ? qz : qx, qy, H, W, idx, twt[p], twx0[p], twx1[p], twy0[p], twy1[p], valid);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { trow[p][k] = b * H * W + idx[k]; vmask |= valid[k] ? 1 << (4 * p + k) : 0; }
+        }
+        float dxs = 0.f, dys = 0.f, dzs = 0.f;          // (MODE 2) d loss / d p' of this lane's query, filled in stage 2
+
+        // ---------------- stage 2: lane = channel
+        int wkey[2][4] = {{-1, -1, -1, -1}, {-1, -1, -1, -1}};
+        float wacc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        auto bcast_i = [&](int v, int q) { return __builtin_amdgcn_readlane(v, 4 * q); };
+        auto bcast_f = [&](float v, int q) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 4 * q)); };
+#pragma unroll 1
+        for (int qg = 0; qg < FR_RUN / 4; ++qg) {
+            float t[4][2][4]; float2 g2[4]; float gpe[4];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int q = 4 * qg + qq;
+                const int64_t i = i0 + q < a.n ? i0 + q : a.n - 1;          // (queries past the end repeat the last one; nothing of them leaves)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) t[qq][p][k] = a.planes[p * plane_sz + (size_t)bcast_i(trow[p][k], q) * C + cc];
+                if (MODE != 0) {
+                    g2[qq] = *reinterpret_cast<const float2*>(a.dX + i * XW + 2 * cc);
+                    gpe[qq] = a.dX[i * XW + 2 * C + (pe_on ? lane : 0)];
+                }
+            }
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int q = 4 * qg + qq;
+                const int64_t i = i0 + q;
+                if (i >= a.n) break;          // wave-uniform
+                const int vm = bcast_i(vmask, q);
+                float dqx = 0.f, dqy = 0.f, dqz = 0.f;
+                float xo[2];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    float w[4], tt4[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { w[k] = bcast_f(twt[p][k], q); tt4[k] = ((vm >> (4 * p + k)) & 1) ? t[qq][p][k] : 0.f; }
+                    if (MODE == 0) {
+                        xo[p] = ((tt4[0] * w[0] + tt4[1] * w[1]) + tt4[2] * w[2]) + tt4[3] * w[3];
+                    } else {
+                        const float g = con ? (p ? g2[qq].y : g2[qq].x) : 0.f;
+                        const float wx0 = bcast_f(twx0[p], q), wx1 = bcast_f(twx1[p], q), wy0 = bcast_f(twy0[p], q), wy1 = bcast_f(twy1[p], q);
+                        if (a.dplanes) {
+                            // new window: the four taps of this query; old sums move to the slot of the same texel or are flushed
+                            int nkey[4]; float nacc[4];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                nkey[k] = ((vm >> (4 * p + k)) & 1) ? bcast_i(trow[p][k], q) : -1;
+                                nacc[k] = w[k] * g;
+                            }
+                            float* dp0 = a.dplanes + p * plane_sz;
+#pragma unroll
+                            for (int o = 0; o < 4; ++o) {
+                                const int ok = wkey[p][o];
+                                if (ok < 0) continue;
+                                if (ok == nkey[0]) nacc[0] += wacc[p][o];
+                                else if (ok == nkey[1]) nacc[1] += wacc[p][o];
+                                else if (ok == nkey[2]) nacc[2] += wacc[p][o];
+                                else if (ok == nkey[3]) nacc[3] += wacc[p][o];
+                                else if (con) atomicAdd(dp0 + (size_t)ok * C + lane, wacc[p][o]);
+                            }
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) { wkey[p][k] = nkey[k]; wacc[p][k] = nacc[k]; }
+                        }
+                        const float ggx = g * ((tt4[1] - tt4[0]) * wy0 + (tt4[3] - tt4[2]) * wy1);
+                        const float ggy = g * ((tt4[2] - tt4[0]) * wx0 + (tt4[3] - tt4[1]) * wx1);
+                        if (p == 0) dqx += ggx; else dqz += ggx;
+                        dqy += ggy;
+                    }
+                }
+                const float rxq = bcast_f(rx, q), ryq = bcast_f(ry, q), rzq = bcast_f(rz, q);
+                const float coord = j == 0 ? rxq : (j == 1 ? ryq : rzq);
+                const float arg = r6 >= 3 ? coord * freq + 1.57079632679489661923f : coord * freq;
+                if (MODE == 0) {
+                    if (con) *reinterpret_cast<float2*>(a.X + i * XW + 2 * lane) = make_float2(xo[0], xo[1]);
+                    if (pe_on) a.X[i * XW + 2 * C + lane] = sinf(arg);
+                } else if (a.dvol) {
+                    float dx = dqx * (0.5f * (float)(W - 1)) * a.bs[0], dy = dqy * (0.5f * (float)(H - 1)) * a.bs[1], dz = dqz * (0.5f * (float)(W - 1)) * a.bs[2];
+                    if (pe_on) {
+                        const float ge = gpe[qq] * freq * cosf(arg);
+                        if (j == 0) dx += ge; else if (j == 1) dy += ge; else dz += ge;
+                    }
+                    dx = wsum64(dx); dy = wsum64(dy); dz = wsum64(dz);
+                    if (ql == q) { dxs = dx; dys = dy; dzs = dz; }
+                }
+            }
+        }
+        if (MODE != 0 && a.dplanes) {          // end of the run: whatever is still in the windows
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int o = 0; o < 4; ++o)
+                    if (wkey[p][o] >= 0 && con) atomicAdd(a.dplanes + p * plane_sz + (size_t)wkey[p][o] * C + lane, wacc[p][o]);
+        }
+        if (MODE != 0 && a.dvol && qok) {
+            // p' = h0 p0 + h1 p1, h_i = w_i / s: d/dw_i = (d/dh_i - sum_j d/dh_j h_j) / s
+            const float dh0 = dxs * px + dys * py + dzs * pz, dh1 = dxs * p1x + dys * p1y + dzs * p1z;
+            const float mix = dh0 * h0 + dh1 * h1;
+            const float dw = ((bone ? dh1 : dh0) - mix) * rs;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+                if (vin[tt] && tw[tt] * dw != 0.f) atomicAdd(a.dvol + vidx[tt], tw[tt] * dw);   // clamped (border) coordinates: half the taps weigh 0
+        }
+    }
+}
+
 // volume taps of MODE 4 -> 64-bit fixed-point accumulators (scale from the maximum the first kernel left in *vmax)
 __global__ void __launch_bounds__(256) vol_fixed_scatter_kernel(long long* __restrict__ fvol, const float* __restrict__ vval, const int* __restrict__ vidx,
                                                                 int64_t n16, const unsigned int* __restrict__ vmax, int fixbits)
@@ -313,7 +494,12 @@ extern "C" int hav_field_inputs_fwd(float* X, const HavFieldParams* p, const flo
     if (p->n == 0) return 0;
     FieldArgs a = field_args(p, pts, inv_T, vol, planes_cl);
     a.X = X;
-    hipLaunchKernelGGL(field_inputs_kernel<0>, dim3(field_blocks(p->n)), dim3(256), 0, (hipStream_t)stream, a);
+    // HAVATAR_FIELD_BWD=walk|taps keeps the one-query-at-a-time kernels (A/B runs); read once
+    static const bool serial = [] { const char* e = getenv("HAVATAR_FIELD_BWD"); return e && (!strcmp(e, "taps") || !strcmp(e, "walk")); }();
+    if (p->C <= 64 && !serial)
+        hipLaunchKernelGGL(field_inputs_run_kernel<0>, dim3(field_blocks((p->n + FR_RUN - 1) / FR_RUN)), dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(field_inputs_kernel<0>, dim3(field_blocks(p->n)), dim3(256), 0, (hipStream_t)stream, a);
     HAV_LAUNCH_CHECK();
     return 0;
 }
@@ -328,7 +514,12 @@ extern "C" int hav_field_inputs_bwd(float* dplanes_cl, float* dvol, const float*
     a.dX = dX; a.dplanes = dplanes_cl; a.dvol = dvol;
     // HAVATAR_FIELD_BWD=taps keeps the one-row-of-atomics-per-tap kernel (A/B runs); read once
     static const bool per_tap = [] { const char* e = getenv("HAVATAR_FIELD_BWD"); return e && !strcmp(e, "taps"); }();
-    if (p->C <= 64 && !per_tap)
+    // the 16-queries-at-a-time kernel is the forward's default; backward it is bound by its atomics and wave sums, not by latency, and runs
+    // at 2 waves per SIMD: 1.73 vs 1.48 ms per call at config 5's size (tools/bench_field_inputs.py), so it only runs on request
+    static const bool runs = [] { const char* e = getenv("HAVATAR_FIELD_BWD"); return e && !strcmp(e, "runs"); }();
+    if (p->C <= 64 && !per_tap && runs)
+        hipLaunchKernelGGL(field_inputs_run_kernel<2>, dim3(field_blocks((p->n + FR_RUN - 1) / FR_RUN)), dim3(256), 0, (hipStream_t)stream, a);
+    else if (p->C <= 64 && !per_tap)
         hipLaunchKernelGGL(field_inputs_kernel<2>, dim3(field_blocks((p->n + FI_RUN - 1) / FI_RUN)), dim3(256), 0, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL(field_inputs_kernel<1>, dim3(field_blocks(p->n)), dim3(256), 0, (hipStream_t)stream, a);

@@ -479,6 +479,22 @@ def test_field_inputs_deterministic_scatter_is_bit_reproducible_and_agrees(monke
     assert float(z[0].abs().max()) == 0.0 and float(z[1].abs().max()) == 0.0
 
 
+def test_field_inputs_run_kernels_agree_with_the_one_query_at_a_time_kernels():
+    """field_inputs_run_kernel (16 queries of a wave at a time: the forward's default, HAVATAR_FIELD_BWD=runs backward) against
+    field_inputs_kernel at BASELINE config 5's size: X and both gradients equal up to the order the float atomics land in.  The choice is
+    read once per process: tools/bench_field_inputs.py runs each variant in a child process and prints the differences."""
+    import re
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bench_field_inputs.py")
+    r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    diffs = dict(re.findall(r"^(X|gp|gv)\s+max \|walk - runs\| / max \|walk\| = (\S+)", r.stdout, re.M))
+    assert set(diffs) == {"X", "gp", "gv"}, r.stdout
+    print(r.stdout)
+    assert float(diffs["X"]) <= 1e-5 and float(diffs["gp"]) <= 5e-5 and float(diffs["gv"]) <= 5e-5, diffs
+
+
 def test_composite_forward_and_gradients_match_volume_render_radiance_field():
     """hav_composite_{fwd,bwd} vs utils/nerf_util.py::volume_render_radiance_field under ATen autograd (fp64 = truth): all four maps
     and d/d rf with every output carrying a gradient; S = 64 and a ragged S = 48 / 7; with and without noise and background."""
