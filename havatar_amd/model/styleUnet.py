@@ -700,7 +700,18 @@ class SWGAN_unet(nn.Module, _CondEncoder):
         if not input_is_latent:
             styles = [self.style(s if cond is None else torch.cat([s, cond], dim=-1)) for s in styles]
         if noise is None:
-            noise = [None] * self.num_layers if randomize_noise else [getattr(self.noises, f"noise_{i}") for i in range(self.num_layers)]
+            if randomize_noise and condition_img.is_cuda and not torch.is_grad_enabled():
+                # inference on the device: every layer's fresh noise map from ONE normal_() launch instead of one per layer (the maps are
+                # i.i.d. either way; 12 launches of ~5 us and their boundaries at 512 -> 1024)
+                shapes = [(condition_img.shape[0], 1) + tuple(getattr(self.noises, f"noise_{i}").shape[2:]) for i in range(self.num_layers)]
+                sizes = [s[0] * s[2] * s[3] for s in shapes]
+                flat = condition_img.new_empty(sum(sizes), dtype=torch.float32).normal_()
+                noise, off = [], 0
+                for s, n in zip(shapes, sizes):
+                    noise.append(flat[off:off + n].view(s))
+                    off += n
+            else:
+                noise = [None] * self.num_layers if randomize_noise else [getattr(self.noises, f"noise_{i}") for i in range(self.num_layers)]
         if truncation < 1:
             styles = [truncation_latent + truncation * (s - truncation_latent) for s in styles]
         latent = _mix_latents(styles, self.n_latent, inject_index)
