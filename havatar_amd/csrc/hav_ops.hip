@@ -1529,6 +1529,121 @@ __global__ void __launch_bounds__(256) haar_idwt_kernel(float* __restrict__ out,
     }
 }
 
+// The wavelet-domain skip path of ToRGB (model/styleUnet.py:476-480: skip = dwt(upsample(iwt(skip)))) as ONE pass: synthesis, x2 up-sampling with
+// the 4x4 FIR (pad (2, 1)) and analysis, [B,4C,H,W] -> [B,4C,2H,2W].  A thread produces 4 output columns of one (plane, row) in all four bands:
+// it rebuilds the 3 x 6 synthesised pixels around them from 2 x 4 input pixels of each band (hav_haar_idwt's arithmetic: one rounded product
+// per band, summed ((ll + lh) + hl) + hh), the 2 x 8 up-sampled pixels from those (the up-sampling kernels' FMA chain over the real taps, i then
+// j ascending, zeros outside the image) and the four band values of each output from their 2 x 2 block (hav_haar_dwt's FMA chain): the three
+// stages' results, operation for operation -- bit-identical to the three-launch sequence (16 -> 5 launches per SWGAN_unet forward).
+__global__ void __launch_bounds__(256) haar_up2_kernel(float* __restrict__ out, const float* __restrict__ in, const float* __restrict__ ki,
+                                                       const float* __restrict__ fir, const float* __restrict__ kd, int B, int C, int H, int W)
+{
+    const int OH = 2 * H, OW = 2 * W, OW4 = OW >> 2, IH = 2 * H, IW = 2 * W;          // output and synthesised-image sizes (both 2H x 2W)
+    const int64_t total = (int64_t)B * C * OH * OW4;
+    float ks[16], kf[16], ka[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { ks[q] = ki[q]; ka[q] = kd[q]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) kf[i * 4 + j] = fir[(3 - i) * 4 + (3 - j)];          // flipped FIR (upfirdn2d_kernel.cu:136-137)
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int x4 = (int)(idx % OW4);
+        int64_t t = idx / OW4;
+        const int Y = (int)(t % OH);
+        const int64_t n = t / OH;
+        const int64_t b = n / C, c = n - b * C;
+        const int X0 = 4 * x4;
+        // input pixels: rows (Y - 1) >> 1 and + 1, columns X0 / 2 - 1 .. X0 / 2 + 2, four bands
+        const int ra = (Y - 1) >> 1, ca = (X0 >> 1) - 1;
+        float v[4][2][4];
+#pragma unroll
+        for (int band = 0; band < 4; ++band) {
+            const float* pl = in + (((b * 4 + band) * C + c) * (int64_t)H) * W;
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int iy = ra + r, ix = ca + q;
+                    v[band][r][q] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? pl[(int64_t)iy * W + ix] : 0.f;
+                }
+        }
+        // synthesised image I[Y - 1 + a][X0 - 1 + e], a = 0..2, e = 0..5 (zero outside)
+        float I[3][6];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int e = 0; e < 6; ++e) {
+                const int y = Y - 1 + a, x = X0 - 1 + e;
+                const int r = (y >> 1) - ra, q = (x >> 1) - ca, ry = y & 1, rx = x & 1;
+                float s;
+                // (r, q, ry, rx depend on the parities of Y only through y: resolved per thread; the selects below keep the indexing static)
+                const float v0 = r == 0 ? (q == 0 ? v[0][0][0] : q == 1 ? v[0][0][1] : q == 2 ? v[0][0][2] : v[0][0][3]) : (q == 0 ? v[0][1][0] : q == 1 ? v[0][1][1] : q == 2 ? v[0][1][2] : v[0][1][3]);
+                const float v1 = r == 0 ? (q == 0 ? v[1][0][0] : q == 1 ? v[1][0][1] : q == 2 ? v[1][0][2] : v[1][0][3]) : (q == 0 ? v[1][1][0] : q == 1 ? v[1][1][1] : q == 2 ? v[1][1][2] : v[1][1][3]);
+                const float v2 = r == 0 ? (q == 0 ? v[2][0][0] : q == 1 ? v[2][0][1] : q == 2 ? v[2][0][2] : v[2][0][3]) : (q == 0 ? v[2][1][0] : q == 1 ? v[2][1][1] : q == 2 ? v[2][1][2] : v[2][1][3]);
+                const float v3 = r == 0 ? (q == 0 ? v[3][0][0] : q == 1 ? v[3][0][1] : q == 2 ? v[3][0][2] : v[3][0][3]) : (q == 0 ? v[3][1][0] : q == 1 ? v[3][1][1] : q == 2 ? v[3][1][2] : v[3][1][3]);
+                const int kq = 2 * ry + rx;
+                const float k0 = kq == 0 ? ks[0] : kq == 1 ? ks[1] : kq == 2 ? ks[2] : ks[3];
+                const float k1 = kq == 0 ? ks[4] : kq == 1 ? ks[5] : kq == 2 ? ks[6] : ks[7];
+                const float k2 = kq == 0 ? ks[8] : kq == 1 ? ks[9] : kq == 2 ? ks[10] : ks[11];
+                const float k3 = kq == 0 ? ks[12] : kq == 1 ? ks[13] : kq == 2 ? ks[14] : ks[15];
+                s = mul_rn(v0, k0);
+                s = add_rn(s, mul_rn(v1, k1));
+                s = add_rn(s, mul_rn(v2, k2));
+                s = add_rn(s, mul_rn(v3, k3));
+                I[a][e] = (y >= 0 && y < IH && x >= 0 && x < IW) ? s : 0.f;
+            }
+        // up-sampled pixels U[2Y + q][2 X0 + p]: row taps i with q + i even on I row Y - 1 + (q + i) / 2, column taps j with p + j even on
+        // I column X0 - 1 + (p + j) / 2 (pad 2: the zero-stuffed coordinate of tap i of row 2Y + q is 2Y + q + i - 2)
+        float U[2][8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if ((q + i) & 1) continue;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if ((p + j) & 1) continue;
+                        acc = fmaf(I[(q + i) >> 1][(p + j) >> 1], kf[i * 4 + j], acc);
+                    }
+                }
+                U[q][p] = acc;
+            }
+        // analysis: band value of output (Y, X0 + t) from U[0..1][2t..2t+1], taps (i, j) with the flipped 2x2 kernel
+#pragma unroll
+        for (int band = 0; band < 4; ++band) {
+            const float* kb = ka + 4 * band;
+            float o[4];
+#pragma unroll
+            for (int tq = 0; tq < 4; ++tq) {
+                float w = fmaf(U[0][2 * tq], kb[3], 0.f);
+                w = fmaf(U[0][2 * tq + 1], kb[2], w);
+                w = fmaf(U[1][2 * tq], kb[1], w);
+                w = fmaf(U[1][2 * tq + 1], kb[0], w);
+                o[tq] = w;
+            }
+            float* dst = out + ((((b * 4 + band) * C + c) * OH + Y) * (int64_t)OW) + X0;
+            *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+extern "C" int hav_haar_up2(float* out, const float* in, const float* ki4x2x2, const float* fir4x4, const float* kd4x2x2, int B, int C, int H, int W,
+                            void* stream)
+{
+    if (!out || !in || !ki4x2x2 || !fir4x4 || !kd4x2x2 || B < 1 || C < 1 || H < 1 || W < 1) return HAV_EINVAL;
+    if ((W & 1) || (((uintptr_t)out) & 15)) return HAV_EUNSUP;
+    const int64_t total = (int64_t)B * C * (2 * H) * (W / 2);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > (int64_t)hav_num_cus() * 32) blocks = (int64_t)hav_num_cus() * 32;
+    hipLaunchKernelGGL(haar_up2_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, in, ki4x2x2, fir4x4, kd4x2x2, B, C, H, W);
+    HAV_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int hav_haar_dwt(float* out, const float* in, const float* k4x2x2, int B, int C, int H, int W, void* stream)
 {
     if (!out || !in || !k4x2x2 || B < 1 || C < 1 || H < 2 || W < 2) return HAV_EINVAL;

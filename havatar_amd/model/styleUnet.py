@@ -475,7 +475,13 @@ class ToRGB(nn.Module):
 
     def forward(self, input, style, skip=None):
         if skip is not None:
-            skip = self.dwt(self.upsample(self.iwt(skip))) if self.use_wt else self.upsample(skip)
+            up = None
+            if (self.use_wt and skip.is_cuda and skip.dtype == torch.float32 and not torch.is_grad_enabled() and _fused_haar_enabled()
+                    and self.upsample.factor == 2 and tuple(self.upsample.pad) == (2, 1)):
+                from ..native import fused           # HIP inference: synthesis, x2 FIR up-sampling and analysis as one pass (hav_haar_up2), same bits
+                up = fused.haar_up2(skip, _haar_bank(self.iwt, (self.iwt.ll, self.iwt.lh, self.iwt.hl, self.iwt.hh)), self.upsample.kernel,
+                                    _haar_bank(self.dwt, (self.dwt.ll, self.dwt.lh, self.dwt.hl, self.dwt.hh)))
+            skip = up if up is not None else (self.dwt(self.upsample(self.iwt(skip))) if self.use_wt else self.upsample(skip))
         if self.conv._hip_inference(input) and os.environ.get("HAVATAR_FUSED_TORGB", "1") != "0":
             # HIP inference: modulation, the 1x1 convolution, bias and skip add in one pass over the activations (hav_torgb) instead of
             # x * s, MIOpen's GEMM between NHWC transposes, and two adds

@@ -202,3 +202,22 @@ def haar(x, k4, inverse=False):
                 C.c_void_p(torch.cuda.current_stream().cuda_stream))
     _lib.check(rc, "hav_haar")
     return out
+
+
+def haar_up2(x, ki4, fir, kd4):
+    """dwt(upsample(iwt(x))) of ToRGB's skip path (model/styleUnet.py:476-480) as one launch (hav_haar_up2): x [B,12,H,W] -> [B,12,2H,2W],
+    bit-identical to haar(inverse) -> upfirdn2d(up 2, pad (2, 1)) -> haar.  ki4 / kd4 [4,2,2]: the synthesis / analysis kernels, fir [4,4]:
+    Upsample's kernel.  Returns None when the shape is not taken (caller falls back)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and tuple(fir.shape) == (4, 4)):
+        return None
+    B, Cc, H, W = x.shape
+    if Cc % 4 or W % 2:
+        return None
+    x = x.contiguous()
+    out = torch.empty(B, Cc, 2 * H, 2 * W, device=x.device, dtype=torch.float32)
+    ki4, kd4, fir = _f32c(ki4, "ki4"), _f32c(kd4, "kd4"), _f32c(fir, "fir")
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().hav_haar_up2(C.c_void_p(out.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(ki4.data_ptr()), C.c_void_p(fir.data_ptr()),
+                                     C.c_void_p(kd4.data_ptr()), B, Cc // 4, H, W, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, "hav_haar_up2")
+    return out

@@ -282,6 +282,11 @@ int hav_upconv_finish(float* y, const float* col, const float* fir4x4, const flo
  * k4x2x2: the four 2x2 kernels exactly as the upfirdn2d calls receive them (the synthesis takes ll, -lh, -hl, hh). */
 int hav_haar_dwt(float* out, const float* in, const float* k4x2x2, int B, int C, int H, int W, void* stream);
 int hav_haar_idwt(float* out, const float* in, const float* k4x2x2, int B, int C, int H, int W, void* stream);
+/* The skip path of ToRGB, `skip = dwt(upsample(iwt(skip)))` (model/styleUnet.py:476-480: InverseHaarTransform -> Upsample (4x4 FIR, up 2,
+ * pad (2, 1)) -> HaarTransform), as one pass: in [B,4C,H,W] -> out [B,4C,2H,2W], bit-identical to hav_haar_idwt -> hav_upfirdn2d -> hav_haar_dwt.
+ * ki4x2x2 / kd4x2x2: the synthesis / analysis kernels as the two calls above receive them; fir4x4: Upsample's kernel (gain folded in).  W even. */
+int hav_haar_up2(float* out, const float* in, const float* ki4x2x2, const float* fir4x4, const float* kd4x2x2, int B, int C, int H, int W,
+                 void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Trilinear x2 up-sampling of a [N,C,D,H,W] float32 volume and its adjoint -- nn.Upsample(scale_factor=2, mode='trilinear',

@@ -196,6 +196,31 @@ def test_upfirdn2d_row_streaming_kernels_are_bit_identical_to_the_tiled_ones(cas
         L.hav_lab_upfirdn2d(1, 0)
 
 
+def test_haar_up2_equals_the_three_stage_skip_path_bit_for_bit():
+    """hav_haar_up2 (ToRGB's skip path dwt(upsample(iwt(skip))) as one pass, reference model/styleUnet.py:476-480) against the three-stage
+    sequence on this library's kernels (each pinned to the reference's upfirdn2d calls elsewhere in this file) and against the plain
+    upfirdn2d statement of the reference: same bits; ragged and tiny maps, B = 2."""
+    from havatar_amd.model.styleUnet import HaarTransform, InverseHaarTransform, Upsample, _haar_bank
+    from havatar_amd.model.op import upfirdn2d
+    from havatar_amd.native import fused
+    iwt, up, dwt = InverseHaarTransform(3).to(DEV), Upsample((1, 3, 3, 1)).to(DEV), HaarTransform(3).to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    for B, H, W in ((1, 256, 256), (2, 48, 40), (1, 5, 6), (1, 1, 2), (2, 33, 64)):
+        x = torch.randn(B, 12, H, W, device=DEV, generator=g)
+        with torch.no_grad():
+            ref = dwt(up(iwt(x)))
+            # the reference's own statement: four up-sampling calls + adds, Upsample, four decimating calls + cat
+            ll, lh, hl, hh = x.chunk(4, 1)
+            i_ref = upfirdn2d(ll, iwt.ll, up=2, pad=(1, 0, 1, 0)) + upfirdn2d(lh, iwt.lh, up=2, pad=(1, 0, 1, 0)) \
+                + upfirdn2d(hl, iwt.hl, up=2, pad=(1, 0, 1, 0)) + upfirdn2d(hh, iwt.hh, up=2, pad=(1, 0, 1, 0))
+            u_ref = upfirdn2d(i_ref, up.kernel, up=2, down=1, pad=up.pad)
+            ref2 = torch.cat([upfirdn2d(u_ref, k, down=2) for k in (dwt.ll, dwt.lh, dwt.hl, dwt.hh)], 1)
+        got = fused.haar_up2(x, _haar_bank(iwt, (iwt.ll, iwt.lh, iwt.hl, iwt.hh)), up.kernel, _haar_bank(dwt, (dwt.ll, dwt.lh, dwt.hl, dwt.hh)))
+        assert got is not None and got.shape == ref.shape == (B, 12, 2 * H, 2 * W)
+        assert torch.equal(got, ref), (B, H, W, float((got - ref).abs().max()))
+        assert torch.equal(got, ref2), (B, H, W, float((got - ref2).abs().max()))
+
+
 def test_upfirdn2d_half_precisions_and_errors():
     from oracle import oracle
     from havatar_amd.native import upfirdn2d as op
