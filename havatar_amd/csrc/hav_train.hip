@@ -23,6 +23,24 @@ __device__ __forceinline__ float wsum64(float v)
     return v;
 }
 
+// the same sum over the 64 lanes on the vector pipe: quad swaps, half-row and row mirrors (DPP), then the four row sums read out of lanes
+// 0 / 16 / 32 / 48 -- 4 + 7 vector instructions instead of 6 trips through the LDS crossbar; every lane gets the same value
+// (a different association of the 64 terms than wsum64's butterfly)
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v)
+{
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wsum64_dpp(float v)
+{
+    v = dpp_add<0xB1>(v);           // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);           // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);          // row_half_mirror
+    v = dpp_add<0x140>(v);          // row_mirror
+    const int b = __float_as_int(v);
+    return (__int_as_float(__builtin_amdgcn_readlane(b, 0)) + __int_as_float(__builtin_amdgcn_readlane(b, 16)))
+         + (__int_as_float(__builtin_amdgcn_readlane(b, 32)) + __int_as_float(__builtin_amdgcn_readlane(b, 48)));
+}
+
 struct FieldArgs {
     float* X;
     const float* dX;
@@ -97,6 +115,9 @@ __global__ void __launch_bounds__(256) field_inputs_kernel(FieldArgs a)
     int wkey[2][4] = {{-1, -1, -1, -1}, {-1, -1, -1, -1}};
     float wacc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     long long facc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};          // (MODE 4)
+    // MODE 2: this lane's pending volume tap -- consecutive samples of a ray fall into the same cell of the 64^3 volume about twice in a
+    // row (the same 8 corners in the same lanes): their contributions are summed here and leave as one atomic when the corner changes
+    long long vkey = -1; float vacc = 0.f;
     for (int qi = 0; qi < RUN; ++qi) {
         const int64_t i = run * RUN + qi;
         if (i >= a.n) break;
@@ -218,7 +239,7 @@ __global__ void __launch_bounds__(256) field_inputs_kernel(FieldArgs a)
                 const float ge = a.dX[i * XW + 2 * C + lane] * freq * cosf(arg);
                 if (j == 0) dx += ge; else if (j == 1) dy += ge; else dz += ge;
             }
-            dx = wsum64(dx); dy = wsum64(dy); dz = wsum64(dz);
+            dx = wsum64_dpp(dx); dy = wsum64_dpp(dy); dz = wsum64_dpp(dz);
             // p' = h0 p0 + h1 p1, h_i = w_i / s: d/dw_i = (d/dh_i - sum_j d/dh_j h_j) / s
             const float dh0 = dx * px + dy * py + dz * pz, dh1 = dx * p1x + dy * p1y + dz * p1z;
             const float mix = dh0 * h0 + dh1 * h1;
@@ -230,9 +251,18 @@ __global__ void __launch_bounds__(256) field_inputs_kernel(FieldArgs a)
                     a.vidx32[i * 16 + lane] = vin ? (int)vidx : -1;
                     vmax_w = fmaxf(vmax_w, fabsf(cv));
                 }
+            } else if (MODE == 2) {
+                const float cv = vin ? tw * dw : 0.f;
+                const long long key = vin ? (long long)vidx : -1;
+                if (key == vkey) vacc += cv;
+                else {
+                    if (vkey >= 0 && vacc != 0.f) atomicAdd(a.dvol + vkey, vacc);
+                    vkey = key; vacc = cv;
+                }
             } else if (vin && tw * dw != 0.f) atomicAdd(a.dvol + vidx, tw * dw);   // clamped (border) coordinates: half the taps weigh 0
         }
     }
+    if (MODE == 2 && a.dvol && vkey >= 0 && vacc != 0.f) atomicAdd(a.dvol + vkey, vacc);
     if (MODE == 2 && a.dplanes) {          // end of the run: whatever is still in the windows
 #pragma unroll
         for (int p = 0; p < 2; ++p)
@@ -413,7 +443,7 @@ __global__ void __launch_bounds__(256) field_inputs_run_kernel(FieldArgs a)
                         const float ge = gpe[qq] * freq * cosf(arg);
                         if (j == 0) dx += ge; else if (j == 1) dy += ge; else dz += ge;
                     }
-                    dx = wsum64(dx); dy = wsum64(dy); dz = wsum64(dz);
+                    dx = wsum64_dpp(dx); dy = wsum64_dpp(dy); dz = wsum64_dpp(dz);
                     if (ql == q) { dxs = dx; dys = dy; dzs = dz; }
                 }
             }
