@@ -138,10 +138,14 @@ struct TrainCtx {
     int lane, j, h;
 };
 
-// gfx950 / ROCm 7.2: v_mfma_f32_32x32x16_* keeps reading its A/B registers after issue and the compiler may let the next VALU
-// instruction recycle them (hav_render.hip, docs/history/DESIGN_r1-r4.md 3.5).  Every batch of MFMAs here ends with FENCE: 32 wait states with the
-// operand registers still live, before any code that builds the next operands can run.
-#define MFMA_FENCE(accv) asm volatile("s_nop 15\n\ts_nop 15" : "+v"(accv))
+// Rounds 1-2 ended every batch of MFMAs with 32 wait states, on the belief that v_mfma_f32_32x32x16_* keeps reading its A/B registers after
+// issue; tools/ubench/mfma_war.hip showed that gfx950 does not (docs/history/DESIGN_r1-r4.md 3.5, retracted in round 3), hav_render.hip and
+// hav_conv.hip dropped their pads then.  The statement stays as a scheduling fence that ties the accumulators (nothing that builds the next
+// operands is moved in front of the batch); -DMLP_MFMA_PAD='"s_nop 15\n\ts_nop 15"' brings the wait states back.
+#ifndef MLP_MFMA_PAD
+#define MLP_MFMA_PAD ""
+#endif
+#define MFMA_FENCE(accv) asm volatile(MLP_MFMA_PAD : "+v"(accv))
 #define KEEP_ALIVE(frag_) asm volatile("" : : "v"((frag_).x), "v"((frag_).w))
 
 // acc[m] += sum over NCH k chunks of  (SWAP ? op(c) . ld(c, m) : ld(c, m) . op(c)):  ld = a weight fragment from memory, op = a register
