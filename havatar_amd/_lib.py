@@ -97,6 +97,8 @@ def lib():
     L.hav_triplane_gather_bwd.restype = i32
     L.hav_field_inputs_fwd.argtypes = [vp, C.POINTER(HavFieldParams), vp, vp, vp, vp, vp]
     L.hav_field_inputs_fwd.restype = i32
+    L.hav_field_inputs_fwd_bf16.argtypes = [vp, C.POINTER(HavFieldParams), vp, vp, vp, vp, vp]
+    L.hav_field_inputs_fwd_bf16.restype = i32
     L.hav_field_inputs_bwd.argtypes = [vp, vp, vp, C.POINTER(HavFieldParams), vp, vp, vp, vp, vp]
     L.hav_field_inputs_bwd.restype = i32
     L.hav_field_inputs_bwd_fixed.argtypes = [vp, vp, vp, vp, vp, C.POINTER(HavFieldParams), vp, vp, vp, vp, vp]
@@ -170,6 +172,10 @@ def lib():
     L.hav_mlp_train_fwd.restype = i32
     L.hav_mlp_train_bwd.argtypes = [vp, C.POINTER(HavMlpGrads), i32, vp, vp, vp, vp, vp, i64, vp]
     L.hav_mlp_train_bwd.restype = i32
+    L.hav_mlp_train_fwd_xbf16.argtypes = [vp, vp, vp, i64, vp]
+    L.hav_mlp_train_fwd_xbf16.restype = i32
+    L.hav_mlp_train_bwd_xbf16.argtypes = [vp, C.POINTER(HavMlpGrads), i32, vp, vp, vp, vp, vp, i64, vp]
+    L.hav_mlp_train_bwd_xbf16.restype = i32
     L.hav_triplane_prepare.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
     L.hav_triplane_prepare.restype = i32
     L.hav_triplane_prepared_bytes.argtypes = [i32, i32, i32]

@@ -240,6 +240,14 @@ __device__ __forceinline__ void load_x_frags(const float* __restrict__ X, long l
         xf[c] = make_uint4(pk_bf16(a.x, a.y), pk_bf16(a.z, a.w), pk_bf16(b.x, b.y), pk_bf16(b.z, b.w));
     }
 }
+// the same from rows that already are bf16 ([n,176] bf16 = what hav_field_inputs_fwd_bf16 writes: the fp32 values rounded the way pk_bf16
+// rounds them, so the fragments -- and everything computed from them -- have the same bits either way)
+__device__ __forceinline__ void load_x_frags_b(const void* __restrict__ X, long long q, bool valid, int h, uint4 (&xf)[11])
+{
+    const unsigned short* xr = (const unsigned short*)X + q * T_IN + 8 * h;
+#pragma unroll
+    for (int c = 0; c < 11; ++c) xf[c] = valid ? *reinterpret_cast<const uint4*>(xr + 16 * c) : make_uint4(0u, 0u, 0u, 0u);
+}
 // layers 1 and 2 in the T orientation: h1f, h2f = bf16 fragments of relu(h1), relu(h2); acc2 = pre-activation of layer 2 (for the heads)
 __device__ __forceinline__ void forward_T(const TrainCtx& C, const uint4 (&xf)[11], uint4 (&h1f)[8], uint4 (&h2f)[8], f32x16 (&acc)[4])
 {
@@ -254,6 +262,7 @@ __device__ __forceinline__ void forward_T(const TrainCtx& C, const uint4 (&xf)[1
 // ------------------------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------------------------
+template <bool XB>          // XB: X rows are bf16
 __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(float* __restrict__ rf, const float* __restrict__ X, const uint4* __restrict__ fragp,
                                                          const float* __restrict__ vec_in, long long n, int ntiles)
 {
@@ -273,7 +282,7 @@ __global__ void __launch_bounds__(256, 2) mlp_fwd_kernel(float* __restrict__ rf,
         const bool valid = q < n;
         uint4 xf[11], h1f[8], h2f[8];
         f32x16 acc[4];
-        load_x_frags(X, q, valid, h, xf);
+        if (XB) load_x_frags_b(X, q, valid, h, xf); else load_x_frags(X, q, valid, h, xf);
         forward_T(C, xf, h1f, h2f, acc);
         // alpha = Wa . relu(h2) + ba on the fp32 accumulators (each lane holds 64 of its query's 128 units)
         float al = 0.f;
@@ -324,6 +333,7 @@ __device__ __forceinline__ void store_n_tile(uint4* __restrict__ ops, int t, int
     dst[64] = make_uint4(pk_bf16(d[8], d[9]), pk_bf16(d[10], d[11]), pk_bf16(d[12], d[13]), pk_bf16(d[14], d[15]));
 }
 
+template <bool XB>
 __global__ void __launch_bounds__(256) mlp_bwd_data_kernel(float* __restrict__ dX, uint4* __restrict__ ops, const float* __restrict__ X,
                                                               const float* __restrict__ d_rf, const uint4* __restrict__ fragp,
                                                               const float* __restrict__ vec_in, long long n, int ntiles)
@@ -351,7 +361,7 @@ __global__ void __launch_bounds__(256) mlp_bwd_data_kernel(float* __restrict__ d
         uint32_t m1n[2], m2n[2];          // relu masks of the N-orientation tiles, 16 bits per tile
         {
             f32x16 acc[4];
-            load_x_frags(X, q, valid, h, xf);
+            if (XB) load_x_frags_b(X, q, valid, h, xf); else load_x_frags(X, q, valid, h, xf);
             forward_T(C, xf, h1f, h2f, acc);
         }
         // ---- N orientation of the forward quantities: operands swapped, lane = unit ---------------------------------------
@@ -609,21 +619,24 @@ static int tile_grid(int ntiles, int waves_per_block, int blocks_per_cu)
     return need < cap ? (need < 1 ? 1 : need) : cap;
 }
 
-extern "C" int hav_mlp_train_fwd(float* rf, const float* X, const void* blob, int64_t n, void* stream)
+static int mlp_train_fwd_any(float* rf, const void* X, bool xb, const void* blob, int64_t n, void* stream)
 {
     if (!rf || !X || !blob || n < 0) return HAV_EINVAL;
     if (n == 0) return 0;
     const int64_t nt = (n + 31) / 32;
     if (nt > 0x7FFFFFFF) return HAV_EUNSUP;
-    hipLaunchKernelGGL(mlp_fwd_kernel, dim3(tile_grid((int)nt, 4, 4)), dim3(256), 0, (hipStream_t)stream, rf, X, (const uint4*)blob,
-                       (const float*)((const char*)blob + (size_t)TF_END * 16), (long long)n, (int)nt);
+    const float* vec = (const float*)((const char*)blob + (size_t)TF_END * 16);
+    if (xb) hipLaunchKernelGGL(mlp_fwd_kernel<true>, dim3(tile_grid((int)nt, 4, 4)), dim3(256), 0, (hipStream_t)stream, rf, (const float*)X, (const uint4*)blob, vec, (long long)n, (int)nt);
+    else hipLaunchKernelGGL(mlp_fwd_kernel<false>, dim3(tile_grid((int)nt, 4, 4)), dim3(256), 0, (hipStream_t)stream, rf, (const float*)X, (const uint4*)blob, vec, (long long)n, (int)nt);
     HAV_LAUNCH_CHECK();
     return 0;
 }
-
-extern "C" int hav_mlp_train_bwd(float* dX, const HavMlpGrads* grads, int accumulate, const float* X, const float* d_rf, const void* blob,
-                                 void* ops, void* partial, int64_t n, void* stream)
+extern "C" int hav_mlp_train_fwd(float* rf, const float* X, const void* blob, int64_t n, void* stream) { return mlp_train_fwd_any(rf, X, false, blob, n, stream); }
+extern "C" int hav_mlp_train_fwd_xbf16(float* rf, const void* Xb, const void* blob, int64_t n, void* stream) { return mlp_train_fwd_any(rf, Xb, true, blob, n, stream); }
+static int mlp_train_bwd_any(float* dX, const HavMlpGrads* grads, int accumulate, const void* X_, bool xb, const float* d_rf, const void* blob,
+                             void* ops, void* partial, int64_t n, void* stream)
 {
+    const float* X = (const float*)X_;
     if (!grads || !X || !d_rf || !blob || !ops || !partial || n < 0) return HAV_EINVAL;
     if (!grads->W1 || !grads->b1 || !grads->W2 || !grads->b2 || !grads->Wa || !grads->ba || !grads->Wf || !grads->bf || !grads->Wc || !grads->bc)
         return HAV_EINVAL;
@@ -632,8 +645,8 @@ extern "C" int hav_mlp_train_bwd(float* dX, const HavMlpGrads* grads, int accumu
     if (nt > 0x7FFFFFFF) return HAV_EUNSUP;
     hipStream_t st = (hipStream_t)stream;
     const float* vec = (const float*)((const char*)blob + (size_t)TF_END * 16);
-    hipLaunchKernelGGL(mlp_bwd_data_kernel, dim3(tile_grid((int)nt, 4, 1)), dim3(256), 0, st, dX, (uint4*)ops, X, d_rf, (const uint4*)blob, vec,
-                       (long long)n, (int)nt);
+    if (xb) hipLaunchKernelGGL(mlp_bwd_data_kernel<true>, dim3(tile_grid((int)nt, 4, 1)), dim3(256), 0, st, dX, (uint4*)ops, X, d_rf, (const uint4*)blob, vec, (long long)n, (int)nt);
+    else hipLaunchKernelGGL(mlp_bwd_data_kernel<false>, dim3(tile_grid((int)nt, 4, 1)), dim3(256), 0, st, dX, (uint4*)ops, X, d_rf, (const uint4*)blob, vec, (long long)n, (int)nt);
     HAV_LAUNCH_CHECK();
     const int slices = weight_slices(nt);
     hipLaunchKernelGGL(mlp_bwd_weights_kernel, dim3(slices, N_ROLES), dim3(64), 0, st, (float*)partial, (const uint4*)ops, (int)nt, slices);
@@ -643,4 +656,14 @@ extern "C" int hav_mlp_train_bwd(float* dX, const HavMlpGrads* grads, int accumu
     hipLaunchKernelGGL(mlp_reduce_kernel, dim3((G_END + 255) / 256), dim3(256), 0, st, g, (const float*)partial, slices, accumulate);
     HAV_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int hav_mlp_train_bwd(float* dX, const HavMlpGrads* grads, int accumulate, const float* X, const float* d_rf, const void* blob,
+                                 void* ops, void* partial, int64_t n, void* stream)
+{
+    return mlp_train_bwd_any(dX, grads, accumulate, X, false, d_rf, blob, ops, partial, n, stream);
+}
+extern "C" int hav_mlp_train_bwd_xbf16(float* dX, const HavMlpGrads* grads, int accumulate, const void* Xb, const float* d_rf, const void* blob,
+                                       void* ops, void* partial, int64_t n, void* stream)
+{
+    return mlp_train_bwd_any(dX, grads, accumulate, Xb, true, d_rf, blob, ops, partial, n, stream);
 }

@@ -43,6 +43,7 @@ __device__ __forceinline__ float wsum64_dpp(float v)
 
 struct FieldArgs {
     float* X;
+    unsigned short* Xb;          // MODE 0 of the run kernel: bf16 rows instead of X (hav_field_inputs_fwd_bf16)
     const float* dX;
     float* dplanes;
     float* dvol;
@@ -435,8 +436,17 @@ __global__ void __launch_bounds__(256) field_inputs_run_kernel(FieldArgs a)
                 const float coord = j == 0 ? rxq : (j == 1 ? ryq : rzq);
                 const float arg = r6 >= 3 ? coord * freq + 1.57079632679489661923f : coord * freq;
                 if (MODE == 0) {
-                    if (con) *reinterpret_cast<float2*>(a.X + i * XW + 2 * lane) = make_float2(xo[0], xo[1]);
-                    if (pe_on) a.X[i * XW + 2 * C + lane] = sinf(arg);
+                    if (a.Xb) {          // bf16 rows, rounded as the MLP kernels round fp32 rows (v_cvt_pk_bf16_f32: nearest even)
+                        typedef float f2v __attribute__((ext_vector_type(2)));
+                        typedef __bf16 b2v __attribute__((ext_vector_type(2)));
+                        const f2v pr = {xo[0], xo[1]};
+                        if (con) reinterpret_cast<unsigned int*>(a.Xb + i * XW)[lane] = __builtin_bit_cast(unsigned int, __builtin_convertvector(pr, b2v));
+                        const f2v ps = {sinf(arg), 0.f};
+                        if (pe_on) a.Xb[i * XW + 2 * C + lane] = (unsigned short)(__builtin_bit_cast(unsigned int, __builtin_convertvector(ps, b2v)) & 0xFFFFu);
+                    } else {
+                        if (con) *reinterpret_cast<float2*>(a.X + i * XW + 2 * lane) = make_float2(xo[0], xo[1]);
+                        if (pe_on) a.X[i * XW + 2 * C + lane] = sinf(arg);
+                    }
                 } else if (a.dvol) {
                     float dx = dqx * (0.5f * (float)(W - 1)) * a.bs[0], dy = dqy * (0.5f * (float)(H - 1)) * a.bs[1], dz = dqz * (0.5f * (float)(W - 1)) * a.bs[2];
                     if (pe_on) {
@@ -530,6 +540,22 @@ extern "C" int hav_field_inputs_fwd(float* X, const HavFieldParams* p, const flo
         hipLaunchKernelGGL(field_inputs_run_kernel<0>, dim3(field_blocks((p->n + FR_RUN - 1) / FR_RUN)), dim3(256), 0, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL(field_inputs_kernel<0>, dim3(field_blocks(p->n)), dim3(256), 0, (hipStream_t)stream, a);
+    HAV_LAUNCH_CHECK();
+    return 0;
+}
+
+// X as bf16 rows [n, 2C+48] for hav_mlp_train_*_xbf16 (the MLP rounds fp32 rows to bf16 itself: same operands, half the bytes written here
+// and read there twice).  C <= 64 (the run kernel).
+extern "C" int hav_field_inputs_fwd_bf16(void* Xb, const HavFieldParams* p, const float* pts, const float* inv_T, const float* vol,
+                                         const float* planes_cl, void* stream)
+{
+    int rc = field_check(p, pts, inv_T, vol, planes_cl);
+    if (rc || !Xb) return rc ? rc : HAV_EINVAL;
+    if (p->C > 64 || (p->C & 1)) return HAV_EUNSUP;
+    if (p->n == 0) return 0;
+    FieldArgs a = field_args(p, pts, inv_T, vol, planes_cl);
+    a.Xb = (unsigned short*)Xb;
+    hipLaunchKernelGGL(field_inputs_run_kernel<0>, dim3(field_blocks((p->n + FR_RUN - 1) / FR_RUN)), dim3(256), 0, (hipStream_t)stream, a);
     HAV_LAUNCH_CHECK();
     return 0;
 }

@@ -164,7 +164,7 @@ class Trainer(torch.nn.Module):
         fused = (ro.is_cuda and ro.dtype == torch.float32 and max(opt.num_coarse, opt.num_coarse // 2 + opt.num_coarse % 2 + opt.num_fine) <= 64
                  and self.model_coarse.sh_deg == 0 and os.environ.get("HAVATAR_HIP_TRAIN", "1") != "0")
         if fused:
-            from ..native.train_ops import composite, field_inputs
+            from ..native.train_ops import composite, field_inputs, field_mlp, field_mlp_eligible
             gw, sw = self.model_coarse.gridwarper, self.headpose_skin_net.gridwarper
             if getattr(self, "_boxes", None) is None:
                 f = lambda t: t.detach().reshape(3).cpu().tolist()
@@ -174,8 +174,15 @@ class Trainer(torch.nn.Module):
 
         def one_pass_hip(zv):
             pts = (ro[..., None, :] + rd[..., None, :] * zv[..., :, None]).reshape(B, -1, 3)
-            X = field_inputs(pts, inv_head_T, vol, planes, *self._boxes)
-            rf = self.model_coarse.mlp(X).reshape(B * R, zv.shape[-1], -1).float()      # (bf16 under autocast: the compositing is fp32)
+            mc = self.model_coarse
+            ws = mc.mlp_tensors() if (torch.is_grad_enabled() and pts.shape[0] * pts.shape[1] >= 1024 and mc.sh_deg == 0
+                                      and os.environ.get("HAVATAR_TRAIN_MLP", "bf16") == "bf16" and os.environ.get("HAVATAR_FIELD_MLP", "1") != "0") else None
+            if ws is not None and field_mlp_eligible(planes, ws):
+                # field inputs + bf16-MFMA radiance MLP as one autograd node with bf16 rows in between (native/train_ops.py::FieldMlp)
+                rf = field_mlp(pts, inv_head_T, vol, planes, *self._boxes, ws).reshape(B * R, zv.shape[-1], -1)
+            else:
+                X = field_inputs(pts, inv_head_T, vol, planes, *self._boxes)
+                rf = mc.mlp(X).reshape(B * R, zv.shape[-1], -1).float()      # (bf16 under autocast: the compositing is fp32)
             std = float(opt.radiance_field_noise_std)
             noise = torch.randn(rf.shape[:-1], dtype=rf.dtype, device=rf.device) * std if std > 0.0 else None     # same draw as :56
             rgb, acc, w, depth = composite(rf, zv.reshape(-1, zv.shape[-1]), rd.reshape(-1, 3), noise, bg, n_sigmoid=3)

@@ -43,24 +43,26 @@ def pack(weights):
 
 
 def forward_only(X, blob):
+    """X [n,176] float32, or bfloat16 rows as hav_field_inputs_fwd_bf16 writes them (same results: the kernel rounds fp32 rows to bf16 itself)"""
     n = X.shape[0]
     rf = torch.empty(n, 68, dtype=torch.float32, device=X.device)
+    fn = _lib.lib().hav_mlp_train_fwd_xbf16 if X.dtype == torch.bfloat16 else _lib.lib().hav_mlp_train_fwd
     with torch.cuda.device(X.device):
-        _lib.check(_lib.lib().hav_mlp_train_fwd(_p(rf), _p(X), _p(blob), n, _stream()), "hav_mlp_train_fwd")
+        _lib.check(fn(_p(rf), _p(X), _p(blob), n, _stream()), "hav_mlp_train_fwd")
     return rf
 
 
 def backward_only(X, d_rf, blob, shapes, need_dx=True):
     L = _lib.lib()
     n, dev = X.shape[0], X.device
-    dX = torch.empty_like(X) if need_dx else None
+    dX = torch.empty(X.shape, dtype=torch.float32, device=dev) if need_dx else None
     grads = [torch.empty(s, dtype=torch.float32, device=dev) for s in shapes]
     ops = torch.empty(int(L.hav_mlp_train_ops_bytes(n)), dtype=torch.uint8, device=dev)
     partial = torch.empty(int(L.hav_mlp_train_partial_bytes(n)), dtype=torch.uint8, device=dev)
     hg = _lib.HavMlpGrads(*[g.data_ptr() for g in grads])
     with torch.cuda.device(dev):
-        _lib.check(L.hav_mlp_train_bwd(_p(dX), C.byref(hg), 0, _p(X), _p(d_rf), _p(blob), _p(ops), _p(partial), n, _stream()),
-                   "hav_mlp_train_bwd")
+        fn = L.hav_mlp_train_bwd_xbf16 if X.dtype == torch.bfloat16 else L.hav_mlp_train_bwd
+        _lib.check(fn(_p(dX), C.byref(hg), 0, _p(X), _p(d_rf), _p(blob), _p(ops), _p(partial), n, _stream()), "hav_mlp_train_bwd")
     return dX, grads
 
 

@@ -63,29 +63,79 @@ class FieldInputs(Function):
     @once_differentiable
     def backward(ctx, dX):
         pts, inv_T, vol, planes_cl = ctx.saved_tensors
-        p = _field_params(pts, planes_cl, vol, ctx.boxes)
-        det = deterministic() and p.C <= 64
-        mk = torch.empty_like if det else torch.zeros_like          # (the fixed-point route writes every element itself)
-        dvol = mk(vol) if ctx.needs_input_grad[2] else None
-        dpl = mk(planes_cl) if ctx.needs_input_grad[3] else None
-        if dvol is not None or dpl is not None:
-            dX = dX.contiguous()
-            L = _lib.lib()
-            with torch.cuda.device(pts.device):
-                if det:
-                    # HAVATAR_DETERMINISTIC=1: 64-bit fixed-point sums, integer atomics -- the same bits on every run (the float atomics of
-                    # the default route land in a different order every time)
-                    from .conv import absmax
-                    words = absmax(dX)
-                    scratch = torch.empty(int(L.hav_field_inputs_bwd_fixed_scratch_bytes(C.byref(p))), dtype=torch.uint8, device=pts.device)
-                    rc = L.hav_field_inputs_bwd_fixed(_p(dpl), _p(dvol), _p(dX), _p(words), _p(scratch), C.byref(p), _p(pts), _p(inv_T), _p(vol),
-                                                      _p(planes_cl), _stream())
-                else:
-                    rc = L.hav_field_inputs_bwd(_p(dpl), _p(dvol), _p(dX), C.byref(p), _p(pts), _p(inv_T), _p(vol), _p(planes_cl), _stream())
-            _lib.check(rc, "hav_field_inputs_bwd")
-            from .conv import _trace
-            _trace("FieldInputs.bwd dX,dvol,dplanes,vol", dX, dvol, dpl, vol)          # (development aid; a no-op unless HAVATAR_NAN_TRACE)
+        dvol, dpl = _field_backward(pts, inv_T, vol, planes_cl, ctx.boxes, dX, ctx.needs_input_grad[2], ctx.needs_input_grad[3])
         return None, None, dvol, dpl, None
+
+
+def _field_backward(pts, inv_T, vol, planes_cl, boxes, dX, need_vol, need_planes):
+    """(dvol, dplanes_cl) of the field inputs from dX [n, 2C+48] float32 (hav_field_inputs_bwd, or its fixed-point form)"""
+    p = _field_params(pts, planes_cl, vol, boxes)
+    det = deterministic() and p.C <= 64
+    mk = torch.empty_like if det else torch.zeros_like          # (the fixed-point route writes every element itself)
+    dvol = mk(vol) if need_vol else None
+    dpl = mk(planes_cl) if need_planes else None
+    if dvol is not None or dpl is not None:
+        dX = dX.contiguous()
+        L = _lib.lib()
+        with torch.cuda.device(pts.device):
+            if det:
+                # HAVATAR_DETERMINISTIC=1: 64-bit fixed-point sums, integer atomics -- the same bits on every run (the float atomics of
+                # the default route land in a different order every time)
+                from .conv import absmax
+                words = absmax(dX)
+                scratch = torch.empty(int(L.hav_field_inputs_bwd_fixed_scratch_bytes(C.byref(p))), dtype=torch.uint8, device=pts.device)
+                rc = L.hav_field_inputs_bwd_fixed(_p(dpl), _p(dvol), _p(dX), _p(words), _p(scratch), C.byref(p), _p(pts), _p(inv_T), _p(vol),
+                                                  _p(planes_cl), _stream())
+            else:
+                rc = L.hav_field_inputs_bwd(_p(dpl), _p(dvol), _p(dX), C.byref(p), _p(pts), _p(inv_T), _p(vol), _p(planes_cl), _stream())
+        _lib.check(rc, "hav_field_inputs_bwd")
+        from .conv import _trace
+        _trace("FieldInputs.bwd dX,dvol,dplanes,vol", dX, dvol, dpl, vol)          # (development aid; a no-op unless HAVATAR_NAN_TRACE)
+    return dvol, dpl
+
+
+class FieldMlp(Function):
+    """rf [B*N, 68] = radiance_mlp(field_inputs(pts)) as ONE autograd node: the rows X between the two kernels are bf16 (the MLP's bf16
+    kernels round fp32 rows exactly so -- same rf, same gradients as FieldInputs -> FusedMlp), written once and read twice at half the
+    bytes, and kept for the backward at half the memory.  Gradients: vol, planes_cl, the ten MLP tensors."""
+
+    @staticmethod
+    def forward(ctx, pts, inv_T, vol, planes_cl, boxes, *weights):
+        from . import mlp_train
+        _need_hip("FieldMlp", pts, inv_T, vol, planes_cl)
+        pts, inv_T, vol, planes_cl = pts.contiguous(), inv_T.contiguous(), vol.contiguous(), planes_cl.contiguous()
+        p = _field_params(pts, planes_cl, vol, boxes)
+        X = torch.empty(p.n, 2 * p.C + 48, device=pts.device, dtype=torch.bfloat16)
+        with torch.cuda.device(pts.device):
+            rc = _lib.lib().hav_field_inputs_fwd_bf16(_p(X), C.byref(p), _p(pts), _p(inv_T), _p(vol), _p(planes_cl), _stream())
+        _lib.check(rc, "hav_field_inputs_fwd_bf16")
+        blob = mlp_train.pack(weights)
+        ctx.save_for_backward(pts, inv_T, vol, planes_cl, X, blob)
+        ctx.boxes = boxes
+        ctx.shapes = [tuple(w.shape) for w in weights]
+        return mlp_train.forward_only(X, blob)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d_rf):
+        from . import mlp_train
+        pts, inv_T, vol, planes_cl, X, blob = ctx.saved_tensors
+        need_vol, need_pl = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        dX, grads = mlp_train.backward_only(X, d_rf.contiguous(), blob, ctx.shapes, need_dx=need_vol or need_pl)
+        dvol, dpl = _field_backward(pts, inv_T, vol, planes_cl, ctx.boxes, dX, need_vol, need_pl) if dX is not None else (None, None)
+        return (None, None, dvol, dpl, None) + tuple(grads)
+
+
+def field_mlp_eligible(planes_nchw, weights):
+    """shapes FieldMlp takes: C = 64 channels per plane (2C + 48 = 176 input columns) and the radiance MLP the bf16 kernels are written for"""
+    from . import mlp_train
+    return planes_nchw.shape[2] == 64 and [tuple(w.shape) for w in weights] == mlp_train._SHAPES
+
+
+def field_mlp(pts, inv_T, vol, planes_nchw, nerf_box, skin_box, weights):
+    """as field_inputs() followed by mlp_train.fused_mlp(): pts [B,N,3] ... -> rf [B*N, 68]"""
+    boxes = (tuple(nerf_box[0]), tuple(nerf_box[1]), tuple(skin_box[0]), tuple(skin_box[1]))
+    return FieldMlp.apply(pts, inv_T, vol, planes_nchw.permute(0, 1, 3, 4, 2).contiguous(), boxes, *weights)
 
 
 def field_inputs(pts, inv_T, vol, planes_nchw, nerf_box, skin_box):

@@ -160,6 +160,10 @@ typedef struct HavFieldParams {
 
 int hav_field_inputs_fwd(float* X, const HavFieldParams* p, const float* pts, const float* inv_T, const float* vol,
                          const float* planes_cl, void* stream);
+/* The same rows as bf16 [n, 2C+48] (round to nearest even) for hav_mlp_train_fwd_xbf16 / _bwd_xbf16: the radiance MLP's bf16 kernels round
+ * their fp32 input rows exactly so, hence identical results with half the bytes between the two kernels.  C <= 64, C even. */
+int hav_field_inputs_fwd_bf16(void* Xb, const HavFieldParams* p, const float* pts, const float* inv_T, const float* vol,
+                              const float* planes_cl, void* stream);
 int hav_field_inputs_bwd(float* dplanes_cl, float* dvol, const float* dX, const HavFieldParams* p, const float* pts,
                          const float* inv_T, const float* vol, const float* planes_cl, void* stream);
 /* Bit-reproducible form of hav_field_inputs_bwd (ABI 6): the same gradients, summed as 64-bit fixed-point integers with integer atomics
@@ -319,6 +323,10 @@ int hav_mlp_train_fwd(float* rf, const float* X, const void* blob, int64_t n, vo
 /* accumulate != 0: grads += (autograd's accumulation into .grad); 0: grads = */
 int hav_mlp_train_bwd(float* dX, const HavMlpGrads* grads, int accumulate, const float* X, const float* d_rf, const void* blob,
                       void* ops, void* partial, int64_t n, void* stream);
+/* the same with X given as bf16 rows [n,176] (hav_field_inputs_fwd_bf16); dX stays fp32 */
+int hav_mlp_train_fwd_xbf16(float* rf, const void* Xb, const void* blob, int64_t n, void* stream);
+int hav_mlp_train_bwd_xbf16(float* dX, const HavMlpGrads* grads, int accumulate, const void* Xb, const float* d_rf, const void* blob,
+                            void* ops, void* partial, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Ray march -- replaces Trainer.predict_and_render_radiance (model/nerf_trainer.py:120-201) and

@@ -147,3 +147,36 @@ def test_full_cfg5_pass_size_bias_gradients_are_column_sums():
         scale = want.abs().max().item() + d.abs().sum().item() / n * 1e-3
         assert (got.double() - want).abs().max().item() <= 2e-3 * max(scale, d.abs().max().item() * 30), name
     assert torch.isfinite(Xg.grad).all() and Xg.grad.abs().max().item() > 0
+
+
+def test_field_inputs_and_mlp_as_one_node_with_bf16_rows_equal_the_two_nodes():
+    """FieldMlp (native/train_ops.py: hav_field_inputs_fwd_bf16 -> hav_mlp_train_*_xbf16, the rows between the kernels in bf16) against
+    FieldInputs -> FusedMlp (fp32 rows, rounded to bf16 inside the MLP kernels): the same rf bit for bit, the same MLP gradients bit for
+    bit (fixed-order reduction), plane / volume gradients equal up to the order their float atomics land in."""
+    from havatar_amd.native import mlp_train
+    from havatar_amd.native.train_ops import field_inputs, field_mlp
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(31)
+    nerf_box, skin_box = ([0.66, 0.65, 0.7], [0.0, 0.07, 0.14]), ([0.66, 1.9, 0.7], [0.0, -1.7, 0.14])
+    B, R, S, Cc, H, D = 2, 512, 56, 64, 128, 64
+    planes = torch.randn(2, B, Cc, H, H, device=dev, generator=g, requires_grad=True)
+    vol0 = torch.sigmoid(2 * torch.randn(1, 1, D, D, D, device=dev, generator=g))
+    vol = torch.cat([vol0, 1 - vol0], 1).requires_grad_(True)
+    o = torch.rand(B, R, 1, 3, device=dev, generator=g) * 1.2 - 0.6
+    d = torch.nn.functional.normalize(torch.randn(B, R, 1, 3, device=dev, generator=g), dim=-1)
+    tt = torch.linspace(-1.2, 1.2, S, device=dev).view(1, 1, S, 1)
+    pts = (o + d * tt).reshape(B, R * S, 3).contiguous()
+    inv_T = torch.cat([torch.eye(3, device=dev).expand(B, 3, 3), torch.tensor([[[0.02, -0.03, 0.01]]], device=dev).expand(B, 1, 3)], 1).contiguous()
+    ws = _weights(dev)
+    up = torch.randn(B * R * S, 68, device=dev, generator=g) / (B * R * S)
+
+    rf2 = mlp_train.fused_mlp(field_inputs(pts, inv_T, vol, planes, nerf_box, skin_box), ws)
+    g2 = torch.autograd.grad(rf2, [planes, vol] + ws, up)
+    rf1 = field_mlp(pts, inv_T, vol, planes, nerf_box, skin_box, ws)
+    g1 = torch.autograd.grad(rf1, [planes, vol] + ws, up)
+    assert torch.equal(rf1, rf2)
+    for a, b, name in zip(g1[2:], g2[2:], NAMES):
+        assert torch.equal(a, b), name
+    for a, b, name in zip(g1[:2], g2[:2], ("planes", "vol")):
+        scale = b.abs().max().item()
+        assert scale > 0 and (a - b).abs().max().item() <= 2e-5 * scale, (name, (a - b).abs().max().item() / scale)
