@@ -25,8 +25,8 @@ busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in frame)
 print("# one training step: %d launches, span %.1f ms, kernel time %.1f ms" % (len(frame), (t1 - t0) / 1e6, busy / 1e6))
 agg = collections.OrderedDict()
 for r in frame:
-    e = agg.setdefault(r["Kernel_Name"][:100], [0, 0]); e[0] += 1; e[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-for k, (n, d) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:30]:
+    e = agg.setdefault(r["Kernel_Name"][:100] if "at::native" not in r["Kernel_Name"] else r["Kernel_Name"].replace("at::native::", "").replace("(anonymous namespace)::", "")[:330], [0, 0]); e[0] += 1; e[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+for k, (n, d) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:70]:
     print("%9.2f ms  n=%-5d avg %9.1f us  %s" % (d / 1e6, n, d / 1e3 / n, k))
 PY
 rm -rf $OUT/kt
