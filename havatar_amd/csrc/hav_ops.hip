@@ -1338,7 +1338,9 @@ static int ufd_launch(void* out_, const void* in_, const float* k, const UfdArgs
             // the row-streaming kernels take the three classes of the StyleGAN blocks; HAVATAR_UFD=legacy (read once) keeps the strip / tiled
             // kernels below for A/B runs and for the bit-identity tests, HAVATAR_UFD_SEG forces the rows per segment
             const int roll_mode = ufd_lab_mode(), roll_seg = g_ufd_seg.load(std::memory_order_relaxed);
-            if (roll_mode && a.out_w >= 64 && kh <= 4 && kw <= 4 && a.px0 >= 0 && a.py0 >= 0 && a.px0 <= 4 && a.py0 <= 4 && a.in_w > 8) {
+            // (tensors of 2 GiB and more stay on the kernels below: the buffer descriptors of the row-streaming kernels take 32-bit offsets)
+            const bool fits32 = a.major * (int64_t)a.in_h * a.in_w * 4 < 0x7fff0000LL && a.major * (int64_t)a.out_h * a.out_w * 4 < 0x7fff0000LL;
+            if (roll_mode && fits32 && a.out_w >= 64 && kh <= 4 && kw <= 4 && a.px0 >= 0 && a.py0 >= 0 && a.px0 <= 4 && a.py0 <= 4 && a.in_w > 8) {
                 // rows per segment: the longest segment that still gives the chip 9 waves per compute unit (fewer window rows re-read);
                 // small launches take the shortest one
                 auto pick = [&](int rows, int shortest) {

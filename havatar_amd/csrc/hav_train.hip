@@ -658,8 +658,24 @@ __global__ void __launch_bounds__(256) composite_kernel(CompArgs a)
     float* sw = sw_[wv]; float* sd = sd_[wv];
     const int S = a.S, CH = a.CH, RW = a.CH + 1;
     const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    extern __shared__ __attribute__((aligned(16))) float srf_all[];          // MODE 2: [waves][S][RW]
     for (int64_t r = wave0; r < a.n_rays; r += nwaves) {
         const float* rf = a.rf + (size_t)r * S * RW;
+        if (MODE == 2) {
+            // backward: the lane = sample phase below walks a row of CH + 1 values per lane -- straight from memory that is 64 cache lines per
+            // load instruction, the same ones 17 times over, with every resident wave's 17 KB block competing for the 32 KB L1 (0.9 TB/s).
+            // The block is copied once, coalesced, into LDS (row pitch CH + 1 = 69 words: odd, conflict-free for both walks) and read there.
+            float* srf = srf_all + (size_t)wv * S * RW;
+            const int nel = S * RW;
+            __builtin_amdgcn_wave_barrier();
+            if ((nel & 3) == 0 && ((reinterpret_cast<uintptr_t>(rf) & 15) == 0)) {
+                for (int e = lane; e < (nel >> 2); e += 64) reinterpret_cast<float4*>(srf)[e] = reinterpret_cast<const float4*>(rf)[e];
+            } else {
+                for (int e = lane; e < nel; e += 64) srf[e] = rf[e];
+            }
+            __builtin_amdgcn_wave_barrier();
+            rf = srf;
+        }
         // ---- lane = sample: alpha, transmittance, weight (:36-60)
         const bool on = lane < S;
         const int li = on ? lane : S - 1;
@@ -775,7 +791,16 @@ extern "C" int hav_composite_bwd(float* d_rf, const float* d_rgb, const float* d
     a.d_rf = d_rf; a.d_rgb = d_rgb; a.d_acc = d_acc; a.d_w = d_weights; a.d_depth = d_depth;
     a.rf = rf; a.z = z; a.rd = rd; a.noise = noise; a.bg = bg;
     a.n_rays = n_rays; a.S = S; a.CH = CH; a.nsig = n_sigmoid;
-    hipLaunchKernelGGL(composite_kernel<1>, dim3(comp_blocks(n_rays)), dim3(256), 0, (hipStream_t)stream, a);
+    // the staged form: 2 waves per workgroup, S x (CH + 1) floats of LDS per wave (35 KB per workgroup at config 5's 64 x 69); larger blocks and
+    // HAVATAR_COMPOSITE_BWD=direct take the form that reads the rows from memory
+    static const bool direct = [] { const char* e = getenv("HAVATAR_COMPOSITE_BWD"); return e && !strcmp(e, "direct"); }();
+    const size_t lds = (size_t)2 * S * (CH + 1) * sizeof(float);
+    if (!direct && lds <= 48 * 1024) {
+        int64_t blocks = (n_rays + 1) / 2;
+        const int64_t cap = (int64_t)hav_num_cus() * 32;
+        hipLaunchKernelGGL(composite_kernel<2>, dim3((unsigned)(blocks > cap ? cap : blocks)), dim3(128), lds, (hipStream_t)stream, a);
+    } else
+        hipLaunchKernelGGL(composite_kernel<1>, dim3(comp_blocks(n_rays)), dim3(256), 0, (hipStream_t)stream, a);
     HAV_LAUNCH_CHECK();
     return 0;
 }

@@ -196,6 +196,20 @@ def test_upfirdn2d_row_streaming_kernels_are_bit_identical_to_the_tiled_ones(cas
         L.hav_lab_upfirdn2d(1, 0)
 
 
+def test_upfirdn2d_tensors_of_2_gib_and_more_stay_on_the_strip_kernels():
+    """The row-streaming kernels address through buffer descriptors with 32-bit offsets: a tensor of >= 2 GiB must take the strip / tiled
+    kernels (not fail), with the same bits as the same planes filtered in a small call."""
+    from havatar_amd.native import upfirdn2d as op
+    k = torch.tensor([1., 3., 3., 1.], device=DEV)
+    k = k[None] * k[:, None] / 64
+    x = torch.empty(520, 1024, 1024, 1, device=DEV).uniform_(-1, 1)          # 2.03 GiB
+    y = op.upfirdn2d(x, k, 1, 1, 1, 1, 2, 1, 2, 1)
+    for sl in (slice(0, 3), slice(517, 520)):
+        assert torch.equal(y[sl], op.upfirdn2d(x[sl].contiguous(), k, 1, 1, 1, 1, 2, 1, 2, 1))
+    del x, y
+    torch.cuda.empty_cache()
+
+
 def test_haar_up2_equals_the_three_stage_skip_path_bit_for_bit():
     """hav_haar_up2 (ToRGB's skip path dwt(upsample(iwt(skip))) as one pass, reference model/styleUnet.py:476-480) against the three-stage
     sequence on this library's kernels (each pinned to the reference's upfirdn2d calls elsewhere in this file) and against the plain
