@@ -669,7 +669,15 @@ __global__ void __launch_bounds__(256) composite_kernel(CompArgs a)
             const int nel = S * RW;
             __builtin_amdgcn_wave_barrier();
             if ((nel & 3) == 0 && ((reinterpret_cast<uintptr_t>(rf) & 15) == 0)) {
-                for (int e = lane; e < (nel >> 2); e += 64) reinterpret_cast<float4*>(srf)[e] = reinterpret_cast<const float4*>(rf)[e];
+                // 6 vectors per lane in flight (a serial load -> store loop is one memory round trip per 1 KiB)
+                const int n4 = nel >> 2;
+                for (int e0 = 0; e0 < n4; e0 += 6 * 64) {
+                    float4 v[6];
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) { const int e = e0 + 64 * u + lane; v[u] = e < n4 ? reinterpret_cast<const float4*>(rf)[e] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) { const int e = e0 + 64 * u + lane; if (e < n4) reinterpret_cast<float4*>(srf)[e] = v[u]; }
+                }
             } else {
                 for (int e = lane; e < nel; e += 64) srf[e] = rf[e];
             }
@@ -745,6 +753,7 @@ __global__ void __launch_bounds__(256) composite_kernel(CompArgs a)
             sd[lane] = (on && raw > 0.f) ? dsig : 0.f;
             __builtin_amdgcn_wave_barrier();
             // ---- lane = channel: d c_i = w_i d_rgb (sigmoid' on the first nsig), d raw_i in the last column
+            float* srf_w = MODE == 2 ? srf_all + (size_t)wv * S * RW : nullptr;          // MODE 2: the gradient block replaces the staged one in place
             for (int c = lane; c < RW; c += 64) {
                 const float g = c < CH ? drgb[c] : 0.f;
                 for (int i = 0; i < S; ++i) {
@@ -752,7 +761,18 @@ __global__ void __launch_bounds__(256) composite_kernel(CompArgs a)
                     if (c == CH) o = sd[i];
                     else if (c < a.nsig) { const float sg = sigmoidf_(rf[(size_t)i * RW + c]); o = sw[i] * g * sg * (1.0f - sg); }
                     else o = sw[i] * g;
-                    a.d_rf[((size_t)r * S + i) * RW + c] = o;
+                    if (MODE == 2) srf_w[i * RW + c] = o;
+                    else a.d_rf[((size_t)r * S + i) * RW + c] = o;
+                }
+            }
+            if (MODE == 2) {          // ... and leaves as whole 16-byte vectors, a contiguous KiB per wave and store
+                float* dst = a.d_rf + (size_t)r * S * RW;
+                const int nel = S * RW;
+                __builtin_amdgcn_wave_barrier();
+                if ((nel & 3) == 0 && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+                    for (int e = lane; e < (nel >> 2); e += 64) reinterpret_cast<float4*>(dst)[e] = reinterpret_cast<const float4*>(srf_w)[e];
+                } else {
+                    for (int e = lane; e < nel; e += 64) dst[e] = srf_w[e];
                 }
             }
         }
