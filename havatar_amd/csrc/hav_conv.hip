@@ -58,42 +58,57 @@ extern "C" int64_t hav_conv3x3_packed_bytes(int Cout, int Cin) { return (int64_t
 // fragment (chunk cc, tap t, M tile m, part): lane (i, h) holds W[32m + i][16cc + 8h + e][t] * wmul * 2^8, e = 0..7, as fp16 hi or lo
 // transposed != 0: the filters of the DATA GRADIENT, W'[o' = i][i' = o][t] = W[o][i][8 - t] (Cout, Cin are those of W'), read straight
 // from W [Cin, Cout, 3, 3] -- no flip / transpose / contiguous passes in front of the pack
+// One workgroup per (16-channel chunk cc, 32-row tile m): the tile's 32 x 16 x 9 weights are read as whole runs (144 consecutive floats per
+// filter row; transposed: 288 per input channel) into LDS and leave as the 18 fragments (9 taps x hi / lo) of the tile, 16 bytes per lane.
+// (Rounds 1-4 gathered every fragment element straight from memory: 8 loads per thread that each touched 64 cache lines -- 12.9 us per
+// 512 x 512 layer, 36 packs per training step.)
 __global__ void __launch_bounds__(256) conv3x3_pack_kernel(uint4* __restrict__ blob, const float* __restrict__ w, int Cout, int Cin, float wmul,
-                                                           int64_t total, int transposed)
+                                                           int transposed)
 {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const int lane = (int)(idx & 63), i = lane & 31, h = lane >> 5;
-    int64_t q = idx >> 6;
-    const int part = (int)(q & 1); q >>= 1;
-    const int MT = Cout / 32;
-    const int m = (int)(q % MT); q /= MT;
-    const int t = (int)(q % 9);
-    const int cc = (int)(q / 9);
-    uint32_t o[4];
+    __shared__ float tile[16 * 289 > 32 * 145 ? 16 * 289 : 32 * 145];
+    const int cc = blockIdx.x, m = blockIdx.y, MT = Cout / 32, tid = threadIdx.x;
+    if (!transposed) {
+        // rows = filters 32 m .. + 31, 144 floats each: W[o][16 cc .. + 15][0..8]
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        float v[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int o = 32 * m + i, ci = 16 * cc + 8 * h + 2 * d + u;
-            v[u] = (transposed ? w[((int64_t)ci * Cout + o) * 9 + (8 - t)] : w[((int64_t)o * Cin + ci) * 9 + t]) * (wmul * CV_WSHIFT);
+        for (int j = 0; j < 18; ++j) {
+            const int e = tid + 256 * j, row = e / 144, col = e - 144 * row;
+            tile[row * 145 + col] = w[((int64_t)(32 * m + row) * Cin + 16 * cc) * 9 + col];
         }
-        const fl2_t f = {v[0], v[1]};
-        const h2_t hi = __builtin_convertvector(f, h2_t);
-        const h2_t lo = __builtin_convertvector(f - __builtin_convertvector(hi, fl2_t), h2_t);
-        o[d] = __builtin_bit_cast(uint32_t, part ? lo : hi);
+    } else {
+        // rows = input channels 16 cc .. + 15 of W' = rows of W, 288 floats each: W[ci][32 m .. + 31][0..8]
+#pragma unroll
+        for (int j = 0; j < 18; ++j) {
+            const int e = tid + 256 * j, row = e / 288, col = e - 288 * row;
+            tile[row * 289 + col] = w[((int64_t)(16 * cc + row) * Cout + 32 * m) * 9 + col];
+        }
     }
-    blob[idx] = make_uint4(o[0], o[1], o[2], o[3]);
+    __syncthreads();
+    for (int q = tid; q < 9 * 2 * 64; q += 256) {
+        const int lane = q & 63, part = (q >> 6) & 1, t = q >> 7, i = lane & 31, h = lane >> 5;
+        uint32_t o[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            float v[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int cl = 8 * h + 2 * d + u;
+                v[u] = (transposed ? tile[cl * 289 + i * 9 + (8 - t)] : tile[i * 145 + cl * 9 + t]) * (wmul * CV_WSHIFT);
+            }
+            const fl2_t f = {v[0], v[1]};
+            const h2_t hi = __builtin_convertvector(f, h2_t);
+            const h2_t lo = __builtin_convertvector(f - __builtin_convertvector(hi, fl2_t), h2_t);
+            o[d] = __builtin_bit_cast(uint32_t, part ? lo : hi);
+        }
+        blob[((((int64_t)cc * 9 + t) * MT + m) * 2 + part) * 64 + lane] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
 }
 
 extern "C" int hav_conv3x3_pack(void* blob, const float* w, int Cout, int Cin, float wmul, void* stream)
 {
     if (!blob || !w || Cout < 32 || Cin < 16) return HAV_EINVAL;
     if ((Cout % 32) || (Cin % 16)) return HAV_EUNSUP;
-    const int64_t total = hav_conv3x3_packed_bytes(Cout, Cin) / 16;
-    hipLaunchKernelGGL(conv3x3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (uint4*)blob, w, Cout, Cin,
-                       wmul, total, 0);
+    hipLaunchKernelGGL(conv3x3_pack_kernel, dim3((unsigned)(Cin / 16), (unsigned)(Cout / 32)), dim3(256), 0, (hipStream_t)stream, (uint4*)blob, w, Cout, Cin,
+                       wmul, 0);
     HAV_LAUNCH_CHECK();
     return 0;
 }
@@ -103,9 +118,8 @@ extern "C" int hav_conv3x3_pack_t(void* blob, const float* w, int Cout_w, int Ci
     // w [Cout_w, Cin_w, 3, 3] -> the blob of the convolution with Cin_w output and Cout_w input channels (flipped taps)
     if (!blob || !w || Cout_w < 16 || Cin_w < 32) return HAV_EINVAL;
     if ((Cout_w % 16) || (Cin_w % 32)) return HAV_EUNSUP;
-    const int64_t total = hav_conv3x3_packed_bytes(Cin_w, Cout_w) / 16;
-    hipLaunchKernelGGL(conv3x3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (uint4*)blob, w, Cin_w, Cout_w,
-                       wmul, total, 1);
+    hipLaunchKernelGGL(conv3x3_pack_kernel, dim3((unsigned)(Cout_w / 16), (unsigned)(Cin_w / 32)), dim3(256), 0, (hipStream_t)stream, (uint4*)blob, w, Cin_w, Cout_w,
+                       wmul, 1);
     HAV_LAUNCH_CHECK();
     return 0;
 }

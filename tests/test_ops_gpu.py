@@ -210,6 +210,39 @@ def test_upfirdn2d_tensors_of_2_gib_and_more_stay_on_the_strip_kernels():
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("Cout,Cin", [(512, 512), (64, 32), (96, 160), (32, 32)])
+def test_conv3x3_pack_layout_bit_for_bit(Cout, Cin):
+    """hav_conv3x3_pack / _pack_t (tile-wise through LDS since round 5) against the fragment layout stated in hav_conv.hip, built with torch:
+    fragment (chunk cc, tap t, row tile m, part) -- lane (i, h) holds W[32 m + i][16 cc + 8 h + e][t] * wmul * 2^8, e = 0..7, as the fp16 hi
+    or lo part; pack_t: the filters of the data gradient, W'[o'][i'][t] = W[i'][o'][8 - t]."""
+    from havatar_amd.native import conv
+    g = torch.Generator(device=DEV).manual_seed(Cout + Cin)
+    w = torch.randn(Cout, Cin, 3, 3, device=DEV, generator=g)
+    wmul = 0.0371
+
+    def ref(wp, fused):          # wp [Co, Ci, 3, 3]; fused: the low part from the unrounded product (the compiler contracts w * c - hi into an FMA)
+        Co, Ci = wp.shape[:2]
+        c = torch.tensor(wmul * 256.0, dtype=torch.float32, device=DEV)
+        v = wp.reshape(Co, Ci, 9) * c
+        hi = v.half()
+        lo = ((wp.reshape(Co, Ci, 9).double() * c.double() - hi.double()).float() if fused else v - hi.float()).half()
+        parts = torch.stack([hi, lo], 0)                                              # [part, Co, Ci, 9]
+        f = parts.reshape(2, Co // 32, 32, Ci // 16, 2, 8, 9)                          # [part, m, i, cc, h, e, t]
+        return f.permute(3, 6, 1, 0, 4, 2, 5).contiguous().reshape(-1)                 # [cc, t, m, part, h, i, e]
+
+    for got, wp in ((conv.pack(w, wmul), w), (conv.pack_t(w, wmul), w.permute(1, 0, 2, 3).flip(2, 3).contiguous())):
+        got = got.view(torch.float16)
+        a, b = ref(wp, True), ref(wp, False)
+        assert got.shape == a.shape
+        ok = (got.view(torch.int16) == a.view(torch.int16)) | (got.view(torch.int16) == b.view(torch.int16))          # either rounding of the low part
+        assert bool(ok.all()), int((~ok).sum())
+        # (the high parts, half of the blob, have one valid value only)
+        hi_mask = torch.zeros(2, dtype=torch.bool, device=DEV)
+        hi_mask[0] = True
+        sel = hi_mask.view(1, 1, 1, 2, 1, 1, 1).expand(wp.shape[1] // 16, 9, wp.shape[0] // 32, 2, 2, 32, 8).reshape(-1)
+        assert torch.equal(got[sel].view(torch.int16), a[sel].view(torch.int16))
+
+
 def test_haar_up2_equals_the_three_stage_skip_path_bit_for_bit():
     """hav_haar_up2 (ToRGB's skip path dwt(upsample(iwt(skip))) as one pass, reference model/styleUnet.py:476-480) against the three-stage
     sequence on this library's kernels (each pinned to the reference's upfirdn2d calls elsewhere in this file) and against the plain
