@@ -111,7 +111,7 @@ class EqualConv2d(nn.Module, _InferenceCache):
 
     def forward(self, input):
         w = self._cached("w", self.weight, lambda: self.weight * self.scale)
-        if (torch.is_grad_enabled() and _fused_conv_enabled() and input.shape[-1] * input.shape[-2] >= 1024
+        if (torch.is_grad_enabled() and _fused_conv_enabled() and input.shape[-1] * input.shape[-2] >= 256
                 and _conv.eligible(input, w, self.stride, self.padding)):
             # training on HIP tensors: forward and both gradients on the split-fp16 MFMA kernels (native/conv.py)
             out = _conv.conv3x3_autograd(input, w)
@@ -164,9 +164,9 @@ class ModulatedConv2d(nn.Module, _InferenceCache):
         return input.is_cuda and input.dtype == torch.float32 and not torch.is_grad_enabled()
 
     def fused_conv_ok(self, input):
-        """3x3, no re-sampling, a shape hav_conv3x3_split takes (32^2 and up; 32^2 maps run K-split over 4 workgroups per tile)."""
+        """3x3, no re-sampling, a shape hav_conv3x3_split takes (16^2 and up: 16-wide maps on the 8 x 16-tile variant; small maps run K-split over several workgroups per tile)."""
         return (self.kernel_size == 3 and not self.upsample and not self.downsample and _fused_conv_enabled()
-                and input.shape[-1] * input.shape[-2] >= 1024 and _conv.eligible(input, self.weight[0]))
+                and input.shape[-1] * input.shape[-2] >= 256 and _conv.eligible(input, self.weight[0]))
 
     def packed3x3(self):
         return self._cached("w3x3", self.weight, lambda: _conv.pack(self.weight[0], self.scale))
@@ -213,7 +213,7 @@ class ModulatedConv2d(nn.Module, _InferenceCache):
             out = self.blur(conv2d_gradfix.conv_transpose2d(x, wt, padding=0, stride=2))
         elif self.downsample:
             out = conv2d_gradfix.conv2d(self.blur(x), w, padding=0, stride=2)
-        elif (torch.is_grad_enabled() and self.kernel_size == 3 and _fused_conv_enabled() and x.shape[-1] * x.shape[-2] >= 1024
+        elif (torch.is_grad_enabled() and self.kernel_size == 3 and _fused_conv_enabled() and x.shape[-1] * x.shape[-2] >= 256
               and _conv.eligible(x, w)):
             out = _conv.conv3x3_autograd(x, w)          # training: forward, data and weight gradient on the split-fp16 MFMA kernels (native/conv.py)
         else:
@@ -301,14 +301,14 @@ class ConvLayer(nn.Sequential):
             return self[2](out) if len(self) > 2 else out
         ec = self[0]
         if (isinstance(ec, EqualConv2d) and input.is_cuda and input.dtype == torch.float32 and torch.is_grad_enabled()
-                and _fused_conv_enabled() and ec.stride == 1 and ec.padding == 1 and input.shape[-1] * input.shape[-2] >= 1024
+                and _fused_conv_enabled() and ec.stride == 1 and ec.padding == 1 and input.shape[-1] * input.shape[-2] >= 256
                 and _conv.block_eligible(input, ec.weight)):
             # HIP training: EqualConv2d 3x3 + bias + leaky-ReLU as one autograd node (native/conv.py::_FusedConvBlock)
             if len(self) > 1:
                 return _conv.fused_block(input, ec.weight, ec.scale, bias=self[1].bias, slope=self[1].negative_slope, gain=self[1].scale, act=True)
             return _conv.fused_block(input, ec.weight, ec.scale, bias=ec.bias, act=False)
         if (isinstance(ec, EqualConv2d) and input.is_cuda and input.dtype == torch.float32 and not torch.is_grad_enabled()
-                and _fused_conv_enabled() and input.shape[-1] * input.shape[-2] >= 1024
+                and _fused_conv_enabled() and input.shape[-1] * input.shape[-2] >= 256
                 and _conv.eligible(input, ec.weight, ec.stride, ec.padding)):
             # HIP inference: EqualConv2d 3x3 + bias + leaky-ReLU as one kernel (hav_conv3x3_split)
             act = len(self) > 1
@@ -430,7 +430,7 @@ class StyledConv(nn.Module):
                                    gain=self.activate.scale, act=True)
         if (input.is_cuda and input.dtype == torch.float32 and torch.is_grad_enabled() and self.conv.kernel_size == 3
                 and not self.conv.upsample and not self.conv.downsample and _fused_conv_enabled()
-                and input.shape[-1] * input.shape[-2] >= 1024 and _conv.block_eligible(input, self.conv.weight[0])):
+                and input.shape[-1] * input.shape[-2] >= 256 and _conv.block_eligible(input, self.conv.weight[0])):
             # HIP training, 3x3: the whole block as one autograd node (native/conv.py::_FusedConvBlock)
             s, d = self.conv.style_vectors(style)
             if noise is None:
