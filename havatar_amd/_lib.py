@@ -115,6 +115,8 @@ def lib():
     for fn in (L.hav_haar_dwt, L.hav_haar_idwt):
         fn.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
         fn.restype = i32
+    L.hav_style_mlp.argtypes = [vp, vp, vp, i32, i32, i32, i32, f32, f32, vp]
+    L.hav_style_mlp.restype = i32
     L.hav_haar_up2.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.hav_haar_up2.restype = i32
     L.hav_conv3x3_wgrad_scratch_bytes.argtypes = [i32] * 5

@@ -253,6 +253,45 @@ __global__ void __launch_bounds__(SD_OT * SD_SL) style_demod_batched_kernel(cons
                      (int)blockIdx.x - L.first_block, s_sq);
 }
 
+// The style network of a generator -- PixelNorm, then n x (EqualLinear + fused leaky-ReLU) on a [B, <= 64] vector (model/styleUnet.py:
+// _style_mlp; the tri-plane generators run 32 -> 32 x 4) -- as ONE wave per batch row instead of 5 + 2 n launch-bound ATen / rocBLAS
+// launches at the head of every generator's chain (13 launches, ~75 us of the frame's critical path).  lane = output unit; the input
+// vector lives one value per lane and is broadcast with v_readlane.  blob: per layer the scaled weight TRANSPOSED [Din][Dout] (coalesced
+// over the lanes) followed by the scaled bias [Dout], as the EqualLinear caches hold them (scale * W, lr_mul * b).
+__global__ void __launch_bounds__(64) style_mlp_kernel(float* __restrict__ out, const float* __restrict__ z, const float* __restrict__ blob,
+                                                       int n_layers, int D0, int D, float slope, float gain)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    float x = lane < D0 ? z[(int64_t)b * D0 + lane] : 0.f;
+    float ss = x * x;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    x = x * rsqrtf(ss / (float)D0 + 1e-8f);          // PixelNorm (:53-55)
+    const float* w = blob;
+    for (int l = 0; l < n_layers; ++l) {
+        const int Din = l == 0 ? D0 : D;
+        float acc = 0.f;
+        const int oc = lane < D ? lane : D - 1;
+        for (int k = 0; k < Din; ++k) {
+            const float xk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), k));
+            acc = fmaf(xk, w[k * D + oc], acc);
+        }
+        const float y = acc + w[Din * D + oc];
+        x = lane < D ? (y > 0.f ? y : y * slope) * gain : 0.f;          // fused_leaky_relu (fused_bias_act_kernel.cu:40-63)
+        w += (Din + 1) * D;
+    }
+    if (lane < D) out[(int64_t)b * D + lane] = x;
+}
+
+extern "C" int hav_style_mlp(float* out, const float* z, const float* blob, int n_layers, int B, int D0, int D, float slope, float gain, void* stream)
+{
+    if (!out || !z || !blob || n_layers < 1 || B < 1 || D0 < 1 || D < 1) return HAV_EINVAL;
+    if (D0 > 64 || D > 64) return HAV_EUNSUP;
+    hipLaunchKernelGGL(style_mlp_kernel, dim3((unsigned)B), dim3(64), 0, (hipStream_t)stream, out, z, blob, n_layers, D0, D, slope, gain);
+    HAV_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int hav_style_demod(float* s_out, float* d_out, const float* style, const float* mod_w, const float* mod_b,
                                const float* wsq, float eps, int B, int D, int Cin, int Cout, void* stream)
 {

@@ -535,6 +535,32 @@ def _style_mlp(in_dim, dim, n_mlp, lr_mlp):
     return nn.Sequential(*layers)
 
 
+def _run_style(style, z):
+    """style(z) for a _style_mlp Sequential.  HIP inference with widths <= 64 (the tri-plane generators: 32 -> 32 x 4): PixelNorm and all
+    layers as ONE launch (hav_style_mlp) instead of 5 + 2 n launch-bound ones at the head of the generator's chain; the blob of scaled,
+    transposed weights is cached per weights epoch.  Anything else: the module itself."""
+    if (z.is_cuda and z.dtype == torch.float32 and z.dim() == 2 and not torch.is_grad_enabled()
+            and os.environ.get("HAVATAR_STYLE_MLP", "1") != "0" and isinstance(style, nn.Sequential) and len(style) >= 2
+            and isinstance(style[0], PixelNorm)):
+        layers = list(style)[1:]
+        D = layers[0].weight.shape[0] if isinstance(layers[0], EqualLinear) else 0
+        ok = (0 < D <= 64 and z.shape[1] <= 64 and all(isinstance(l, EqualLinear) and l.activation and l.bias is not None for l in layers)
+              and layers[0].weight.shape[1] == z.shape[1] and all(tuple(l.weight.shape) == (D, D) for l in layers[1:]))
+        if ok:
+            from ..native import fused
+            key = tuple((l.weight.data_ptr(), l.weight._version, l.bias.data_ptr(), l.bias._version) for l in layers) + (z.device, weights_epoch())
+            hit = style.__dict__.get("_mlp_blob")
+            if hit is None or hit[0] != key:
+                with torch.no_grad():
+                    parts = []
+                    for l in layers:
+                        parts += [(l.weight * l.scale).t().contiguous().reshape(-1), (l.bias * l.lr_mul).reshape(-1)]
+                    hit = (key, torch.cat(parts).contiguous())
+                style.__dict__["_mlp_blob"] = hit
+            return fused.style_mlp(z, hit[1], len(layers), D)
+    return style(z)
+
+
 class _CondEncoder:
     """shared by both nets: conv_in (256->128) then FromRGB-pyramid + ConvBlocks, returning the feature list (fine -> coarse)."""
 
@@ -615,7 +641,7 @@ class StyleGAN_zxc(nn.Module, _CondEncoder):
         return noises
 
     def get_latent(self, styles, n_latent=None, inject_index=None):
-        return _mix_latents([self.style(s) for s in styles], self.n_latent if n_latent is None else n_latent, inject_index)
+        return _mix_latents([_run_style(self.style, s) for s in styles], self.n_latent if n_latent is None else n_latent, inject_index)
 
     def forward(self, styles, cond_feats, return_latents=False, inject_index=None, truncation=1, truncation_latent=None,
                 input_is_latent=False, noise=None, randomize_noise=True, **kwargs):
@@ -623,7 +649,7 @@ class StyleGAN_zxc(nn.Module, _CondEncoder):
         if self.zero_latents is None:
             if not input_is_latent:
                 assert self.n_mlp > 0
-                styles = [self.style(s) for s in styles]
+                styles = [_run_style(self.style, s) for s in styles]
             if truncation < 1:
                 styles = [truncation_latent + truncation * (s - truncation_latent) for s in styles]
             latent = _mix_latents(styles, self.n_latent, inject_index)

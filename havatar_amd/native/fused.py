@@ -221,3 +221,15 @@ def haar_up2(x, ki4, fir, kd4):
                                      C.c_void_p(kd4.data_ptr()), B, Cc // 4, H, W, C.c_void_p(torch.cuda.current_stream().cuda_stream))
     _lib.check(rc, "hav_haar_up2")
     return out
+
+
+def style_mlp(z, blob, n_layers, D, slope=0.2, gain=2 ** 0.5):
+    """PixelNorm + n x (EqualLinear + fused leaky-ReLU) on z [B, D0 <= 64] in one launch (hav_style_mlp); blob: see include/havatar.h."""
+    z = _f32c(z.contiguous(), "z")
+    B, D0 = z.shape
+    out = torch.empty(B, D, device=z.device, dtype=torch.float32)
+    with torch.cuda.device(z.device):
+        rc = _lib.lib().hav_style_mlp(C.c_void_p(out.data_ptr()), C.c_void_p(z.data_ptr()), C.c_void_p(blob.data_ptr()), int(n_layers), B, D0, int(D),
+                                      float(slope), float(gain), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, "hav_style_mlp")
+    return out

@@ -66,6 +66,10 @@ int hav_upfirdn2d_out_size(int in_h, int in_w, int kh, int kw, int up_x, int up_
                            int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0,
                            int pad_y1, int* out_h, int* out_w);
 
+/* The style network of a generator, `self.style(z)` = PixelNorm -> n x (EqualLinear + fused leaky-ReLU) (model/styleUnet.py:53-55,
+ * EqualLinear.forward, _style_mlp), for widths <= 64 in one launch.  blob: per layer [Din][Dout] scale * W^T then [Dout] lr_mul * b. */
+int hav_style_mlp(float* out, const float* z, const float* blob, int n_layers, int B, int D0, int D, float slope, float gain, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * StyleGAN2 block glue -- the tiny-op chains around every modulated convolution of the tri-plane encoders / the upsampler
  * (model/styleUnet.py: ModulatedConv2d.forward :196-254 non-fused branch, NoiseInjection :306-310, FusedLeakyReLU;

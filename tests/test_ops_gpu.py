@@ -243,6 +243,32 @@ def test_conv3x3_pack_layout_bit_for_bit(Cout, Cin):
         assert torch.equal(got[sel].view(torch.int16), a[sel].view(torch.int16))
 
 
+def test_style_network_in_one_launch_matches_the_module():
+    """hav_style_mlp (PixelNorm + n x (EqualLinear + fused leaky-ReLU) as one wave per batch row; reference model/styleUnet.py:53-55 and
+    the style Sequential of StyleGAN_zxc) against the module on ATen / rocBLAS and against its fp64 statement; the blob follows weight
+    updates (cache key: versions + weights epoch)."""
+    from havatar_amd.model import styleUnet as su
+    g = torch.Generator().manual_seed(9)
+    for D0, D, n in ((32, 32, 4), (17, 64, 2), (64, 24, 3)):
+        style = su._style_mlp(D0, D, n, 0.01).to(DEV)
+        with torch.no_grad():
+            for l in list(style)[1:]:
+                l.bias.copy_(torch.randn(l.bias.shape, generator=g))
+        z = torch.randn(3, D0, generator=g).to(DEV)
+        with torch.no_grad():
+            got = su._run_style(style, z)
+            ref = style(z)
+            ref64 = style.double()(z.double())
+            style.float()
+        assert got.shape == ref.shape == (3, D)
+        scale = float(ref64.abs().max())
+        assert float((got.double() - ref64).abs().max()) <= 3e-6 * scale
+        assert float((got - ref).abs().max()) <= 3e-6 * scale
+        with torch.no_grad():
+            list(style)[1].weight.mul_(1.5)          # (bumps the parameter's version: the cached blob must follow)
+            assert float((su._run_style(style, z) - style(z)).abs().max()) <= 3e-6 * float(style(z).abs().max())
+
+
 def test_haar_up2_equals_the_three_stage_skip_path_bit_for_bit():
     """hav_haar_up2 (ToRGB's skip path dwt(upsample(iwt(skip))) as one pass, reference model/styleUnet.py:476-480) against the three-stage
     sequence on this library's kernels (each pinned to the reference's upfirdn2d calls elsewhere in this file) and against the plain
