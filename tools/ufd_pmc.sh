@@ -13,7 +13,7 @@ for pass in "GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST
             "TCP_TA_TCP_STATE_READ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_WRITE_REQ_LATENCY_sum" \
             "TCC_REQ_sum TCC_READ_sum TCC_WRITE_sum TCC_TAG_STALL_sum TCC_BUSY_sum"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/p$i -o pmc -- python tools/lab/ufd_pmc_drv.py $CASE > $OUT/p$i.log 2>&1 || tail -3 $OUT/p$i.log
+  timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $OUT/p$i -o pmc -- python tools/ufd_pmc_drv.py $CASE > $OUT/p$i.log 2>&1 || tail -3 $OUT/p$i.log
 done
 python - "$OUT" <<'PY' | tee gpurun_out/ufd_pmc_$CASE.txt
 import csv, glob, os, sys
