@@ -987,29 +987,39 @@ __global__ void __launch_bounds__(256, 2) gemm_split_kernel(GemmArgs a)
         out_sc = pow2f(-e - 8);
     }
 
-    // staging task q of this thread: pixel p = tid & 127, channel pair cp = (tid >> 7) + 2 q  (0..15)
+    // staging task q (0, 1) of this thread: pixel p = tid & 127, octet o = (tid >> 7) + 2 q (0..3) = 8 consecutive channels (k group o >> 1, half
+    // o & 1): the 8 split values leave as ONE 16-byte LDS write for the high and one for the low parts, at the lane stride (80 bytes) of the
+    // reads -- conflict-free.  (Rounds 3-4 wrote channel PAIRS with 4-byte stores at that stride: 4-way bank conflicts, 16 writes per thread.)
     const int t_p = tid & (GM_NT - 1), t_c0 = tid >> 7;
-    float sv[GM_TPT][2], ssc[GM_TPT][2];
+    float sv[GM_TPT][2], ssc[GM_TPT][2];          // [2 q + (pair >> 2)... ] flattened: task q holds pairs 4 q .. 4 q + 3
     auto fetch = [&](int cc, float (&v)[GM_TPT][2], float (&sc)[GM_TPT][2]) {
         const float* src = xb + (int64_t)(GM_KC * cc) * N + t_p;
 #pragma unroll
-        for (int q = 0; q < GM_TPT; ++q) {
-            const int k = 2 * (t_c0 + 2 * q);
-            v[q][0] = src[(int64_t)k * N];
-            v[q][1] = src[(int64_t)(k + 1) * N];
-            if (HAS_S) { sc[q][0] = sb[GM_KC * cc + k] * in_sc; sc[q][1] = sb[GM_KC * cc + k + 1] * in_sc; }
-        }
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = 8 * (t_c0 + 2 * q) + 2 * e;
+                v[4 * q + e][0] = src[(int64_t)k * N];
+                v[4 * q + e][1] = src[(int64_t)(k + 1) * N];
+                if (HAS_S) { sc[4 * q + e][0] = sb[GM_KC * cc + k] * in_sc; sc[4 * q + e][1] = sb[GM_KC * cc + k + 1] * in_sc; }
+            }
     };
     auto stash = [&](int buf, const float (&v)[GM_TPT][2], const float (&sc)[GM_TPT][2]) {
 #pragma unroll
-        for (int q = 0; q < GM_TPT; ++q) {
-            const int cp = t_c0 + 2 * q, g = cp >> 3, ci = cp & 7;
-            const fl2_t f = {v[q][0] * (HAS_S ? sc[q][0] : in_sc), v[q][1] * (HAS_S ? sc[q][1] : in_sc)};
-            const h2_t hi = __builtin_convertvector(f, h2_t);
-            const h2_t lo = __builtin_convertvector(f - __builtin_convertvector(hi, fl2_t), h2_t);
-            const int at = (g * GM_NT + t_p) * CV_REC + ci;
-            lds[buf][at] = __builtin_bit_cast(uint32_t, hi);
-            lds[buf][at + 8] = __builtin_bit_cast(uint32_t, lo);
+        for (int q = 0; q < 2; ++q) {
+            const int o = t_c0 + 2 * q, g = o >> 1, hf = o & 1;
+            uint32_t hw[4], lw[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const fl2_t f = {v[4 * q + e][0] * (HAS_S ? sc[4 * q + e][0] : in_sc), v[4 * q + e][1] * (HAS_S ? sc[4 * q + e][1] : in_sc)};
+                const h2_t hi = __builtin_convertvector(f, h2_t);
+                const h2_t lo = __builtin_convertvector(f - __builtin_convertvector(hi, fl2_t), h2_t);
+                hw[e] = __builtin_bit_cast(uint32_t, hi);
+                lw[e] = __builtin_bit_cast(uint32_t, lo);
+            }
+            uint32_t* at = &lds[buf][(g * GM_NT + t_p) * CV_REC + 4 * hf];
+            *reinterpret_cast<uint4*>(at) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+            *reinterpret_cast<uint4*>(at + 8) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
         }
     };
     f32x16 acc[2][2];
