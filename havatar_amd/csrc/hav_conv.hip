@@ -657,9 +657,9 @@ extern "C" int hav_conv3x3_split(float* y, const float* x, const void* packed, c
 #define S2_PR (2 * CV_ROWS + 1)            // 9 patch rows
 #define S2_HC (CV_COLS + 1)                // 33 entries per (row, parity)
 #define S2_RECS (S2_PR * 2 * S2_HC)        // 594 records (9 of them -- odd column 65 -- never read)
-#define S2_TASKS (S2_RECS * 8)
+#define S2_TASKS (S2_RECS * 2)            // (record, half of its 8 channel pairs): 8 values in, two 16-byte LDS writes out
 #define S2_THREADS 512
-#define S2_TPT ((S2_TASKS + S2_THREADS - 1) / S2_THREADS)    // 10
+#define S2_TPT ((S2_TASKS + S2_THREADS - 1) / S2_THREADS)    // 3
 struct ConvS2Args {
     float* y; const float* x; const uint4* blob;
     float* partial; int ksplit;          // K-split: [ksplit][B,Cout,Hout,Wout] raw sums, reduced by conv3x3_finish_kernel
@@ -693,45 +693,50 @@ __global__ void __launch_bounds__(S2_THREADS, 1) conv3x3s2_split_kernel(ConvS2Ar
         in_sc = pow2f(e);
         out_sc = pow2f(-e - 8);
     }
-    // staging tasks: (record of the patch, channel pair)
+    // staging tasks: (record of the patch, half of the chunk's 16 channels).  The 8 split values of a task leave as one 16-byte LDS write for the
+    // high and one for the low parts, at the records' 80-byte stride -- conflict-free (channel pairs written with 4-byte stores at that stride
+    // were 4-way bank conflicts, 20 writes per thread and chunk)
     int t_off[S2_TPT], t_lds[S2_TPT];
     bool t_ok[S2_TPT];
 #pragma unroll
     for (int q = 0; q < S2_TPT; ++q) {
         const int task = tid + S2_THREADS * q;
-        const int cp = task / S2_RECS, rec = task - cp * S2_RECS;
+        const int qd = task / S2_RECS, rec = task - qd * S2_RECS;
         const int prow = rec / (2 * S2_HC), rem = rec - prow * (2 * S2_HC);
         const int par = rem / S2_HC, half = rem - par * S2_HC;
         const int pcol = 2 * half + par;
         const int gy = 2 * y0 + prow - a.pad, gx = 2 * x0 + pcol - a.pad;
         t_ok[q] = task < S2_TASKS && pcol <= 2 * CV_COLS && gy >= 0 && gy < Hin && gx >= 0 && gx < Win;
-        t_off[q] = t_ok[q] ? (int)((2 * cp) * HWin + (int64_t)gy * Win + gx) : 0;
-        t_lds[q] = task < S2_TASKS ? rec * CV_REC + cp : -1;
+        t_off[q] = t_ok[q] ? (int)((8 * qd) * HWin + (int64_t)gy * Win + gx) : 0;
+        t_lds[q] = task < S2_TASKS ? rec * CV_REC + 4 * qd : -1;
     }
-    float sv[S2_TPT][2];
-    auto fetch = [&](int cc, float (&v)[S2_TPT][2]) {
+    float sv[S2_TPT][8];
+    auto fetch = [&](int cc, float (&v)[S2_TPT][8]) {
         const float* src = xb + (int64_t)(16 * cc) * HWin;
 #pragma unroll
-        for (int q = 0; q < S2_TPT; ++q) {
-            v[q][0] = t_ok[q] ? src[t_off[q]] : 0.f;
-            v[q][1] = t_ok[q] ? src[t_off[q] + HWin] : 0.f;
-        }
+        for (int q = 0; q < S2_TPT; ++q)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[q][e] = t_ok[q] ? src[t_off[q] + e * HWin] : 0.f;
     };
-    auto stash = [&](int buf, int cc, const float (&v)[S2_TPT][2]) {
+    auto stash = [&](int buf, int cc, const float (&v)[S2_TPT][8]) {
         uint32_t* L = s2_lds + buf * (S2_RECS * CV_REC);
 #pragma unroll
         for (int q = 0; q < S2_TPT; ++q) {
             if (t_lds[q] < 0) continue;
-            float m0 = in_sc, m1 = in_sc;
-            if (HAS_S) {          // the chunk's 16 modulation factors: L1 hits, issued behind the matrix work
-                const int cp = (tid + S2_THREADS * q) / S2_RECS;
-                m0 *= sb[16 * cc + 2 * cp]; m1 *= sb[16 * cc + 2 * cp + 1];
+            const int qd = (tid + S2_THREADS * q) / S2_RECS;
+            uint32_t hw[4], lw[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float m0 = in_sc, m1 = in_sc;
+                if (HAS_S) { m0 *= sb[16 * cc + 8 * qd + 2 * e]; m1 *= sb[16 * cc + 8 * qd + 2 * e + 1]; }          // L1 hits, issued behind the matrix work
+                const fl2_t f = {v[q][2 * e] * m0, v[q][2 * e + 1] * m1};
+                const h2_t hi = __builtin_convertvector(f, h2_t);
+                const h2_t lo = __builtin_convertvector(f - __builtin_convertvector(hi, fl2_t), h2_t);
+                hw[e] = __builtin_bit_cast(uint32_t, hi);
+                lw[e] = __builtin_bit_cast(uint32_t, lo);
             }
-            const fl2_t f = {v[q][0] * m0, v[q][1] * m1};
-            const h2_t hi = __builtin_convertvector(f, h2_t);
-            const h2_t lo = __builtin_convertvector(f - __builtin_convertvector(hi, fl2_t), h2_t);
-            L[t_lds[q]] = __builtin_bit_cast(uint32_t, hi);
-            L[t_lds[q] + 8] = __builtin_bit_cast(uint32_t, lo);
+            *reinterpret_cast<uint4*>(L + t_lds[q]) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+            *reinterpret_cast<uint4*>(L + t_lds[q] + 8) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
         }
     };
     f32x16 acc[2];
@@ -756,7 +761,7 @@ __global__ void __launch_bounds__(S2_THREADS, 1) conv3x3s2_split_kernel(ConvS2Ar
         }
         // input prefetch runs TWO chunks ahead (the maps come from L2 / HBM: one chunk of 27 MFMAs per wave is shorter than that
         // round trip), the weight fragments (L2-resident, shared by every workgroup) one chunk ahead
-        auto step = [&](int cc, int buf, const uint4 (&F)[5][2], uint4 (&Fn)[5][2], float (&Sc)[S2_TPT][2], float (&So)[S2_TPT][2]) {
+        auto step = [&](int cc, int buf, const uint4 (&F)[5][2], uint4 (&Fn)[5][2], float (&Sc)[S2_TPT][8], float (&So)[S2_TPT][8]) {
             if (cc + 2 < c_hi) fetch(cc + 2, So);
             if (cc + 1 < c_hi) load_a(cc + 1, Fn);
             const uint32_t* L = s2_lds + buf * (S2_RECS * CV_REC);
@@ -786,7 +791,7 @@ __global__ void __launch_bounds__(S2_THREADS, 1) conv3x3s2_split_kernel(ConvS2Ar
 #endif
             __syncthreads();
         };
-        float sv2[S2_TPT][2];
+        float sv2[S2_TPT][8];
         fetch(c_lo, sv);
         load_a(c_lo, A0);
         stash(0, c_lo, sv);
