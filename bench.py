@@ -751,7 +751,10 @@ def main():
                        "headline_rule": "value = the fastest TIMED mode whose operands are not narrower than the reference's fp32 (modes.* holds every timed loop)",
                        "phase_ms": {"encoders_P3": round(enc_ms, 3), "plane_prepare": round(prep_ms, 3), "ray_march_kernel": round(kms, 3),
                                     "encoders_P3_inside_the_graph": round(step_ms - kms - prep_ms, 3),
-                                    "note": "encoders_P3 is timed eagerly on one stream; inside the frame's hipGraph the two encoders run "
+                                    "note": "encoders_P3_inside_the_graph is a DIFFERENCE (step - march - preparation) and inherits the march's box-to-box and "
+                                            "clock-state spread: the march is timed alone here, straight after an idle period, and runs 1-2 % slower at the "
+                                            "sustained power cap inside the frame loop (profiles/r05_frame_streams.txt holds the per-queue trace of a replay: "
+                                            "the encoder phase ends 1.72-1.82 ms after the previous march).  encoders_P3 is timed eagerly on one stream; inside the frame's hipGraph the two encoders run "
                                             "on two streams without launch gaps: step - march - preparation"},
                        "stage_two": ({"upsampler_ms": round(cfg4_ms, 3), "output": [1, 3, 2 * H, 2 * W],
                                       "what": "BASELINE configs[3]: the step is the cfg2 frame below followed by SWGAN_unet(512 -> 1024) on render[:, 3:] "
