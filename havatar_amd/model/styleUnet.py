@@ -316,6 +316,18 @@ class ConvLayer(nn.Sequential):
             if act:
                 return _conv.conv3x3(input, pk, ec.weight.shape[0], bias=self[1].bias, slope=self[1].negative_slope, gain=self[1].scale, act=True)
             return _conv.conv3x3(input, pk, ec.weight.shape[0], bias=ec.bias, act=False)
+        if (isinstance(ec, EqualConv2d) and input.is_cuda and input.dtype == torch.float32 and not torch.is_grad_enabled()
+                and _fused_conv_enabled() and os.environ.get("HAVATAR_CONV_1X1", "0") == "1" and ec.stride == 1 and ec.padding == 0
+                and _conv.conv1x1_eligible(input, ec.weight)):
+            # HIP inference, on request (HAVATAR_CONV_1X1=1): the 1x1 EqualConv2d (FromRGB, conv_out) as a split-fp16 matrix product
+            # (hav_gemm_split) instead of rocBLAS' fp32 GEMM.  Measured on SWGAN_unet 512 -> 1024 (K = 64, three layers): 2.74 against 2.70 ms
+            # for the whole up-sampler -- with 2 k chunks the product is a pass over x and y, and the range-control pass in front of it costs
+            # more than the fp32 GEMM's slower arithmetic: not the default
+            pk = ec._cached("w1x1", ec.weight, lambda: _conv.pack_1x1(ec.weight, ec.scale))
+            out = _conv.conv1x1(input, pk, ec.weight.shape[0])
+            if len(self) > 1:
+                return self[1](out)
+            return out if ec.bias is None else out + ec.bias.view(1, -1, 1, 1)
         return super().forward(input)
 
 

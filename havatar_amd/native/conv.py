@@ -132,6 +132,43 @@ def pack_t(weight, wmul=1.0):
     return blob
 
 
+def conv1x1_eligible(x, weight):
+    """weight [Cout,Cin,1,1]; x [B,Cin,H,W] float32 on a HIP device: shapes hav_gemm_split takes as y[Cout, HW] = W . x[Cin, HW]."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and weight.dim() == 4):
+        return False
+    Cout, Cin, kh, kw = weight.shape
+    return kh == 1 and kw == 1 and x.shape[1] == Cin and Cin % 32 == 0 and (x.shape[2] * x.shape[3]) % 128 == 0
+
+
+def pack_1x1(weight, wmul=1.0):
+    """[Cout,Cin,1,1] -> fragment blob of the [Cout x Cin] matrix (hav_gemm_pack) with `wmul` folded in."""
+    w = weight.detach()
+    Cout, Cin = w.shape[:2]
+    a = w.reshape(Cout, Cin).contiguous()
+    L = _lib.lib()
+    blob = torch.empty(int(L.hav_gemm_packed_bytes(Cout, Cin)), dtype=torch.uint8, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(L.hav_gemm_pack(_p(blob), _p(a), Cout, Cin, float(wmul), _stream(w.device)), "hav_gemm_pack")
+    return blob
+
+
+def conv1x1(x, packed, Cout, autoscale=None):
+    """y [B,Cout,H,W] = conv2d(x, W [Cout,Cin,1,1]): the 1x1 EqualConv2d of ConvLayer / FromRGB (reference model/styleUnet.py:104-122,
+    251-266) as one split-fp16 matrix product per sample (hav_gemm_split) instead of rocBLAS' fp32 GEMM; bias / activation stay with the
+    caller (FusedLeakyReLU = hav_fused_bias_act)."""
+    if autoscale is None:
+        autoscale = _autoscale_default()
+    x = x.contiguous()
+    B, Cin, H, W = x.shape
+    y = torch.empty(B, Cout, H, W, dtype=torch.float32, device=x.device)
+    L = _lib.lib()
+    with torch.cuda.device(x.device):
+        st = _stream(x.device)
+        amax = _absmax(x, st) if autoscale else None
+        _lib.check(L.hav_gemm_split(_p(y), _p(x), _p(packed), None, _p(amax), B, Cout, Cin, H * W, st), "hav_gemm_split")
+    return y
+
+
 def conv3x3(x, packed, Cout, s=None, d=None, noise=None, noise_weight=None, bias=None, slope=0.2, gain=2 ** 0.5, act=True, autoscale=None, amax=None):
     """y = act(d * conv3x3(s * x, W) + noise_weight * noise + bias) * gain; see include/havatar.h for the exact order.
     autoscale (default on; HAVATAR_CONV_AUTOSCALE=0 turns the default off): s * x is brought into fp16's comfortable range by an

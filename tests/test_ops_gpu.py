@@ -269,6 +269,30 @@ def test_style_network_in_one_launch_matches_the_module():
             assert float((su._run_style(style, z) - style(z)).abs().max()) <= 3e-6 * float(style(z).abs().max())
 
 
+@pytest.mark.parametrize("Cin,Cout,H,act", [(64, 512, 64, True), (128, 32, 128, True), (256, 96, 32, False), (64, 12, 16, True)])
+def test_conv_layer_1x1_on_the_split_matrix_product(Cin, Cout, H, act, monkeypatch):
+    """The 1x1 ConvLayer (FromRGB / conv_out, reference model/styleUnet.py:251-266,394) in HIP inference with HAVATAR_CONV_1X1=1 = hav_gemm_split
+    + the FusedLeakyReLU kernel: against the fp64 statement (truth) with the fp32 ATen / rocBLAS route as the yardstick."""
+    from havatar_amd.model.styleUnet import ConvLayer
+    torch.manual_seed(Cin + Cout)
+    layer = ConvLayer(Cin, Cout, 1, activate=act).to(DEV)
+    with torch.no_grad():
+        for p_ in layer.parameters():
+            if p_.dim() == 1:
+                p_.normal_()
+        x = torch.randn(2, Cin, H, H, device=DEV) * 3.0
+        monkeypatch.setenv("HAVATAR_CONV_1X1", "1")          # (opt-in: not faster than rocBLAS at K = 64, see ConvLayer.forward)
+        got = layer(x)
+        monkeypatch.setenv("HAVATAR_CONV_1X1", "0")
+        aten = layer(x)
+        ref = layer.double()(x.double())
+        layer.float()
+    scale = float(ref.abs().max())
+    e_got, e_aten = float((got.double() - ref).abs().max()) / scale, float((aten.double() - ref).abs().max()) / scale
+    assert got.shape == ref.shape and e_got <= max(2.0 * e_aten, 2e-6), (e_got, e_aten)
+    assert not torch.equal(got, aten) or Cin % 32 != 0          # (the two routes are different arithmetic: a bit-equal result means the kernel was not reached)
+
+
 def test_haar_up2_equals_the_three_stage_skip_path_bit_for_bit():
     """hav_haar_up2 (ToRGB's skip path dwt(upsample(iwt(skip))) as one pass, reference model/styleUnet.py:476-480) against the three-stage
     sequence on this library's kernels (each pinned to the reference's upfirdn2d calls elsewhere in this file) and against the plain
