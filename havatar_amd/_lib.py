@@ -162,6 +162,9 @@ def lib():
     L.hav_upsample3d_2x_fwd.argtypes = [vp, vp, i64, i32, i32, i32, vp]
     L.hav_upsample3d_2x_fwd.restype = i32
     L.hav_upsample3d_2x_bwd.argtypes = [vp, vp, i64, i32, i32, i32, vp]
+    for fn in (L.hav_im2col3d, L.hav_col2im3d):
+        fn.argtypes = [vp, vp, i32, i32, vp]
+        fn.restype = i32
     L.hav_upsample3d_2x_bwd.restype = i32
     L.hav_mlp_train_blob_bytes.restype = i64
     L.hav_mlp_train_ops_bytes.argtypes = [i64]

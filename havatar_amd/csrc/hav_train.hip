@@ -929,3 +929,64 @@ extern "C" int hav_upsample3d_2x_bwd(float* din, const float* dout, int64_t NC, 
     HAV_LAUNCH_CHECK();
     return 0;
 }
+
+// ================================================================================================
+// Conv3d 3^3 / padding 1 on SMALL volumes (the first layers of the skinning-volume decoder, reference model/network/voxel_encoder.py:183-210:
+// 1024 -> 512 channels on 2^3 voxels, 512 -> 256 on 4^3, 256 -> 128 on 8^3) as matrix products over an explicit patch matrix:
+//   col[(i, t)][p] = x[i][p + off(t)]  (0 outside)   K = 27 Cin rows, P = R^3 columns: 0.9 / 3.5 / 14 MB
+//   y = W[Cout, K] . col,  dW = dy . col^T,  dcol = W^T . dy,  dx[i][q] = sum_t dcol[(i, t)][q - off(t)]
+// The three products are plain GEMMs (rocBLAS through ATen: W is streamed once each, the layers are weight-bound: 56 / 14 / 3.5 MB);
+// MIOpen / CK take 350 / 200 / 115 us for the forward and 120 us for the gradients of each of these layers.  These two kernels build the
+// patch matrix and fold its gradient back (gather form both ways: no atomics).
+// ================================================================================================
+__global__ void __launch_bounds__(256) im2col3d_kernel(float* __restrict__ col, const float* __restrict__ x, int C, int R)
+{
+    const int P = R * R * R;
+    const int64_t total = (int64_t)C * 27 * P;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(e % P);
+        const int64_t k = e / P;
+        const int t = (int)(k % 27), i = (int)(k / 27);
+        const int pz = p / (R * R), py = (p / R) % R, px = p % R;
+        const int z = pz + t / 9 - 1, y = py + (t / 3) % 3 - 1, xx = px + t % 3 - 1;
+        col[e] = (z >= 0 && z < R && y >= 0 && y < R && xx >= 0 && xx < R) ? x[(int64_t)i * P + (z * R + y) * R + xx] : 0.f;
+    }
+}
+__global__ void __launch_bounds__(256) col2im3d_kernel(float* __restrict__ dx, const float* __restrict__ dcol, int C, int R)
+{
+    const int P = R * R * R;
+    const int64_t total = (int64_t)C * P;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(e % P), i = (int)(e / P);
+        const int qz = q / (R * R), qy = (q / R) % R, qx = q % R;
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+            // x[q] fed col[(i, t)][p] with p = q - off(t)
+            const int z = qz - (t / 9 - 1), y = qy - ((t / 3) % 3 - 1), xx = qx - (t % 3 - 1);
+            if (z >= 0 && z < R && y >= 0 && y < R && xx >= 0 && xx < R) s += dcol[((int64_t)i * 27 + t) * P + (z * R + y) * R + xx];
+        }
+        dx[e] = s;
+    }
+}
+extern "C" int hav_im2col3d(float* col, const float* x, int C, int R, void* stream)
+{
+    if (!col || !x || C < 1 || R < 1) return HAV_EINVAL;
+    const int64_t total = (int64_t)C * 27 * R * R * R;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > (int64_t)hav_num_cus() * 32) blocks = (int64_t)hav_num_cus() * 32;
+    hipLaunchKernelGGL(im2col3d_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, col, x, C, R);
+    HAV_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int hav_col2im3d(float* dx, const float* dcol, int C, int R, void* stream)
+{
+    if (!dx || !dcol || C < 1 || R < 1) return HAV_EINVAL;
+    const int64_t total = (int64_t)C * R * R * R;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > (int64_t)hav_num_cus() * 32) blocks = (int64_t)hav_num_cus() * 32;
+    hipLaunchKernelGGL(col2im3d_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dx, dcol, C, R);
+    HAV_LAUNCH_CHECK();
+    return 0;
+}
+

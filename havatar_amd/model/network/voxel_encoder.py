@@ -46,6 +46,13 @@ class UpConv3DBlock(nn.Module):
         self.norm = nn.InstanceNorm3d(output_nc, affine=False)
 
     def forward(self, x):
+        if isinstance(self.up, nn.Sequential) and x.is_cuda:
+            from ...native.train_ops import conv3d_small, conv3d_small_eligible
+            y = self.up[0](x)
+            if conv3d_small_eligible(y, self.up[1]):
+                # volumes of <= 8^3 voxels: the convolution as GEMMs over an explicit patch matrix (native/train_ops.py::Conv3dSmall)
+                return self.norm(conv3d_small(y, self.up[1]))
+            return self.norm(self.up[1](y))
         return self.norm(self.up(x))
 
 

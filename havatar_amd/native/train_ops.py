@@ -219,6 +219,56 @@ def upsample3d_2x(x):
     return Upsample3d2x.apply(x)
 
 
+class Conv3dSmall(Function):
+    """nn.Conv3d(kernel 3, padding 1, stride 1) on a small cubic volume [1,C,R,R,R] (R <= 8: the first three layers of VolumeDecoder) as
+    matrix products over an explicit patch matrix (hav_im2col3d / hav_col2im3d + three GEMMs): these layers are weight-bound (56 / 14 /
+    3.5 MB of filters for 8 / 64 / 512 voxels) and MIOpen / CK take 350 / 200 / 115 us for their forward alone."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        _need_hip("Conv3dSmall", x, w)
+        x, w = x.contiguous(), w.contiguous()
+        _, Cc, R = x.shape[:3]
+        Cout = w.shape[0]
+        col = torch.empty(27 * Cc, R ** 3, device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().hav_im2col3d(_p(col), _p(x), Cc, R, _stream()), "hav_im2col3d")
+        w2 = w.view(Cout, 27 * Cc)
+        y = torch.mm(w2, col) if b is None else torch.addmm(b.view(-1, 1), w2, col)
+        ctx.save_for_backward(col, w)
+        ctx.shape, ctx.has_bias = (Cc, R), b is not None
+        return y.view(1, Cout, R, R, R)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        col, w = ctx.saved_tensors
+        Cc, R = ctx.shape
+        Cout = w.shape[0]
+        g2 = g.contiguous().view(Cout, R ** 3)
+        dx = dw = db = None
+        if ctx.needs_input_grad[1]:
+            dw = torch.mm(g2, col.t()).view_as(w)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = g2.sum(1)
+        if ctx.needs_input_grad[0]:
+            dcol = torch.mm(w.view(Cout, 27 * Cc).t(), g2)
+            dx = torch.empty(1, Cc, R, R, R, device=g.device, dtype=torch.float32)
+            with torch.cuda.device(g.device):
+                _lib.check(_lib.lib().hav_col2im3d(_p(dx), _p(dcol), Cc, R, _stream()), "hav_col2im3d")
+        return dx, dw, db
+
+
+def conv3d_small_eligible(x, conv):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and x.shape[0] == 1 and x.shape[2] == x.shape[3] == x.shape[4] and x.shape[2] <= 8
+            and tuple(conv.kernel_size) == (3, 3, 3) and tuple(conv.padding) == (1, 1, 1) and tuple(conv.stride) == (1, 1, 1)
+            and tuple(conv.dilation) == (1, 1, 1) and conv.groups == 1 and os.environ.get("HAVATAR_CONV3D_SMALL", "1") != "0")
+
+
+def conv3d_small(x, conv):
+    return Conv3dSmall.apply(x, conv.weight, conv.bias)
+
+
 class Demod(Function):
     """d [B,Cout] = rsqrt(sum_i s[b,i]^2 * scale^2 sum_k W[o,i,k]^2 + eps): the demodulation factors of a ModulatedConv2d
     (reference model/styleUnet.py:214-227, factored form) as one autograd node -- two launches each way (hav_demod_fwd / _bwd)

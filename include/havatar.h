@@ -303,6 +303,10 @@ int hav_haar_up2(float* out, const float* in, const float* ki4x2x2, const float*
  * ------------------------------------------------------------------------------------------ */
 int hav_upsample3d_2x_fwd(float* out, const float* in, int64_t NC, int D, int H, int W, void* stream);
 int hav_upsample3d_2x_bwd(float* din, const float* dout, int64_t NC, int D, int H, int W, void* stream);
+/* Patch matrix of a 3^3 / padding-1 Conv3d on a small cubic volume and its adjoint (the first layers of VolumeDecoder, model/network/voxel_encoder.py:
+ * 183-210, as matrix products): col [27 C, R^3], col[(i, t)][p] = x[i][p + off(t)] or 0; dx[i][q] = sum_t dcol[(i, t)][q - off(t)].  x / dx [C, R, R, R]. */
+int hav_im2col3d(float* col, const float* x, int C, int R, void* stream);
+int hav_col2im3d(float* dx, const float* dcol, int C, int R, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Radiance MLP of the training path on the bf16 matrix cores (BASELINE config 5) -- replaces, under

@@ -293,6 +293,29 @@ def test_conv_layer_1x1_on_the_split_matrix_product(Cin, Cout, H, act, monkeypat
     assert not torch.equal(got, aten) or Cin % 32 != 0          # (the two routes are different arithmetic: a bit-equal result means the kernel was not reached)
 
 
+@pytest.mark.parametrize("Cin,Cout,R", [(1024, 512, 2), (512, 256, 4), (256, 128, 8), (24, 10, 3), (8, 4, 1)])
+def test_conv3d_on_small_volumes_matches_the_aten_convolution(Cin, Cout, R):
+    """Conv3dSmall (hav_im2col3d + GEMMs + hav_col2im3d: the first layers of VolumeDecoder, reference model/network/voxel_encoder.py:183-210)
+    against torch's Conv3d in fp64 (truth) with its fp32 result as the yardstick: output, input / weight / bias gradients."""
+    from havatar_amd.native.train_ops import Conv3dSmall
+    g = torch.Generator(device=DEV).manual_seed(Cin + R)
+    x = torch.randn(1, Cin, R, R, R, device=DEV, generator=g, requires_grad=True)
+    w = (torch.randn(Cout, Cin, 3, 3, 3, device=DEV, generator=g) / (27 * Cin) ** 0.5).requires_grad_(True)
+    b = torch.randn(Cout, device=DEV, generator=g, requires_grad=True)
+    up = torch.randn(1, Cout, R, R, R, device=DEV, generator=g)
+    y = Conv3dSmall.apply(x, w, b)
+    got = (y,) + torch.autograd.grad(y, (x, w, b), up)
+    y32 = torch.nn.functional.conv3d(x, w, b, padding=1)
+    r32 = (y32,) + torch.autograd.grad(y32, (x, w, b), up)
+    xd, wd, bd = [t_.detach().double().requires_grad_(True) for t_ in (x, w, b)]
+    y64 = torch.nn.functional.conv3d(xd, wd, bd, padding=1)
+    r64 = (y64,) + torch.autograd.grad(y64, (xd, wd, bd), up.double())
+    for name, a, r3, r6 in zip(("y", "dx", "dw", "db"), got, r32, r64):
+        scale = float(r6.abs().max())
+        e_a, e_3 = float((a.double() - r6).abs().max()) / scale, float((r3.double() - r6).abs().max()) / scale
+        assert a.shape == r6.shape and e_a <= max(3.0 * e_3, 3e-6), (name, e_a, e_3)
+
+
 def test_haar_up2_equals_the_three_stage_skip_path_bit_for_bit():
     """hav_haar_up2 (ToRGB's skip path dwt(upsample(iwt(skip))) as one pass, reference model/styleUnet.py:476-480) against the three-stage
     sequence on this library's kernels (each pinned to the reference's upfirdn2d calls elsewhere in this file) and against the plain
