@@ -101,6 +101,8 @@ def lib():
     L.hav_field_inputs_fwd_bf16.restype = i32
     L.hav_field_inputs_bwd.argtypes = [vp, vp, vp, C.POINTER(HavFieldParams), vp, vp, vp, vp, vp]
     L.hav_field_inputs_bwd.restype = i32
+    L.hav_field_inputs_bwd_rows.argtypes = [vp, vp, vp, C.POINTER(HavFieldParams), vp, vp, vp, vp, i32, vp]
+    L.hav_field_inputs_bwd_rows.restype = i32
     L.hav_field_inputs_bwd_fixed.argtypes = [vp, vp, vp, vp, vp, C.POINTER(HavFieldParams), vp, vp, vp, vp, vp]
     L.hav_field_inputs_bwd_fixed.restype = i32
     L.hav_field_inputs_bwd_fixed_scratch_bytes.argtypes = [C.POINTER(HavFieldParams)]

@@ -177,11 +177,17 @@ class Trainer(torch.nn.Module):
             mc = self.model_coarse
             ws = mc.mlp_tensors() if (torch.is_grad_enabled() and pts.shape[0] * pts.shape[1] >= 1024 and mc.sh_deg == 0
                                       and os.environ.get("HAVATAR_TRAIN_MLP", "bf16") == "bf16" and os.environ.get("HAVATAR_FIELD_MLP", "1") != "0") else None
+            # patch training (dataloader.py:93-121: a 64 x 64 patch, row-major): neighbouring rays are neighbouring pixels.  With
+            # HAVATAR_FIELD_ROWS=1 the scatter of the field-input gradients merges across 16 rays instead of along one (same sums;
+            # native/train_ops.py::_field_backward).  Off by default: faster on dense in-box patches (1.82 -> 1.59 ms per call,
+            # tools/bench_field_rows.py), slower inside this step on the harness' frames (0.685 -> 0.754 ms, profiles/r05_field_rows_ab.txt)
+            rows = zv.shape[-1] if (os.environ.get("HAVATAR_FIELD_ROWS", "0") == "1" and bool(getattr(self.cfg.experiment, "patch_rgb", False))
+                                    and R % 16 == 0) else 0
             if ws is not None and field_mlp_eligible(planes, ws):
                 # field inputs + bf16-MFMA radiance MLP as one autograd node with bf16 rows in between (native/train_ops.py::FieldMlp)
-                rf = field_mlp(pts, inv_head_T, vol, planes, *self._boxes, ws).reshape(B * R, zv.shape[-1], -1)
+                rf = field_mlp(pts, inv_head_T, vol, planes, *self._boxes, ws, ray_rows=rows).reshape(B * R, zv.shape[-1], -1)
             else:
-                X = field_inputs(pts, inv_head_T, vol, planes, *self._boxes)
+                X = field_inputs(pts, inv_head_T, vol, planes, *self._boxes, ray_rows=rows)
                 rf = mc.mlp(X).reshape(B * R, zv.shape[-1], -1).float()      # (bf16 under autocast: the compositing is fp32)
             std = float(opt.radiance_field_noise_std)
             noise = torch.randn(rf.shape[:-1], dtype=rf.dtype, device=rf.device) * std if std > 0.0 else None     # same draw as :56

@@ -47,7 +47,7 @@ class FieldInputs(Function):
     """X [B*N, 2C+48] = cat(triplane(boxwarp(p')), PE(p')),  p' = skinning_field(pts, inv_T, vol).  Gradients: planes_cl, vol."""
 
     @staticmethod
-    def forward(ctx, pts, inv_T, vol, planes_cl, boxes):
+    def forward(ctx, pts, inv_T, vol, planes_cl, boxes, ray_rows=0):
         _need_hip("FieldInputs", pts, inv_T, vol, planes_cl)
         pts, inv_T, vol, planes_cl = pts.contiguous(), inv_T.contiguous(), vol.contiguous(), planes_cl.contiguous()
         p = _field_params(pts, planes_cl, vol, boxes)
@@ -56,19 +56,22 @@ class FieldInputs(Function):
             rc = _lib.lib().hav_field_inputs_fwd(_p(X), C.byref(p), _p(pts), _p(inv_T), _p(vol), _p(planes_cl), _stream())
         _lib.check(rc, "hav_field_inputs_fwd")
         ctx.save_for_backward(pts, inv_T, vol, planes_cl)
-        ctx.boxes = boxes
+        ctx.boxes, ctx.ray_rows = boxes, ray_rows
         return X
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dX):
         pts, inv_T, vol, planes_cl = ctx.saved_tensors
-        dvol, dpl = _field_backward(pts, inv_T, vol, planes_cl, ctx.boxes, dX, ctx.needs_input_grad[2], ctx.needs_input_grad[3])
-        return None, None, dvol, dpl, None
+        dvol, dpl = _field_backward(pts, inv_T, vol, planes_cl, ctx.boxes, dX, ctx.needs_input_grad[2], ctx.needs_input_grad[3],
+                                    ctx.ray_rows)
+        return None, None, dvol, dpl, None, None
 
 
-def _field_backward(pts, inv_T, vol, planes_cl, boxes, dX, need_vol, need_planes):
-    """(dvol, dplanes_cl) of the field inputs from dX [n, 2C+48] float32 (hav_field_inputs_bwd, or its fixed-point form)"""
+def _field_backward(pts, inv_T, vol, planes_cl, boxes, dX, need_vol, need_planes, ray_rows=0):
+    """(dvol, dplanes_cl) of the field inputs from dX [n, 2C+48] float32 (hav_field_inputs_bwd, or its fixed-point form).  ray_rows > 0 =
+    the samples per ray of queries whose neighbouring rays are neighbouring pixels (hav_field_inputs_bwd_rows: the same sums, the scatter
+    merges across 16 rays instead of along one)"""
     p = _field_params(pts, planes_cl, vol, boxes)
     det = deterministic() and p.C <= 64
     mk = torch.empty_like if det else torch.zeros_like          # (the fixed-point route writes every element itself)
@@ -86,6 +89,9 @@ def _field_backward(pts, inv_T, vol, planes_cl, boxes, dX, need_vol, need_planes
                 scratch = torch.empty(int(L.hav_field_inputs_bwd_fixed_scratch_bytes(C.byref(p))), dtype=torch.uint8, device=pts.device)
                 rc = L.hav_field_inputs_bwd_fixed(_p(dpl), _p(dvol), _p(dX), _p(words), _p(scratch), C.byref(p), _p(pts), _p(inv_T), _p(vol),
                                                   _p(planes_cl), _stream())
+            elif ray_rows > 0:
+                rc = L.hav_field_inputs_bwd_rows(_p(dpl), _p(dvol), _p(dX), C.byref(p), _p(pts), _p(inv_T), _p(vol), _p(planes_cl), int(ray_rows),
+                                                 _stream())
             else:
                 rc = L.hav_field_inputs_bwd(_p(dpl), _p(dvol), _p(dX), C.byref(p), _p(pts), _p(inv_T), _p(vol), _p(planes_cl), _stream())
         _lib.check(rc, "hav_field_inputs_bwd")
@@ -100,7 +106,7 @@ class FieldMlp(Function):
     bytes, and kept for the backward at half the memory.  Gradients: vol, planes_cl, the ten MLP tensors."""
 
     @staticmethod
-    def forward(ctx, pts, inv_T, vol, planes_cl, boxes, *weights):
+    def forward(ctx, pts, inv_T, vol, planes_cl, boxes, ray_rows, *weights):
         from . import mlp_train
         _need_hip("FieldMlp", pts, inv_T, vol, planes_cl)
         pts, inv_T, vol, planes_cl = pts.contiguous(), inv_T.contiguous(), vol.contiguous(), planes_cl.contiguous()
@@ -111,7 +117,7 @@ class FieldMlp(Function):
         _lib.check(rc, "hav_field_inputs_fwd_bf16")
         blob = mlp_train.pack(weights)
         ctx.save_for_backward(pts, inv_T, vol, planes_cl, X, blob)
-        ctx.boxes = boxes
+        ctx.boxes, ctx.ray_rows = boxes, ray_rows
         ctx.shapes = [tuple(w.shape) for w in weights]
         return mlp_train.forward_only(X, blob)
 
@@ -122,8 +128,8 @@ class FieldMlp(Function):
         pts, inv_T, vol, planes_cl, X, blob = ctx.saved_tensors
         need_vol, need_pl = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
         dX, grads = mlp_train.backward_only(X, d_rf.contiguous(), blob, ctx.shapes, need_dx=need_vol or need_pl)
-        dvol, dpl = _field_backward(pts, inv_T, vol, planes_cl, ctx.boxes, dX, need_vol, need_pl) if dX is not None else (None, None)
-        return (None, None, dvol, dpl, None) + tuple(grads)
+        dvol, dpl = _field_backward(pts, inv_T, vol, planes_cl, ctx.boxes, dX, need_vol, need_pl, ctx.ray_rows) if dX is not None else (None, None)
+        return (None, None, dvol, dpl, None, None) + tuple(grads)
 
 
 def field_mlp_eligible(planes_nchw, weights):
@@ -132,17 +138,18 @@ def field_mlp_eligible(planes_nchw, weights):
     return planes_nchw.shape[2] == 64 and [tuple(w.shape) for w in weights] == mlp_train._SHAPES
 
 
-def field_mlp(pts, inv_T, vol, planes_nchw, nerf_box, skin_box, weights):
+def field_mlp(pts, inv_T, vol, planes_nchw, nerf_box, skin_box, weights, ray_rows=0):
     """as field_inputs() followed by mlp_train.fused_mlp(): pts [B,N,3] ... -> rf [B*N, 68]"""
     boxes = (tuple(nerf_box[0]), tuple(nerf_box[1]), tuple(skin_box[0]), tuple(skin_box[1]))
-    return FieldMlp.apply(pts, inv_T, vol, planes_nchw.permute(0, 1, 3, 4, 2).contiguous(), boxes, *weights)
+    return FieldMlp.apply(pts, inv_T, vol, planes_nchw.permute(0, 1, 3, 4, 2).contiguous(), boxes, int(ray_rows), *weights)
 
 
-def field_inputs(pts, inv_T, vol, planes_nchw, nerf_box, skin_box):
+def field_inputs(pts, inv_T, vol, planes_nchw, nerf_box, skin_box, ray_rows=0):
     """pts [B,N,3], inv_T [B,4,3], vol [1,2,D,D,D], planes [2,B,C,H,W] (the Trainer's layout), boxes = (scale3, trans3) of the two
-    UniformBoxWarp_new modules -> X [B*N, 2C+48].  The NCHW -> channels-last permutation is a differentiable ATen op."""
+    UniformBoxWarp_new modules -> X [B*N, 2C+48].  The NCHW -> channels-last permutation is a differentiable ATen op.  ray_rows = S when
+    pts is [B, rays, S] flattened and neighbouring rays are neighbouring pixels of an image row (the training patch): a hint for the backward."""
     boxes = (tuple(nerf_box[0]), tuple(nerf_box[1]), tuple(skin_box[0]), tuple(skin_box[1]))
-    return FieldInputs.apply(pts, inv_T, vol, planes_nchw.permute(0, 1, 3, 4, 2).contiguous(), boxes)
+    return FieldInputs.apply(pts, inv_T, vol, planes_nchw.permute(0, 1, 3, 4, 2).contiguous(), boxes, int(ray_rows))
 
 
 class Composite(Function):

@@ -170,6 +170,11 @@ int hav_field_inputs_fwd_bf16(void* Xb, const HavFieldParams* p, const float* pt
                               const float* planes_cl, void* stream);
 int hav_field_inputs_bwd(float* dplanes_cl, float* dvol, const float* dX, const HavFieldParams* p, const float* pts,
                          const float* inv_T, const float* vol, const float* planes_cl, void* stream);
+/* the same for queries laid out [B][rays][samples_per_ray] whose neighbouring rays are neighbouring pixels of an image row (the training patch,
+ * dataloader/dataloader.py:93-121): the scatter merges the taps of 16 neighbouring rays per depth.  Falls back to hav_field_inputs_bwd's order
+ * when the rays per batch element are not a multiple of 16. */
+int hav_field_inputs_bwd_rows(float* dplanes_cl, float* dvol, const float* dX, const HavFieldParams* p, const float* pts,
+                              const float* inv_T, const float* vol, const float* planes_cl, int samples_per_ray, void* stream);
 /* Bit-reproducible form of hav_field_inputs_bwd (ABI 6): the same gradients, summed as 64-bit fixed-point integers with integer atomics
  * (integer addition is associative: the result does not depend on the order the atomics land in; float atomics do).  dx_amax: the
  * HAV_ABSMAX_WORDS words of hav_absmax(dX) (the planes' scale; the volume taps are buffered and scaled by their own maximum).  scratch:

@@ -1538,3 +1538,29 @@ def test_native_install_registers_the_bare_module_names_the_reference_imports():
     gi = upfirdn2d_op.upfirdn2d(_t(go), _t(grad_kernel), down_x, down_y, up_x, up_y, g_pad_x0, g_pad_x1, g_pad_y0, g_pad_y1)
     gio = oracle.upfirdn2d(go, grad_kernel, down_x, down_y, up_x, up_y, g_pad_x0, g_pad_x1, g_pad_y0, g_pad_y1)
     assert gi.shape == (6, in_h, in_w, 1) and linf(gi.cpu().numpy(), gio) <= 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("side,S", [(64, 112), (16, 37), (12, 20)])
+def test_field_inputs_bwd_rows_equals_ray_major(side, S):
+    """hav_field_inputs_bwd_rows (the scatter merges 16 neighbouring rays per depth: the training patch) sums the same terms as
+    hav_field_inputs_bwd (16 depths per ray): gradients agree to the rounding of the atomics' order.  12 x 12 rays = 144 per frame is a
+    multiple of 16, 16 x 16 with S = 37 an odd depth count; a ray count that is no multiple of 16 must fall back (identical route)."""
+    import importlib.util
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bench_field_rows.py")
+    spec = importlib.util.spec_from_file_location("bench_field_rows", tool)
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    dev = torch.device("cuda:0")
+    planes, vol, pts, inv_T, up = m.problem(dev, S=S, side=side)
+    _, (gp0, gv0) = m.gradients(planes, vol, pts, inv_T, up, 0)
+    _, (gp1, gv1) = m.gradients(planes, vol, pts, inv_T, up, S)
+    assert gp0.abs().max() > 0 and gv0.abs().max() > 0
+    assert (gp0 - gp1).abs().max() <= 2e-5 * gp0.abs().max(), ((gp0 - gp1).abs().max().item(), gp0.abs().max().item())
+    assert (gv0 - gv1).abs().max() <= 2e-5 * gv0.abs().max(), ((gv0 - gv1).abs().max().item(), gv0.abs().max().item())
+    # every texel the one route touches the other touches too
+    assert torch.equal(gp0 != 0, gp1 != 0) or ((gp0 != 0) ^ (gp1 != 0)).sum().item() <= 1e-5 * gp0.numel()
+    # rays per frame no multiple of 16: the hint is ignored
+    planes, vol, pts, inv_T, up = m.problem(dev, S=8, side=5)
+    _, (a0, b0) = m.gradients(planes, vol, pts, inv_T, up, 0)
+    _, (a1, b1) = m.gradients(planes, vol, pts, inv_T, up, 8)
+    assert (a0 - a1).abs().max() <= 2e-5 * a0.abs().max() and (b0 - b1).abs().max() <= 2e-5 * b0.abs().max()
