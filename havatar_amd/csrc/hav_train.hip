@@ -1017,3 +1017,92 @@ extern "C" int hav_col2im3d(float* dx, const float* dcol, int C, int R, void* st
     return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Importance resampling of the training pass (model/nerf_trainer.py:166-170 + utils/nerf_util.py:76-117 of the reference):
+//   z_mid = .5 (z[1:] + z[:-1]);  z_s = sample_pdf(z_mid, weights[1:-1], S_f, det);  z2 = sort(cat(z[::2], z_s))
+// as ONE launch instead of ~30 ATen launches (add, sum, div, cumsum, cat, arange / rand arithmetic, searchsorted, clamps, stack,
+// 2 x gather, where, sub / div / mul / add, slice, cat, sort).  No gradient flows through it (the reference detaches z_samples).
+// One wave per ray; the ray's depths, weights, CDF and the merged candidate list live in the wave's own LDS rows.
+//   * sum and cumulative sum: sequential on lane 0 in index order -- the order of the CPU statement the oracle restates (SURVEY B-11);
+//     ATen's device reductions use a tree whose shape depends on the launch geometry, there is no canonical order to match
+//   * every other product / sum is rounded separately like the ATen element-wise ops (no contraction into FMAs)
+//   * searchsorted(right=True) is a count of cdf[i] <= u over the nb entries; the sort is a rank sort (stable on ties, so the
+//     output equals torch.sort's values)
+// ------------------------------------------------------------------------------------------------
+#define RS_MAX 128
+struct ResampleArgs {
+    float* z2; float* zs; const float* z; const float* w; const float* zeta;
+    int64_t n; int S_c, S_f; float u_sN, u_w, u_st;
+};
+__global__ void __launch_bounds__(256) resample_depths_kernel(ResampleArgs a)
+{
+    __shared__ float s_z[4][RS_MAX], s_w[4][RS_MAX], s_cdf[4][RS_MAX], s_cand[4][RS_MAX];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int S_c = a.S_c, S_f = a.S_f, nb = S_c - 1, nw = S_c - 2, S_half = (S_c + 1) >> 1, S_fp = S_half + S_f;
+    float* zc = s_z[wv]; float* w = s_w[wv]; float* cdf = s_cdf[wv]; float* cand = s_cand[wv];
+    for (int64_t r = (int64_t)blockIdx.x * 4 + wv; r < a.n; r += (int64_t)gridDim.x * 4) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < S_c; i += 64) { zc[i] = a.z[r * S_c + i]; w[i] = __fadd_rn(a.w[r * S_c + i], 1e-5f); }   // :79
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            float sum = 0.f;
+            for (int i = 0; i < nw; ++i) sum = __fadd_rn(sum, w[1 + i]);                        // :80
+            float run = 0.f;
+            cdf[0] = 0.f;
+            for (int i = 0; i < nw; ++i) { run = __fadd_rn(run, __fdiv_rn(w[1 + i], sum)); cdf[i + 1] = run; }   // :80-84
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int k = lane; k < S_f; k += 64) {
+            float u;
+            if (!a.zeta)         // det: torch.linspace(0, 1, S_f) -- start + step k below the middle, end - step (S_f-1-k) above it
+                u = (S_f == 1) ? 0.f : ((k < S_f / 2) ? __fmul_rn(a.u_st, (float)k) : __fsub_rn(1.0f, __fmul_rn(a.u_st, (float)(S_f - 1 - k))));
+            else                 // arange * s + rand * (s - 1e-6)   (:93-95)
+                u = __fadd_rn(__fmul_rn((float)k, a.u_sN), __fmul_rn(a.zeta[r * S_f + k], a.u_w));
+            int inds = 0;                                                                       // :102
+            for (int i = 0; i < nb; ++i) inds += (cdf[i] <= u) ? 1 : 0;
+            const int below = max(inds - 1, 0), above = min(inds, nb - 1);                      // :103-104
+            const float c0 = cdf[below], c1 = cdf[above];
+            float dnm = __fsub_rn(c1, c0);                                                      // :112
+            if (dnm < 1e-5f) dnm = 1.0f;                                                        // :113
+            const float tt = __fdiv_rn(__fsub_rn(u, c0), dnm);                                  // :114
+            const float bl = __fmul_rn(0.5f, __fadd_rn(zc[below + 1], zc[below]));              // z_vals_mid (nerf_trainer.py:166)
+            const float ba = __fmul_rn(0.5f, __fadd_rn(zc[above + 1], zc[above]));
+            const float v = __fadd_rn(bl, __fmul_rn(tt, __fsub_rn(ba, bl)));                    // :115
+            cand[S_half + k] = v;
+            if (a.zs) a.zs[r * S_f + k] = v;
+        }
+        for (int i = lane; i < S_half; i += 64) cand[i] = zc[2 * i];                            // z_vals[:, ::2]
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int e = lane; e < S_fp; e += 64) {
+            const float v = cand[e];
+            int rank = 0;
+            for (int q = 0; q < S_fp; ++q) {
+                const float o = cand[q];
+                rank += (o < v || (o == v && q < e)) ? 1 : 0;
+            }
+            a.z2[r * S_fp + rank] = v;
+        }
+    }
+}
+extern "C" int hav_resample_depths(float* z2, float* z_samples, const float* z, const float* weights, const float* zeta, int64_t n_rays,
+                                   int S_c, int S_f, void* stream)
+{
+    if (!z2 || !z || !weights || n_rays < 0 || S_c < 3 || S_f < 1) return HAV_EINVAL;
+    if (S_c > RS_MAX || ((S_c + 1) >> 1) + S_f > RS_MAX) return HAV_EUNSUP;
+    if (n_rays == 0) return 0;
+    ResampleArgs a{};
+    a.z2 = z2; a.zs = z_samples; a.z = z; a.w = weights; a.zeta = zeta; a.n = n_rays; a.S_c = S_c; a.S_f = S_f;
+    a.u_sN = (float)(1.0 / (double)S_f);                 // s = 1 / num_samples is a Python double, cast at the multiplication
+    a.u_w = (float)(1.0 / (double)S_f - 1e-6);
+    a.u_st = S_f > 1 ? 1.0f / (float)(S_f - 1) : 0.f;    // torch.linspace's step, computed in float
+    int64_t blocks = (n_rays + 3) / 4;
+    const int64_t cap = (int64_t)hav_num_cus() * 32;
+    hipLaunchKernelGGL(resample_depths_kernel, dim3((unsigned)(blocks > cap ? cap : blocks)), dim3(256), 0, (hipStream_t)stream, a);
+    HAV_LAUNCH_CHECK();
+    return 0;
+}

@@ -212,8 +212,20 @@ class Trainer(torch.nn.Module):
         if opt.num_fine <= 0:
             return rs(rgb_c), rs(depth_c), rs(acc_c), rs(weights.max(dim=-1)[0]), None, None, None
         zf = z.reshape(-1, z.shape[-1])
-        z_mid = 0.5 * (zf[..., 1:] + zf[..., :-1])
-        z_s = sample_pdf(z_mid, weights[..., 1:-1], opt.num_fine, det=(opt.perturb == 0.0)).detach()
-        z2, _ = torch.sort(torch.cat((zf[:, ::2], z_s), dim=-1), dim=-1)
+        if fused and 3 <= zf.shape[-1] <= 128 and os.environ.get("HAVATAR_RESAMPLE", "hip") != "aten":
+            # the three statements + sample_pdf as one launch (hav_resample_depths; ~30 ATen launches otherwise).  The stratified
+            # draw is made here exactly where sample_pdf makes it (utils/nerf_util.py:95: on the CPU generator; on the device
+            # generator while a training step is being captured, like utils/nerf_util.py::sample_pdf of this package)
+            from ..native.train_ops import resample_depths
+            zeta = None
+            if opt.perturb != 0.0:
+                shape = [zf.shape[0], int(opt.num_fine)]
+                zeta = (torch.rand(shape, dtype=zf.dtype, device=zf.device) if torch.cuda.is_current_stream_capturing()
+                        else torch.rand(shape, dtype=zf.dtype).to(zf.device))
+            z2 = resample_depths(zf, weights, opt.num_fine, zeta)
+        else:
+            z_mid = 0.5 * (zf[..., 1:] + zf[..., :-1])
+            z_s = sample_pdf(z_mid, weights[..., 1:-1], opt.num_fine, det=(opt.perturb == 0.0)).detach()
+            z2, _ = torch.sort(torch.cat((zf[:, ::2], z_s), dim=-1), dim=-1)
         rgb_f, _, acc_f, weights, depth_f = one_pass(z2.reshape(B, R, -1))
         return rs(rgb_c), rs(depth_c), rs(acc_c), rs(weights.max(dim=-1)[0]), rs(rgb_f), rs(depth_f), rs(acc_f)

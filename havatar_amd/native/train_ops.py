@@ -196,6 +196,26 @@ def composite(rf, z, rd, noise=None, bg=None, n_sigmoid=3):
     return Composite.apply(rf, z, rd, noise, bg, n_sigmoid)
 
 
+def resample_depths(z, weights, num_fine, zeta=None, return_samples=False):
+    """z2 [n, ceil(S_c/2)+num_fine] = sort(cat(z[:, ::2], sample_pdf(z_mid, weights[:, 1:-1], num_fine))) -- the statements of
+    model/nerf_trainer.py:166-170 + utils/nerf_util.py:76-117 of the reference as one launch (hav_resample_depths).  z, weights
+    [n, S_c] HIP float32; zeta [n, num_fine] = the raw torch.rand draw (the caller makes it, in the reference's order), None =
+    det=True.  No gradient, like the reference's .detach()."""
+    _need_hip("resample_depths", z, weights, zeta)
+    z, weights = z.detach().contiguous(), weights.detach().contiguous()
+    zeta = zeta.detach().contiguous() if zeta is not None else None
+    n, S_c = z.shape
+    num_fine = int(num_fine)
+    if weights.shape != (n, S_c) or (zeta is not None and zeta.shape != (n, num_fine)):
+        raise RuntimeError("resample_depths: z, weights [n,S_c], zeta [n,num_fine]")
+    z2 = torch.empty(n, (S_c + 1) // 2 + num_fine, device=z.device, dtype=torch.float32)
+    zs = torch.empty(n, num_fine, device=z.device, dtype=torch.float32) if return_samples else None
+    with torch.cuda.device(z.device):
+        rc = _lib.lib().hav_resample_depths(_p(z2), _p(zs), _p(z), _p(weights), _p(zeta), n, S_c, num_fine, _stream())
+    _lib.check(rc, "hav_resample_depths")
+    return (z2, zs) if return_samples else z2
+
+
 class Upsample3d2x(Function):
     """nn.Upsample(scale_factor=2, mode='trilinear', align_corners=False) on a float32 HIP tensor [N,C,D,H,W]: one launch forward,
     one backward (hav_upsample3d_2x_*), instead of the ~30 / ~60 ATen launches of the slice-and-lerp statement."""

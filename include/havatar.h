@@ -187,6 +187,17 @@ int hav_composite_fwd(float* rgb, float* acc, float* weights, float* depth, cons
 int hav_composite_bwd(float* d_rf, const float* d_rgb, const float* d_acc, const float* d_weights, const float* d_depth,
                       const float* rf, const float* z, const float* rd, const float* noise, const float* bg, int64_t n_rays,
                       int S, int CH, int n_sigmoid, void* stream);
+/* Importance resampling between the two passes under autograd (added within ABI 6: additive) -- replaces the ATen chain of
+ * model/nerf_trainer.py:166-170 (z_vals_mid, sample_pdf, z_samples.detach(), cat with z_vals[::2], sort) and utils/nerf_util.py:76-117
+ * (sample_pdf: +1e-5, sum, cumsum, stratified or linspace u, searchsorted(right), clamped gathers, the 1e-5 denominator floor):
+ *   z2 [n, ceil(S_c/2) + S_f] = sort(cat(z[:, ::2], z_samples)),  z_samples [n, S_f] (nullable output)
+ * z, weights [n, S_c]: the coarse pass' depths and compositing weights (weights[:, 1:-1] are the ones used).  zeta [n, S_f] = the
+ * raw torch.rand draw of utils/nerf_util.py:95 (u = k * (1/S_f) + zeta * (1/S_f - 1e-6), the library never draws random numbers
+ * here), NULL = det=True (u = linspace(0, 1, S_f)).  Sum / cumulative sum run in index order (what the oracle restates); every
+ * other operation is rounded separately like the ATen statement: bit-exact against orc_resample_depths_f32.  No gradient (the
+ * reference detaches).  S_c >= 3, S_c <= 128, ceil(S_c/2) + S_f <= 128 (else HAV_EUNSUP). */
+int hav_resample_depths(float* z2, float* z_samples, const float* z, const float* weights, const float* zeta, int64_t n_rays,
+                        int S_c, int S_f, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * 3x3, stride-1, zero-padded convolution of the StyleGAN blocks with the block's glue fused in -- replaces, at

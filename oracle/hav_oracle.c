@@ -171,6 +171,66 @@ int orc_gen_rays_f32(float* rays, int H, int W, const float intr[4], const float
     return 0;
 }
 
+/* ---- importance resampling between the two passes of the training forward --------------------------------
+ * model/nerf_trainer.py:166-170 (z_vals_mid, sample_pdf, cat with z_vals[::2], sort) + utils/nerf_util.py:76-117 (sample_pdf),
+ * one ray at a time.  Statement for statement like the PyTorch code: every product / sum rounded on its own (the function is
+ * compiled without FMA contraction -- ATen's element-wise ops do not fuse across statements); sum and cumsum in index order
+ * (the CPU cumsum's order; SURVEY B-11).  z, w [n,S_c]; zeta [n,S_f] raw torch.rand values or NULL (det=True);
+ * zs [n,S_f] (nullable), z2 [n, ceil(S_c/2)+S_f]. */
+#define DEF_RESAMPLE(NAME, T)                                                                                       \
+    static int NAME##_cmp(const void* a, const void* b)                                                             \
+    {                                                                                                               \
+        T x = *(const T*)a, y = *(const T*)b;                                                                       \
+        return (x > y) - (x < y);                                                                                   \
+    }                                                                                                               \
+    __attribute__((optimize("fp-contract=off"))) int NAME(const T* z, const T* w, int64_t n, int S_c, int S_f,      \
+                                                          const float* zeta, T* zs, T* z2)                          \
+    {                                                                                                               \
+        if (!z || !w || !z2 || S_c < 3 || S_f < 1 || S_c > 4096 || S_f > 4096) return HAV_EINVAL;                   \
+        const int nb = S_c - 1, nw = S_c - 2, S_half = (S_c + 1) / 2, S_fp = S_half + S_f;                          \
+        T* cdf = (T*)malloc(sizeof(T) * (size_t)(nb + S_c + S_fp));                                                 \
+        T* wp = cdf + nb;                                                                                           \
+        T* cand = wp + S_c;                                                                                         \
+        for (int64_t r = 0; r < n; ++r) {                                                                           \
+            const T* zr = z + (size_t)r * S_c;                                                                      \
+            T sum = 0;                                                                                              \
+            for (int i = 0; i < nw; ++i) { wp[i] = w[(size_t)r * S_c + 1 + i] + (T)1e-5; sum = sum + wp[i]; } /* :79-80 */ \
+            T run = 0;                                                                                              \
+            cdf[0] = 0;                                                                                             \
+            for (int i = 0; i < nw; ++i) { T pdf = wp[i] / sum; run = run + pdf; cdf[i + 1] = run; }   /* :80-84 */ \
+            for (int k = 0; k < S_f; ++k) {                                                                         \
+                T u;                                                                                                \
+                if (!zeta) {                                            /* torch.linspace(0, 1, S_f), :87-90 */     \
+                    T step = (T)1 / (T)(S_f - 1), lo_ = step * (T)k, hi_ = step * (T)(S_f - 1 - k);                 \
+                    u = (S_f == 1) ? (T)0 : ((k < S_f / 2) ? lo_ : (T)1 - hi_);                                     \
+                } else {                                                /* arange * s (a FLOAT32 tensor whatever the weights' dtype) + rand * (s - 1e-6), :93-95 */ \
+                    T a_ = (T)((float)k * (float)(1.0 / (double)S_f)), b_ = (T)zeta[(size_t)r * S_f + k] * (T)(1.0 / (double)S_f - 1e-6); \
+                    u = a_ + b_;                                                                                    \
+                }                                                                                                   \
+                int inds = 0;                                           /* searchsorted(right=True), :102 */        \
+                while (inds < nb && cdf[inds] <= u) ++inds;                                                         \
+                int below = inds - 1 < 0 ? 0 : inds - 1, above = inds > nb - 1 ? nb - 1 : inds;   /* :103-104 */    \
+                T den = cdf[above] - cdf[below];                                                                    \
+                if (den < (T)1e-5) den = 1;                             /* :112-113 */                              \
+                T num = u - cdf[below];                                                                             \
+                T t = num / den;                                                                                    \
+                T sb = zr[below + 1] + zr[below], sa = zr[above + 1] + zr[above];                                   \
+                T bl = (T)0.5 * sb, ba = (T)0.5 * sa;                   /* z_vals_mid, nerf_trainer.py:166 */       \
+                T d_ = ba - bl, m_ = t * d_;                                                                        \
+                T v = bl + m_;                                          /* :114-115 */                              \
+                cand[S_half + k] = v;                                                                               \
+                if (zs) zs[(size_t)r * S_f + k] = v;                                                                \
+            }                                                                                                       \
+            for (int i = 0; i < S_half; ++i) cand[i] = zr[2 * i];       /* z_vals[:, ::2], nerf_trainer.py:170 */   \
+            qsort(cand, (size_t)S_fp, sizeof(T), NAME##_cmp);                                                       \
+            for (int i = 0; i < S_fp; ++i) z2[(size_t)r * S_fp + i] = cand[i];                                      \
+        }                                                                                                           \
+        free(cdf);                                                                                                  \
+        return 0;                                                                                                   \
+    }
+DEF_RESAMPLE(orc_resample_depths_f32, float)
+DEF_RESAMPLE(orc_resample_depths_f64, double)
+
 double orc_now(void)
 {
     struct timespec ts;

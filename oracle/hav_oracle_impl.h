@@ -216,8 +216,9 @@ static void SUF(sample_pdf)(const REAL* bins, const REAL* weights, int nb, int n
             if (ns == 1) u = 0;
         } else {
             /* s = 1/ns is a Python double; arange*s and rand*(s-1e-6) are float32 ops on the casted scalars (:93-95) */
-            REAL sN = (REAL)(1.0 / (double)ns);
-            u = (REAL)k * sN + (REAL)zeta[k] * (REAL)(1.0 / (double)ns - 1e-6);
+            /* torch.arange(ns) * s is a float32 tensor whatever the weights' dtype (int64 tensor x Python scalar) */
+            REAL kN = (REAL)((float)k * (float)(1.0 / (double)ns));
+            u = kN + (REAL)zeta[k] * (REAL)(1.0 / (double)ns - 1e-6);
         }
         int inds = 0;                                                            /* searchsorted(right=True), :102 */
         while (inds < nb && cdf[inds] <= u) ++inds;

@@ -179,3 +179,19 @@ def gen_rays(H, W, intr, c2w, near, far, y0=0, y1=None):
     if rc != 0:
         raise RuntimeError(f"orc_gen_rays failed: {rc}")
     return out
+
+
+def resample_depths(z, weights, S_f, zeta=None, dtype=np.float32):
+    """(z_samples [n,S_f], z2 [n, ceil(S_c/2)+S_f]) of model/nerf_trainer.py:166-170 + utils/nerf_util.py:76-117; zeta = the raw
+    torch.rand draw [n,S_f] or None (det=True)."""
+    z = np.ascontiguousarray(z, dtype)
+    weights = np.ascontiguousarray(weights, dtype)
+    n, S_c = z.shape
+    zs = np.empty((n, S_f), dtype)
+    z2 = np.empty((n, (S_c + 1) // 2 + S_f), dtype)
+    zt = None if zeta is None else np.ascontiguousarray(zeta, np.float32)
+    fn = lib().orc_resample_depths_f32 if dtype == np.float32 else lib().orc_resample_depths_f64
+    rc = fn(_p(z), _p(weights), C.c_int64(n), S_c, S_f, _p(zt) if zt is not None else None, _p(zs), _p(z2))
+    if rc != 0:
+        raise RuntimeError(f"orc_resample_depths failed: {rc}")
+    return zs, z2

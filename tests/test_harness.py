@@ -391,6 +391,33 @@ def test_training_step_gpu_fused_field_ops_equal_the_aten_statement(dataset, gol
 
 
 @pytest.mark.gpu
+def test_training_step_gpu_resampling_kernel_equals_the_aten_statement(dataset, gold, monkeypatch):
+    """The same jittered, noisy step (same host / device RNG streams: hav_resample_depths takes the draw sample_pdf would make) with the
+    importance resampling as one launch and as the ATen statement of model/nerf_trainer.py:166-170: loss and parts agree to 1e-5, gradients
+    to the 2e-2 two statements of the coarse-to-fine hand-over agree to (the fine pass amplifies rounding of the CDF, SURVEY B-11)."""
+    from havatar_amd.native import train_ops
+    runs, calls = [], []
+    real = train_ops.resample_depths
+    monkeypatch.setattr(train_ops, "resample_depths", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    monkeypatch.setenv("HAVATAR_TRAIN_MLP", "torch")
+    for flag in ("aten", "hip"):
+        monkeypatch.setenv("HAVATAR_RESAMPLE", flag)
+        trainer, loss, parts, _ = _train_step(dataset, gold, "rnd", "cuda")
+        grads = {n: p.grad.detach().clone() for n, p in trainer.named_parameters() if p.grad is not None}
+        runs.append((loss.item(), {k: v.item() for k, v in parts.items()}, grads, len(calls)))
+    (l0, p0, g0, c0), (l1, p1, g1, c1) = runs
+    assert c0 == 0 and c1 >= 1                       # the kernel is what ran in the second step
+    assert abs(l0 - l1) <= 1e-5 * abs(l0)
+    for k in p0:
+        assert abs(p0[k] - p1[k]) <= 1e-5 * max(abs(p0[k]), 1e-3), k
+    for n in g0:
+        if n.startswith("headpose_skin_net.canonical_Wvolume.filters") and n.endswith(".bias"):
+            continue
+        scale = g0[n].abs().max().item()
+        assert (g0[n] - g1[n]).abs().max().item() <= 2e-2 * scale + 1e-12, n
+
+
+@pytest.mark.gpu
 def test_training_steps_as_one_hipgraph_launch_follow_the_eager_trajectory(dataset, gold, monkeypatch):
     """graph.GraphedTrainStep: forward + backward + Adam of a deterministic-depth step replayed as one graph.  Six steps from the
     same initial state, eager vs (2 eager + 4 replayed): the loss curves agree, the parameters end up equal, and the
