@@ -1037,6 +1037,7 @@ struct ResampleArgs {
 };
 __global__ void __launch_bounds__(256) resample_depths_kernel(ResampleArgs a)
 {
+#pragma clang fp contract(off)      // plain operators below, none fused (the __f*_rn intrinsics are inline operators compiled with contraction on)
     __shared__ float s_z[4][RS_MAX], s_w[4][RS_MAX], s_cdf[4][RS_MAX], s_cand[4][RS_MAX];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int S_c = a.S_c, S_f = a.S_f, nb = S_c - 1, nw = S_c - 2, S_half = (S_c + 1) >> 1, S_fp = S_half + S_f;
@@ -1044,34 +1045,34 @@ __global__ void __launch_bounds__(256) resample_depths_kernel(ResampleArgs a)
     for (int64_t r = (int64_t)blockIdx.x * 4 + wv; r < a.n; r += (int64_t)gridDim.x * 4) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        for (int i = lane; i < S_c; i += 64) { zc[i] = a.z[r * S_c + i]; w[i] = __fadd_rn(a.w[r * S_c + i], 1e-5f); }   // :79
+        for (int i = lane; i < S_c; i += 64) { zc[i] = a.z[r * S_c + i]; w[i] = a.w[r * S_c + i] + 1e-5f; }   // :79
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) {
             float sum = 0.f;
-            for (int i = 0; i < nw; ++i) sum = __fadd_rn(sum, w[1 + i]);                        // :80
+            for (int i = 0; i < nw; ++i) sum = sum + w[1 + i];                        // :80
             float run = 0.f;
             cdf[0] = 0.f;
-            for (int i = 0; i < nw; ++i) { run = __fadd_rn(run, __fdiv_rn(w[1 + i], sum)); cdf[i + 1] = run; }   // :80-84
+            for (int i = 0; i < nw; ++i) { const float pdf = w[1 + i] / sum; run = run + pdf; cdf[i + 1] = run; }   // :80-84
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         for (int k = lane; k < S_f; k += 64) {
             float u;
             if (!a.zeta)         // det: torch.linspace(0, 1, S_f) -- start + step k below the middle, end - step (S_f-1-k) above it
-                u = (S_f == 1) ? 0.f : ((k < S_f / 2) ? __fmul_rn(a.u_st, (float)k) : __fsub_rn(1.0f, __fmul_rn(a.u_st, (float)(S_f - 1 - k))));
+                { const float lo = a.u_st * (float)k, hi = a.u_st * (float)(S_f - 1 - k); u = (S_f == 1) ? 0.f : ((k < S_f / 2) ? lo : 1.0f - hi); }
             else                 // arange * s + rand * (s - 1e-6)   (:93-95)
-                u = __fadd_rn(__fmul_rn((float)k, a.u_sN), __fmul_rn(a.zeta[r * S_f + k], a.u_w));
+                { const float ks = (float)k * a.u_sN, zw = a.zeta[r * S_f + k] * a.u_w; u = ks + zw; }
             int inds = 0;                                                                       // :102
             for (int i = 0; i < nb; ++i) inds += (cdf[i] <= u) ? 1 : 0;
             const int below = max(inds - 1, 0), above = min(inds, nb - 1);                      // :103-104
             const float c0 = cdf[below], c1 = cdf[above];
-            float dnm = __fsub_rn(c1, c0);                                                      // :112
+            float dnm = c1 - c0;                                                      // :112
             if (dnm < 1e-5f) dnm = 1.0f;                                                        // :113
-            const float tt = __fdiv_rn(__fsub_rn(u, c0), dnm);                                  // :114
-            const float bl = __fmul_rn(0.5f, __fadd_rn(zc[below + 1], zc[below]));              // z_vals_mid (nerf_trainer.py:166)
-            const float ba = __fmul_rn(0.5f, __fadd_rn(zc[above + 1], zc[above]));
-            const float v = __fadd_rn(bl, __fmul_rn(tt, __fsub_rn(ba, bl)));                    // :115
+            const float num = u - c0, tt = num / dnm;                                  // :114
+            const float sb = zc[below + 1] + zc[below], bl = 0.5f * sb;              // z_vals_mid (nerf_trainer.py:166)
+            const float sa = zc[above + 1] + zc[above], ba = 0.5f * sa;
+            const float dd = ba - bl, md = tt * dd, v = bl + md;                    // :115
             cand[S_half + k] = v;
             if (a.zs) a.zs[r * S_f + k] = v;
         }
@@ -1092,9 +1093,10 @@ __global__ void __launch_bounds__(256) resample_depths_kernel(ResampleArgs a)
 extern "C" int hav_resample_depths(float* z2, float* z_samples, const float* z, const float* weights, const float* zeta, int64_t n_rays,
                                    int S_c, int S_f, void* stream)
 {
-    if (!z2 || !z || !weights || n_rays < 0 || S_c < 3 || S_f < 1) return HAV_EINVAL;
+    if (n_rays < 0 || S_c < 3 || S_f < 1) return HAV_EINVAL;
     if (S_c > RS_MAX || ((S_c + 1) >> 1) + S_f > RS_MAX) return HAV_EUNSUP;
-    if (n_rays == 0) return 0;
+    if (n_rays == 0) return 0;                           // (an empty tensor's pointer is null)
+    if (!z2 || !z || !weights) return HAV_EINVAL;
     ResampleArgs a{};
     a.z2 = z2; a.zs = z_samples; a.z = z; a.w = weights; a.zeta = zeta; a.n = n_rays; a.S_c = S_c; a.S_f = S_f;
     a.u_sN = (float)(1.0 / (double)S_f);                 // s = 1 / num_samples is a Python double, cast at the multiplication
