@@ -1027,8 +1027,8 @@ extern "C" int hav_col2im3d(float* dx, const float* dcol, int C, int R, void* st
 //   * sum and cumulative sum: sequential on lane 0 in index order -- the order of the CPU statement the oracle restates (SURVEY B-11);
 //     ATen's device reductions use a tree whose shape depends on the launch geometry, there is no canonical order to match
 //   * every other product / sum is rounded separately like the ATen element-wise ops (no contraction into FMAs)
-//   * searchsorted(right=True) is a count of cdf[i] <= u over the nb entries; the sort is a rank sort (stable on ties, so the
-//     output equals torch.sort's values)
+//   * the pdf's divisions run one per lane between the two sequential passes; searchsorted(right=True) is a binary search (the CDF of
+//     non-negative weights is non-decreasing in fp32 too); the sort is a rank sort (stable on ties: the output equals torch.sort's values)
 // ------------------------------------------------------------------------------------------------
 #define RS_MAX 128
 struct ResampleArgs {
@@ -1048,12 +1048,23 @@ __global__ void __launch_bounds__(256) resample_depths_kernel(ResampleArgs a)
         for (int i = lane; i < S_c; i += 64) { zc[i] = a.z[r * S_c + i]; w[i] = a.w[r * S_c + i] + 1e-5f; }   // :79
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (lane == 0) {
+        if (lane == 0) {                                   // sum in index order; w[0] (not part of weights[1:-1]) carries it to the other lanes
             float sum = 0.f;
-            for (int i = 0; i < nw; ++i) sum = sum + w[1 + i];                        // :80
+            for (int i = 0; i < nw; ++i) sum = sum + w[1 + i];                                  // :80
+            w[0] = sum;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        {
+            const float sum = w[0];
+            for (int i = lane; i < nw; i += 64) w[1 + i] = w[1 + i] / sum;                      // pdf, :80 (one division per lane)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {                                   // cumulative sum in index order, :81-84
             float run = 0.f;
             cdf[0] = 0.f;
-            for (int i = 0; i < nw; ++i) { const float pdf = w[1 + i] / sum; run = run + pdf; cdf[i + 1] = run; }   // :80-84
+            for (int i = 0; i < nw; ++i) { run = run + w[1 + i]; cdf[i + 1] = run; }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1063,8 +1074,8 @@ __global__ void __launch_bounds__(256) resample_depths_kernel(ResampleArgs a)
                 { const float lo = a.u_st * (float)k, hi = a.u_st * (float)(S_f - 1 - k); u = (S_f == 1) ? 0.f : ((k < S_f / 2) ? lo : 1.0f - hi); }
             else                 // arange * s + rand * (s - 1e-6)   (:93-95)
                 { const float ks = (float)k * a.u_sN, zw = a.zeta[r * S_f + k] * a.u_w; u = ks + zw; }
-            int inds = 0;                                                                       // :102
-            for (int i = 0; i < nb; ++i) inds += (cdf[i] <= u) ? 1 : 0;
+            int inds = 0, hi_ = nb;                        // :102 searchsorted(right=True): the CDF is non-decreasing (pdf >= 0)
+            while (inds < hi_) { const int mid = (inds + hi_) >> 1; if (cdf[mid] <= u) inds = mid + 1; else hi_ = mid; }
             const int below = max(inds - 1, 0), above = min(inds, nb - 1);                      // :103-104
             const float c0 = cdf[below], c1 = cdf[above];
             float dnm = c1 - c0;                                                      // :112
