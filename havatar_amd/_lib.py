@@ -113,6 +113,10 @@ def lib():
     L.hav_composite_bwd.restype = i32
     L.hav_resample_depths.argtypes = [vp] * 5 + [i64, i32, i32, vp]
     L.hav_resample_depths.restype = i32
+    L.hav_equal_linear_fwd.argtypes = [vp] * 4 + [C.c_float, C.c_float, i32, i32, i32, vp]
+    L.hav_equal_linear_fwd.restype = i32
+    L.hav_equal_linear_bwd.argtypes = [vp] * 6 + [C.c_float, C.c_float, i32, i32, i32, vp]
+    L.hav_equal_linear_bwd.restype = i32
     L.hav_mlp_blob_bytes.restype = i64
     L.hav_mlp_pack.argtypes = [vp, C.POINTER(HavMlpWeights), vp]
     L.hav_mlp_pack.restype = i32

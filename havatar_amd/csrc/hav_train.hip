@@ -1119,3 +1119,84 @@ extern "C" int hav_resample_depths(float* z2, float* z_samples, const float* z, 
     HAV_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// EqualLinear without activation under autograd (model/styleUnet.py:128-162 of the reference: F.linear(x, weight * scale, bias * lr_mul)) --
+// the modulation layer of every ModulatedConv2d: x [B, in] (B <= 8, in = the style width, 32 on this path), W [out, in].  The ATen
+// statement is 3 launches forward (two scalar products over the parameters, addmm) and 6-7 backward (two products, two GEMMs, a sum,
+// accumulation) per layer, 26 layers per optimisation step: one launch each way here.
+//   forward : y[b,o] = sum_i x[b,i] * fl(W[o,i] * scale) + fl(bias[o] * lr_mul)          (products of the scaled weight, like the reference)
+//   backward: dW[o,i] = scale * sum_b dy[b,o] x[b,i];  db[o] = lr_mul * sum_b dy[b,o];  dx[b,i] = sum_o dy[b,o] * fl(W[o,i] * scale)
+// All sums run in a fixed order (bit-reproducible); dx is a wave per (b, i) with a fixed butterfly.
+// ------------------------------------------------------------------------------------------------
+#define EQL_MAXB 8
+struct EqLinArgs {
+    float* y; float* dx; float* dW; float* db;
+    const float* x; const float* W; const float* b; const float* dy;
+    float scale, lr_mul; int B, in, out, nA;
+};
+__global__ void __launch_bounds__(64) equal_linear_fwd_kernel(EqLinArgs a)
+{
+    const int o = blockIdx.x * 64 + threadIdx.x;
+    if (o >= a.out) return;
+    float acc[EQL_MAXB];
+#pragma unroll
+    for (int b = 0; b < EQL_MAXB; ++b) acc[b] = 0.f;
+    const float* wr = a.W + (size_t)o * a.in;
+    for (int i = 0; i < a.in; ++i) {
+        const float w = wr[i] * a.scale;
+#pragma unroll
+        for (int b = 0; b < EQL_MAXB; ++b)
+            if (b < a.B) acc[b] = fmaf(a.x[b * a.in + i], w, acc[b]);
+    }
+    const float bias = a.b ? a.b[o] * a.lr_mul : 0.f;
+#pragma unroll
+    for (int b = 0; b < EQL_MAXB; ++b)
+        if (b < a.B) a.y[(size_t)b * a.out + o] = acc[b] + bias;
+}
+__global__ void __launch_bounds__(256) equal_linear_bwd_kernel(EqLinArgs a)
+{
+    if ((int)blockIdx.x < a.nA) {                                  // dW, db: one thread per weight
+        const int e = blockIdx.x * 256 + threadIdx.x;
+        if (e >= a.out * a.in) return;
+        const int o = e / a.in, i = e - o * a.in;
+        float g = 0.f, gb = 0.f;
+        for (int b = 0; b < a.B; ++b) { const float d = a.dy[(size_t)b * a.out + o]; g = fmaf(d, a.x[b * a.in + i], g); gb += d; }
+        if (a.dW) a.dW[e] = g * a.scale;
+        if (a.db && i == 0) a.db[o] = gb * a.lr_mul;
+        return;
+    }
+    if (!a.dx) return;
+    const int q = ((int)blockIdx.x - a.nA) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;     // dx: one wave per (b, i)
+    if (q >= a.B * a.in) return;
+    const int b = q / a.in, i = q - b * a.in;
+    float acc = 0.f;
+    for (int o = lane; o < a.out; o += 64) acc = fmaf(a.dy[(size_t)b * a.out + o], a.W[(size_t)o * a.in + i] * a.scale, acc);
+    acc = wsum64(acc);
+    if (lane == 0) a.dx[q] = acc;
+}
+extern "C" int hav_equal_linear_fwd(float* y, const float* x, const float* W, const float* bias, float scale, float lr_mul, int B, int in_dim,
+                                    int out_dim, void* stream)
+{
+    if (!y || !x || !W || B < 1 || in_dim < 1 || out_dim < 1) return HAV_EINVAL;
+    if (B > EQL_MAXB || in_dim > 4096 || (int64_t)in_dim * out_dim > (1 << 24)) return HAV_EUNSUP;
+    EqLinArgs a{};
+    a.y = y; a.x = x; a.W = W; a.b = bias; a.scale = scale; a.lr_mul = lr_mul; a.B = B; a.in = in_dim; a.out = out_dim;
+    hipLaunchKernelGGL(equal_linear_fwd_kernel, dim3((out_dim + 63) / 64), dim3(64), 0, (hipStream_t)stream, a);
+    HAV_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int hav_equal_linear_bwd(float* dx, float* dW, float* dbias, const float* dy, const float* x, const float* W, float scale, float lr_mul,
+                                    int B, int in_dim, int out_dim, void* stream)
+{
+    if (!dy || !x || !W || B < 1 || in_dim < 1 || out_dim < 1) return HAV_EINVAL;
+    if (B > EQL_MAXB || in_dim > 4096 || (int64_t)in_dim * out_dim > (1 << 24)) return HAV_EUNSUP;
+    if (!dx && !dW && !dbias) return 0;
+    EqLinArgs a{};
+    a.dx = dx; a.dW = dW; a.db = dbias; a.dy = dy; a.x = x; a.W = W; a.scale = scale; a.lr_mul = lr_mul; a.B = B; a.in = in_dim; a.out = out_dim;
+    a.nA = (dW || dbias) ? (in_dim * out_dim + 255) / 256 : 0;
+    const int nB = dx ? (B * in_dim + 3) / 4 : 0;
+    hipLaunchKernelGGL(equal_linear_bwd_kernel, dim3(a.nA + nB), dim3(256), 0, (hipStream_t)stream, a);
+    HAV_LAUNCH_CHECK();
+    return 0;
+}

@@ -129,6 +129,12 @@ class EqualLinear(nn.Module, _InferenceCache):
         self.lr_mul = lr_mul
 
     def forward(self, input):
+        if (not self.activation and input.is_cuda and torch.is_grad_enabled() and os.environ.get("HAVATAR_HIP_TRAIN", "1") != "0"
+                and os.environ.get("HAVATAR_EQUAL_LINEAR", "1") != "0"):
+            from ..native.train_ops import equal_linear, equal_linear_eligible
+            if equal_linear_eligible(input, self.weight, self.bias):
+                # training: the scalar products over the parameters, the GEMM and their adjoints as one launch each way (hav_equal_linear_*)
+                return equal_linear(input, self.weight, self.bias, self.scale, self.lr_mul)
         w = self._cached("w", self.weight, lambda: self.weight * self.scale)
         b = self._cached("b", self.bias, lambda: self.bias * self.lr_mul) if self.bias is not None else None
         if self.activation:

@@ -216,6 +216,56 @@ def resample_depths(z, weights, num_fine, zeta=None, return_samples=False):
     return (z2, zs) if return_samples else z2
 
 
+class EqualLinearFn(Function):
+    """y = F.linear(x, W * scale, bias * lr_mul) for x [B <= 8, in]: one launch forward, one backward (hav_equal_linear_*), instead of the
+    3 + 6-7 ATen launches of the statement (model/styleUnet.py:128-162 of the reference) -- the modulation layer of every ModulatedConv2d."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias, scale, lr_mul):
+        _need_hip("EqualLinearFn", x, W, bias)
+        x, W = x.contiguous(), W.contiguous()
+        bias = bias.contiguous() if bias is not None else None
+        B, n_in = x.shape
+        n_out = W.shape[0]
+        if W.shape != (n_out, n_in) or (bias is not None and bias.shape != (n_out,)):
+            raise RuntimeError("EqualLinearFn: x [B,in], W [out,in], bias [out]")
+        y = torch.empty(B, n_out, device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            rc = _lib.lib().hav_equal_linear_fwd(_p(y), _p(x), _p(W), _p(bias), float(scale), float(lr_mul), B, n_in, n_out, _stream())
+        _lib.check(rc, "hav_equal_linear_fwd")
+        ctx.save_for_backward(x, W)
+        ctx.consts = (float(scale), float(lr_mul), bias is not None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        scale, lr_mul, has_bias = ctx.consts
+        dy = dy.contiguous()
+        B, n_in = x.shape
+        n_out = W.shape[0]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dW = torch.empty_like(W) if ctx.needs_input_grad[1] else None
+        db = torch.empty(n_out, device=x.device, dtype=torch.float32) if (has_bias and ctx.needs_input_grad[2]) else None
+        with torch.cuda.device(x.device):
+            rc = _lib.lib().hav_equal_linear_bwd(_p(dx), _p(dW), _p(db), _p(dy), _p(x), _p(W), scale, lr_mul, B, n_in, n_out, _stream())
+        _lib.check(rc, "hav_equal_linear_bwd")
+        return dx, dW, db, None, None
+
+
+def equal_linear_eligible(x, W, bias):
+    """training on HIP float32 tensors, a 2-D input of at most 8 rows (the style vectors of a batch), a shape the kernels take"""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and 1 <= x.shape[0] <= 8 and W.dtype == torch.float32 and W.dim() == 2
+            and x.shape[1] == W.shape[1] and W.shape[1] <= 4096 and W.shape[0] * W.shape[1] <= (1 << 24)
+            and (bias is None or bias.dtype == torch.float32) and torch.is_grad_enabled()
+            and (x.requires_grad or W.requires_grad or (bias is not None and bias.requires_grad)))
+
+
+def equal_linear(x, W, bias, scale, lr_mul):
+    return EqualLinearFn.apply(x, W, bias, scale, lr_mul)
+
+
 class Upsample3d2x(Function):
     """nn.Upsample(scale_factor=2, mode='trilinear', align_corners=False) on a float32 HIP tensor [N,C,D,H,W]: one launch forward,
     one backward (hav_upsample3d_2x_*), instead of the ~30 / ~60 ATen launches of the slice-and-lerp statement."""

@@ -198,6 +198,16 @@ int hav_composite_bwd(float* d_rf, const float* d_rgb, const float* d_acc, const
  * reference detaches).  S_c >= 3, S_c <= 128, ceil(S_c/2) + S_f <= 128 (else HAV_EUNSUP). */
 int hav_resample_depths(float* z2, float* z_samples, const float* z, const float* weights, const float* zeta, int64_t n_rays,
                         int S_c, int S_f, void* stream);
+/* EqualLinear without activation under autograd (added within ABI 6: additive) -- replaces, per modulation layer of a ModulatedConv2d and
+ * per optimisation step, the ATen launches of model/styleUnet.py:128-162 (`F.linear(input, self.weight * self.scale, bias=self.bias *
+ * self.lr_mul)`: two scalar products over the parameters + addmm forward; their adjoints, two GEMMs and a column sum backward):
+ *   fwd: y [B,out] = x [B,in] . fl(W [out,in] * scale)^T + fl(bias [out] * lr_mul)      (bias nullable)
+ *   bwd: dx [B,in] = dy . fl(W * scale);  dW [out,in] = scale * dy^T . x;  dbias [out] = lr_mul * sum_b dy      (each output nullable)
+ * fp32 throughout, sums in a fixed order (bit-reproducible).  B <= 8, in <= 4096, in * out <= 2^24 (else HAV_EUNSUP). */
+int hav_equal_linear_fwd(float* y, const float* x, const float* W, const float* bias, float scale, float lr_mul, int B, int in_dim,
+                         int out_dim, void* stream);
+int hav_equal_linear_bwd(float* dx, float* dW, float* dbias, const float* dy, const float* x, const float* W, float scale, float lr_mul,
+                         int B, int in_dim, int out_dim, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * 3x3, stride-1, zero-padded convolution of the StyleGAN blocks with the block's glue fused in -- replaces, at
