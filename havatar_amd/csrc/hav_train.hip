@@ -1135,15 +1135,70 @@ struct EqLinArgs {
     const float* x; const float* W; const float* b; const float* dy;
     float scale, lr_mul; int B, in, out, nA;
 };
+// x goes through LDS in chunks of `chunk` columns (B * chunk <= 2048 floats, chunk a multiple of 32; the path's style width of 32 is one
+// chunk); the weight row is read 8 x 16 bytes at a time when rows are 16-byte aligned (in % 4 == 0), so that one round trip to memory
+// covers 32 weights.  The sum runs over i in ascending order either way.
 __global__ void __launch_bounds__(64) equal_linear_fwd_kernel(EqLinArgs a)
 {
+    __shared__ float sx[2048];
     const int o = blockIdx.x * 64 + threadIdx.x;
+    const bool active = o < a.out;
+    const int chunk = (2048 / a.B) & ~31;
+    float acc[EQL_MAXB];
+#pragma unroll
+    for (int b = 0; b < EQL_MAXB; ++b) acc[b] = 0.f;
+    const float* wr = a.W + (size_t)(active ? o : 0) * a.in;
+    const bool vec = (a.in & 3) == 0 && (reinterpret_cast<uintptr_t>(a.W) & 15) == 0;
+    for (int c0 = 0; c0 < a.in; c0 += chunk) {
+        const int cn = min(chunk, a.in - c0);
+        if (c0) __syncthreads();
+        for (int e = threadIdx.x; e < a.B * cn; e += 64) { const int b = e / cn, i = e - b * cn; sx[b * chunk + i] = a.x[b * a.in + c0 + i]; }
+        __syncthreads();
+        if (!active) continue;
+        int i0 = 0;
+        if (vec) {
+            const float4* wr4 = reinterpret_cast<const float4*>(wr + c0);
+            const int n4 = cn >> 2;
+            for (int c = 0; c + 8 <= n4; c += 8) {
+                float4 wv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) wv[j] = wr4[c + j];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float w4[4] = {wv[j].x * a.scale, wv[j].y * a.scale, wv[j].z * a.scale, wv[j].w * a.scale};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int b = 0; b < EQL_MAXB; ++b)
+                            if (b < a.B) acc[b] = fmaf(sx[b * chunk + (c + j) * 4 + t], w4[t], acc[b]);
+                }
+            }
+            i0 = (n4 & ~7) << 2;
+        }
+        for (int i = i0; i < cn; ++i) {
+            const float w = wr[c0 + i] * a.scale;
+#pragma unroll
+            for (int b = 0; b < EQL_MAXB; ++b)
+                if (b < a.B) acc[b] = fmaf(sx[b * chunk + i], w, acc[b]);
+        }
+    }
+    if (!active) return;
+    const float bias = a.b ? a.b[o] * a.lr_mul : 0.f;
+#pragma unroll
+    for (int b = 0; b < EQL_MAXB; ++b)
+        if (b < a.B) a.y[(size_t)b * a.out + o] = acc[b] + bias;
+}
+// wide inputs (in >= 128; not on this path, whose style width is 32): a wave per output, lanes across the row (coalesced 256-byte reads of W
+// and x), one butterfly per batch row.  A thread per output would make every load instruction touch 64 different rows.
+__global__ void __launch_bounds__(256) equal_linear_fwd_wave_kernel(EqLinArgs a)
+{
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (o >= a.out) return;
     float acc[EQL_MAXB];
 #pragma unroll
     for (int b = 0; b < EQL_MAXB; ++b) acc[b] = 0.f;
     const float* wr = a.W + (size_t)o * a.in;
-    for (int i = 0; i < a.in; ++i) {
+    for (int i = lane; i < a.in; i += 64) {
         const float w = wr[i] * a.scale;
 #pragma unroll
         for (int b = 0; b < EQL_MAXB; ++b)
@@ -1152,7 +1207,10 @@ __global__ void __launch_bounds__(64) equal_linear_fwd_kernel(EqLinArgs a)
     const float bias = a.b ? a.b[o] * a.lr_mul : 0.f;
 #pragma unroll
     for (int b = 0; b < EQL_MAXB; ++b)
-        if (b < a.B) a.y[(size_t)b * a.out + o] = acc[b] + bias;
+        if (b < a.B) {
+            const float t = wsum64(acc[b]);
+            if (lane == 0) a.y[(size_t)b * a.out + o] = t + bias;
+        }
 }
 __global__ void __launch_bounds__(256) equal_linear_bwd_kernel(EqLinArgs a)
 {
@@ -1182,7 +1240,10 @@ extern "C" int hav_equal_linear_fwd(float* y, const float* x, const float* W, co
     if (B > EQL_MAXB || in_dim > 4096 || (int64_t)in_dim * out_dim > (1 << 24)) return HAV_EUNSUP;
     EqLinArgs a{};
     a.y = y; a.x = x; a.W = W; a.b = bias; a.scale = scale; a.lr_mul = lr_mul; a.B = B; a.in = in_dim; a.out = out_dim;
-    hipLaunchKernelGGL(equal_linear_fwd_kernel, dim3((out_dim + 63) / 64), dim3(64), 0, (hipStream_t)stream, a);
+    if (in_dim >= 128)
+        hipLaunchKernelGGL(equal_linear_fwd_wave_kernel, dim3((out_dim + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(equal_linear_fwd_kernel, dim3((out_dim + 63) / 64), dim3(64), 0, (hipStream_t)stream, a);
     HAV_LAUNCH_CHECK();
     return 0;
 }
