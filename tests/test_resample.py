@@ -97,6 +97,26 @@ def test_oracle_rejects_bad_sizes():
         oracle.resample_depths(z, z, 4, None)
 
 
+def test_the_training_wrappers_refuse_cpu_tensors_instead_of_falling_back():
+    """native/train_ops.py::resample_depths / equal_linear are HIP-only like the reference's CHECK_INPUT: a CPU tensor raises (the CPU
+    statement of the same steps lives in the Trainer / EqualLinear modules, never behind these entry points)."""
+    import torch
+    from havatar_amd.native.train_ops import equal_linear, equal_linear_eligible, resample_depths
+    z = torch.zeros(4, 64)
+    with pytest.raises(RuntimeError, match="HIP float32 tensors only"):
+        resample_depths(z, z, 16, None)
+    x, W, b = torch.zeros(2, 32, requires_grad=True), torch.zeros(64, 32, requires_grad=True), torch.zeros(64, requires_grad=True)
+    assert not equal_linear_eligible(x, W, b)
+    with pytest.raises(RuntimeError, match="HIP float32 tensors only"):
+        equal_linear(x, W, b, 1.0, 1.0)
+    # the module on CPU tensors: the reference's statement, unchanged
+    from havatar_amd.model.styleUnet import EqualLinear
+    m = EqualLinear(32, 64)
+    y = m(x)
+    assert type(y.grad_fn).__name__ == "AddmmBackward0"
+    assert torch.equal(y, torch.nn.functional.linear(x, m.weight * m.scale, m.bias * m.lr_mul))
+
+
 # ------------------------------------------------------------------------------------------------ GPU
 def _hip(z, w, S_f, zeta, samples=True):
     import torch
