@@ -97,6 +97,23 @@ def test_oracle_rejects_bad_sizes():
         oracle.resample_depths(z, z, 4, None)
 
 
+@pytest.mark.parametrize("jitter", [False, True])
+def test_oracle_resampling_equals_the_march_oracles_own(jitter):
+    """orc_resample_depths on the coarse depths / weights the march oracle (orc_render_rays, pinned to the reference's whole-frame outputs)
+    reports must give that oracle's merged fine depths: the two restate the same reference lines; they differ only in FMA contraction
+    (the march oracle is compiled with it, this function without: one ulp of the depth in fp32, 4e-15 in fp64)."""
+    from havatar_amd import synth
+    sc = synth.scene(16, 16, "primary")
+    n = sc["rays"].shape[1]
+    okw = {"t_rand": synth.uniform((1, n, 64), 11), "u_rand": synth.uniform((n, 16), 12)} if jitter else {}
+    for f64, tol in ((True, 4e-15), (False, 4.8e-7)):
+        d = oracle.render_rays(sc, 64, 16, perturb=jitter, nthreads=4, f64=f64, debug=True, **okw)
+        _, z2 = oracle.resample_depths(d["z_coarse"], d["w_coarse"], 16, okw.get("u_rand"), dtype=np.float64 if f64 else np.float32)
+        err = np.abs(z2.astype(np.float64) - d["z_fine"])
+        assert err.max() <= tol, (f64, err.max())
+        assert (err == 0).mean() >= 0.99
+
+
 def test_the_training_wrappers_refuse_cpu_tensors_instead_of_falling_back():
     """native/train_ops.py::resample_depths / equal_linear are HIP-only like the reference's CHECK_INPUT: a CPU tensor raises (the CPU
     statement of the same steps lives in the Trainer / EqualLinear modules, never behind these entry points)."""
