@@ -1597,7 +1597,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
                     int rank = 0;
                     for (int q = 0; q < S_fp; ++q) {
                         const float o = cand[q];
-                        rank += (o < v || (o == v && q < e)) ? 1 : 0;
+                        rank += ((o == o) ? ((v != v) || o < v || (o == v && q < e)) : ((v != v) && q < e)) ? 1 : 0;      // total order, NaN last (torch.sort)
                     }
                     zf[rank] = v;
                     if (a.dbg_zfine && (slot == 0 || has1)) a.dbg_zfine[gr * S_fp + rank] = v;

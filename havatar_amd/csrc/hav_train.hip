@@ -1095,7 +1095,10 @@ __global__ void __launch_bounds__(256) resample_depths_kernel(ResampleArgs a)
             int rank = 0;
             for (int q = 0; q < S_fp; ++q) {
                 const float o = cand[q];
-                rank += (o < v || (o == v && q < e)) ? 1 : 0;
+                // a TOTAL order, NaN last with the index as tie-break (what torch.sort does): every output slot is written exactly once even
+                // when a diverged step hands NaN depths / weights in (with `o < v || (o == v && q < e)` alone all NaNs ranked 0 and collided)
+                const bool before = (o == o) ? ((v != v) || o < v || (o == v && q < e)) : ((v != v) && q < e);
+                rank += before ? 1 : 0;
             }
             a.z2[r * S_fp + rank] = v;
         }

@@ -18,11 +18,15 @@ def _check_runtime_workaround():
     it at import unless the caller chose otherwise).  A process that initialised HIP before importing this package, or that switched the
     packet capture back on, is told once."""
     import warnings
-    from . import HIPGRAPH_PACKET_CAPTURE_ENV, hipgraph_replays_safe
+    from . import HIPGRAPH_PACKET_CAPTURE_ENV, hipgraph_replays_safe, hipgraph_state
     if not hipgraph_replays_safe() and not _WARNED[0]:
         _WARNED[0] = True
-        warnings.warn("%s is not 0: on ROCm 7.0.x replays of a captured hipGraph can return stale results once a reduction kernel has been "
-                      "launched eagerly between replays (tools/repro_graph_reduce.py)" % HIPGRAPH_PACKET_CAPTURE_ENV, RuntimeWarning)
+        st = hipgraph_state()
+        why = ("the HIP runtime was initialised before havatar_amd was imported and %s was not set: set it to 0 at the top of the script, before "
+               "the first torch.cuda call" % HIPGRAPH_PACKET_CAPTURE_ENV) if st["hip_initialised_before_setting"] else \
+              ("%s = %r, not 0" % (HIPGRAPH_PACKET_CAPTURE_ENV, st["env"]))
+        warnings.warn("hipGraph packet capture may be on (%s): on ROCm 7.0.x replays of a captured hipGraph can return stale results once a "
+                      "reduction kernel has been launched eagerly between replays (tools/repro_graph_reduce.py)" % why, RuntimeWarning)
 
 
 def weights_epoch():

@@ -750,10 +750,18 @@ class SWGAN_unet(nn.Module, _CondEncoder):
         if not input_is_latent:
             styles = [self.style(s if cond is None else torch.cat([s, cond], dim=-1)) for s in styles]
         if noise is None:
-            if randomize_noise and condition_img.is_cuda and not torch.is_grad_enabled():
+            Hc, Wc = condition_img.shape[-2:]
+            mid = 2 ** self.middle_log_size
+            if (randomize_noise and condition_img.is_cuda and not torch.is_grad_enabled()
+                    and (Hc * mid) % self.inp_size == 0 and (Wc * mid) % self.inp_size == 0):
                 # inference on the device: every layer's fresh noise map from ONE normal_() launch instead of one per layer (the maps are
-                # i.i.d. either way; 12 launches of ~5 us and their boundaries at 512 -> 1024)
-                shapes = [(condition_img.shape[0], 1) + tuple(getattr(self.noises, f"noise_{i}").shape[2:]) for i in range(self.num_layers)]
+                # i.i.d. either way; 12 launches of ~5 us and their boundaries at 512 -> 1024).  Sizes follow the FEATURE MAPS, as
+                # NoiseInjection's own `new_empty(b, 1, h, w)` does: the encoder takes an H x W condition image down to
+                # (H, W) * middle_size / inp_size, decoder layer li works at that times 2^(li // 2 + 1) -- not the registered noise_i buffers,
+                # whose sizes only match middle_size = 8 and a condition image of inp_size.  Anything that does not divide falls
+                # back to per-layer noise.
+                h0, w0 = Hc * mid // self.inp_size, Wc * mid // self.inp_size
+                shapes = [(condition_img.shape[0], 1, h0 << (i // 2 + 1), w0 << (i // 2 + 1)) for i in range(self.num_layers)]
                 sizes = [s[0] * s[2] * s[3] for s in shapes]
                 flat = condition_img.new_empty(sum(sizes), dtype=torch.float32).normal_()
                 noise, off = [], 0

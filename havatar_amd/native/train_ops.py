@@ -10,6 +10,12 @@ from torch.autograd.function import once_differentiable
 
 from .. import _lib
 
+# Under torch.autocast these nodes compute in fp32 like everywhere else: inputs are cast to fp32 and autocast is off inside forward AND backward
+# (without this, torch.mm inside Conv3dSmall.forward would return bf16 under autocast while backward, which runs outside it, multiplies a
+# bf16 gradient with the saved fp32 patch matrix: dtype mismatch; the kernels themselves refuse anything but fp32).
+_fwd32 = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_bwd32 = torch.amp.custom_bwd(device_type="cuda")
+
 
 def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
@@ -47,6 +53,7 @@ class FieldInputs(Function):
     """X [B*N, 2C+48] = cat(triplane(boxwarp(p')), PE(p')),  p' = skinning_field(pts, inv_T, vol).  Gradients: planes_cl, vol."""
 
     @staticmethod
+    @_fwd32
     def forward(ctx, pts, inv_T, vol, planes_cl, boxes, ray_rows=0):
         _need_hip("FieldInputs", pts, inv_T, vol, planes_cl)
         pts, inv_T, vol, planes_cl = pts.contiguous(), inv_T.contiguous(), vol.contiguous(), planes_cl.contiguous()
@@ -61,6 +68,7 @@ class FieldInputs(Function):
 
     @staticmethod
     @once_differentiable
+    @_bwd32
     def backward(ctx, dX):
         pts, inv_T, vol, planes_cl = ctx.saved_tensors
         dvol, dpl = _field_backward(pts, inv_T, vol, planes_cl, ctx.boxes, dX, ctx.needs_input_grad[2], ctx.needs_input_grad[3],
@@ -106,6 +114,7 @@ class FieldMlp(Function):
     bytes, and kept for the backward at half the memory.  Gradients: vol, planes_cl, the ten MLP tensors."""
 
     @staticmethod
+    @_fwd32
     def forward(ctx, pts, inv_T, vol, planes_cl, boxes, ray_rows, *weights):
         from . import mlp_train
         _need_hip("FieldMlp", pts, inv_T, vol, planes_cl)
@@ -123,6 +132,7 @@ class FieldMlp(Function):
 
     @staticmethod
     @once_differentiable
+    @_bwd32
     def backward(ctx, d_rf):
         from . import mlp_train
         pts, inv_T, vol, planes_cl, X, blob = ctx.saved_tensors
@@ -156,6 +166,7 @@ class Composite(Function):
     """(rgb [n,CH], acc [n], weights [n,S], depth [n]) = volume_render_radiance_field(rf [n,S,CH+1], z, rd, noise, bg)."""
 
     @staticmethod
+    @_fwd32
     def forward(ctx, rf, z, rd, noise, bg, n_sigmoid):
         _need_hip("Composite", rf, z, rd, noise, bg)
         rf, z, rd = rf.contiguous(), z.contiguous(), rd.contiguous()
@@ -177,6 +188,7 @@ class Composite(Function):
 
     @staticmethod
     @once_differentiable
+    @_bwd32
     def backward(ctx, d_rgb, d_acc, d_w, d_depth):
         rf, z, rd, noise, bg = ctx.saved_tensors
         n, S, RW = rf.shape
@@ -221,6 +233,7 @@ class EqualLinearFn(Function):
     3 + 6-7 ATen launches of the statement (model/styleUnet.py:128-162 of the reference) -- the modulation layer of every ModulatedConv2d."""
 
     @staticmethod
+    @_fwd32
     def forward(ctx, x, W, bias, scale, lr_mul):
         _need_hip("EqualLinearFn", x, W, bias)
         x, W = x.contiguous(), W.contiguous()
@@ -239,6 +252,7 @@ class EqualLinearFn(Function):
 
     @staticmethod
     @once_differentiable
+    @_bwd32
     def backward(ctx, dy):
         x, W = ctx.saved_tensors
         scale, lr_mul, has_bias = ctx.consts
@@ -271,6 +285,7 @@ class Upsample3d2x(Function):
     one backward (hav_upsample3d_2x_*), instead of the ~30 / ~60 ATen launches of the slice-and-lerp statement."""
 
     @staticmethod
+    @_fwd32
     def forward(ctx, x):
         _need_hip("Upsample3d2x", x)
         x = x.contiguous()
@@ -283,6 +298,7 @@ class Upsample3d2x(Function):
 
     @staticmethod
     @once_differentiable
+    @_bwd32
     def backward(ctx, g):
         N, Cc, D, H, W = ctx.shape
         g = g.contiguous()
@@ -302,6 +318,7 @@ class Conv3dSmall(Function):
     3.5 MB of filters for 8 / 64 / 512 voxels) and MIOpen / CK take 350 / 200 / 115 us for their forward alone."""
 
     @staticmethod
+    @_fwd32
     def forward(ctx, x, w, b):
         _need_hip("Conv3dSmall", x, w)
         x, w = x.contiguous(), w.contiguous()
@@ -318,6 +335,7 @@ class Conv3dSmall(Function):
 
     @staticmethod
     @once_differentiable
+    @_bwd32
     def backward(ctx, g):
         col, w = ctx.saved_tensors
         Cc, R = ctx.shape
@@ -337,6 +355,10 @@ class Conv3dSmall(Function):
 
 
 def conv3d_small_eligible(x, conv):
+    w, b = conv.weight, conv.bias
+    if not (w.is_cuda and w.device == x.device and w.dtype == torch.float32 and (b is None or (b.dtype == torch.float32 and b.device == x.device))
+            and getattr(conv, "padding_mode", "zeros") == "zeros"):
+        return False          # anything else stays on nn.Conv3d (a non-fp32 weight made Conv3dSmall raise instead of falling back)
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and x.shape[0] == 1 and x.shape[2] == x.shape[3] == x.shape[4] and x.shape[2] <= 8
             and tuple(conv.kernel_size) == (3, 3, 3) and tuple(conv.padding) == (1, 1, 1) and tuple(conv.stride) == (1, 1, 1)
             and tuple(conv.dilation) == (1, 1, 1) and conv.groups == 1 and os.environ.get("HAVATAR_CONV3D_SMALL", "1") != "0")
@@ -352,6 +374,7 @@ class Demod(Function):
     instead of ~8 + ~14 ATen launches, three of which stream the whole weight tensor."""
 
     @staticmethod
+    @_fwd32
     def forward(ctx, s, W, scale, eps):
         _need_hip("Demod", s, W)
         s, W = s.contiguous(), W.contiguous()
@@ -366,6 +389,7 @@ class Demod(Function):
         return d
 
     @staticmethod
+    @_bwd32
     def backward(ctx, gd):
         s, W, d, q = ctx.saved_tensors
         if torch.is_grad_enabled():

@@ -420,8 +420,9 @@ typedef struct HavRenderParams {
 
 /* How the two dense layers run on the matrix cores.  All three pass every parity test at the path's tolerance:
  *  HAV_MLP_SPLIT_BF16: each fp32 operand is split EXACTLY into 3 bf16 parts (24 significant bits: not narrower than the reference's
- *                      fp32) and the 6 leading bf16 x bf16 products are accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (error
- *                      ~2^-23 relative per product); the Python layer's default since round 4, and what bench.py's headline times;
+ *                      fp32) and the 6 leading bf16 x bf16 products are accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (dropped
+ *                      terms ~2^-23 relative per product; measured worst case 2^-21.7, see HAV_MLP_SPLIT_F16_MX); the Python layer's
+ *                      default in round 4, the fp16 range guard's stand-in since;
  *  HAV_MLP_F32:        v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fmaf chain. */
 #define HAV_MLP_SPLIT_BF16 0
 #define HAV_MLP_F32        1
@@ -429,8 +430,11 @@ typedef struct HavRenderParams {
                                   * order 2^-22 that mode drops (hi.tail, tail.hi, lo.lo; tail = v - hi - lo, exact) from one block-scaled
                                   * 4- / 6-bit matrix instruction each per 64 k (v_mfma_scale_f32_32x32x64_f8f6f4; factors rounded to 2-4
                                   * significant bits against per-(row, 32 k) / per-(query, 32 k) power-of-two scales: <= 2^-25 of the
-                                  * product).  Operands carry hi + lo + tail = the fp32 value itself; per-product error <= ~2^-24 -- the
-                                  * class of the bf16 triple split at 0.65 of its matrix time.  Same fp16 RANGE guard and bf16 stand-in
+                                  * product).  Operands carry hi + lo + tail = the fp32 value itself.  MEASURED per-product error against fp64
+                                  * (one-hot inputs, tests/test_render_gpu.py::test_arithmetic_modes_of_the_dense_layers_against_fp64_products):
+                                  * <= 2^-21.3 at worst with the SAME rms as the bf16 triple split (whose worst case is 2^-21.7): six
+                                  * roundings of partial products, not the operands, set both -- the class of the bf16 triple split at
+                                  * 0.65 of its matrix time.  Same fp16 RANGE guard and bf16 stand-in
                                   * as HAV_MLP_SPLIT_F16.  The Python layer's default since round 5 (HAVATAR_MLP=mx). */
 #define HAV_MLP_SPLIT_F16  2     /* each fp32 operand = hi + lo fp16 (both rounded to nearest: <= 2^-22 relative -- the size of the
                                   * fp32 accumulation error of a 128-term dot product), 3 products on v_mfma_f32_32x32x16_f16:

@@ -1,6 +1,9 @@
 import os
 import sys
 
+# before any test module can touch the device (havatar_amd/__init__.py: the HIP runtime reads this at its first call)
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -48,3 +48,50 @@ def test_frame_sharding_is_a_partition():
             parts = [list(shard_frames(n, r, world)) for r in range(world)]
             assert sorted(sum(parts, [])) == list(range(n))
             assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_hipgraph_workaround_state_tells_a_late_import_from_an_early_one():
+    """DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 only helps if it is set before the process's first HIP call.  havatar_amd.hipgraph_state()
+    must say `in_force: False` when the package is imported after the device was touched and nobody had set the variable (fresh interpreters;
+    the "device was touched" case is simulated with a stand-in `torch` module whose cuda.is_initialized() returns True)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = ("import sys, types, json, os\n"
+            "sys.path.insert(0, %r)\n"
+            "if os.environ.get('FAKE_HIP_UP') == '1':\n"
+            "    t = types.ModuleType('torch'); t.cuda = types.SimpleNamespace(is_initialized=lambda: True); sys.modules['torch'] = t\n"
+            "import havatar_amd\n"
+            "print(json.dumps([havatar_amd.hipgraph_state(), havatar_amd.hipgraph_replays_safe()]))\n") % root
+
+    def run(env_value, hip_up):
+        env = {k: v for k, v in os.environ.items() if k != "DEBUG_CLR_GRAPH_PACKET_CAPTURE"}
+        if env_value is not None:
+            env["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = env_value
+        env["FAKE_HIP_UP"] = "1" if hip_up else "0"
+        out = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, check=True).stdout
+        return json.loads(out.strip().splitlines()[-1])
+
+    st, safe = run(None, False)          # the normal import: nothing set, HIP still down -> the package's own setting is in force
+    assert st == {"env": "0", "set_by": "havatar_amd import", "hip_initialised_before_setting": False, "in_force": True} and safe
+    st, safe = run(None, True)           # device touched first, variable unset: the setdefault came too late
+    assert st["env"] == "0" and st["hip_initialised_before_setting"] and not st["in_force"] and not safe
+    st, safe = run("0", True)            # the caller set it at the top of its script (bench.py, the entry scripts): fine whatever came next
+    assert st["set_by"] == "caller" and st["in_force"] and safe
+    st, safe = run("1", False)           # an explicit setting wins and is reported as what it is
+    assert st["env"] == "1" and not st["in_force"] and not safe
+
+
+def test_entry_scripts_set_the_workaround_before_importing_torch():
+    """bench.py / train_avatar.py / avatarHD_reenactment.py touch the device before (or while) importing the package: the variable must be set
+    in their first statements, ahead of any `import torch`."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name in ("bench.py", "train_avatar.py", "avatarHD_reenactment.py"):
+        src = open(os.path.join(root, name)).read()
+        setpos = src.index('os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")')
+        first_torch = re.search(r"^\s*(import torch|from torch|from havatar_amd|import havatar_amd)", src, re.M)
+        assert first_torch is not None and setpos < first_torch.start(), name

@@ -280,3 +280,32 @@ def test_stage_two_cfg4_size_fused_path_equals_aten_path():
     assert fused.shape == (1, 3, 1024, 1024) and torch.isfinite(fused).all()
     scale = plain.abs().max().item()
     assert scale > 0.1 and (fused - plain).abs().max().item() <= 2e-5 * scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("middle_size,in_res", [(8, 64), (16, 64), (8, 32), (4, 64)])
+def test_swgan_unet_fresh_noise_follows_the_feature_maps(middle_size, in_res):
+    """with randomize_noise=True the inference route draws all layers' noise maps in one launch; their sizes must be those of the
+    feature maps (what NoiseInjection allocates itself), not the registered noise_i buffers, which only match middle_size = 8 and a
+    condition image of inp_size.  Other middle sizes and a half-size condition image run, give the output size the per-layer route gives,
+    and -- noise weights zeroed -- the same values as randomize_noise=False."""
+    from havatar_amd.model.styleUnet import SWGAN_unet
+    g = SWGAN_unet(inp_size=64, inp_ch=16, out_ch=3, out_size=128, style_dim=32, n_mlp=2, middle_size=middle_size)
+    g.requires_grad_(False)
+    synth.fill_state_dict(g, seed=4)
+    g = g.cuda().eval()
+    cond = torch.from_numpy(synth.normal((2, 16, in_res, in_res), 94, 0.5)).cuda()
+    style = torch.from_numpy(synth.normal((2, 32), 95)).cuda()
+    with torch.no_grad():
+        a = g(styles=[style], condition_img=cond, randomize_noise=True)
+        b = g(styles=[style], condition_img=cond, randomize_noise=True)
+    assert a.shape == (2, 3, 2 * in_res, 2 * in_res) and torch.isfinite(a).all()
+    assert not torch.equal(a, b)                                   # fresh noise per call
+    if in_res == 64:                                               # (the fixed buffers only fit a full-size condition image with middle_size = 8)
+        for m in g.modules():
+            if type(m).__name__ == "NoiseInjection":
+                m.weight.zero_()
+        with torch.no_grad():
+            c = g(styles=[style], condition_img=cond, randomize_noise=True)
+            none_route = g(styles=[style], condition_img=cond, noise=[None] * g.num_layers)
+        assert (c - none_route).abs().max().item() <= 2e-5 * none_route.abs().max().item()

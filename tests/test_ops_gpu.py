@@ -316,6 +316,34 @@ def test_conv3d_on_small_volumes_matches_the_aten_convolution(Cin, Cout, R):
         assert a.shape == r6.shape and e_a <= max(3.0 * e_3, 3e-6), (name, e_a, e_3)
 
 
+def test_training_nodes_compute_in_fp32_under_autocast_and_small_conv3d_eligibility():
+    """under torch.autocast the nodes of native/train_ops.py cast their inputs to fp32 and run forward AND backward with autocast
+    off (custom_fwd / custom_bwd) -- Conv3dSmall used to return bf16 from its torch.mm and then fail in backward on bf16 x fp32; and
+    conv3d_small_eligible sends non-fp32 / non-zero-padded / off-device convolutions to nn.Conv3d instead of letting the node raise."""
+    from havatar_amd.native.train_ops import Conv3dSmall, conv3d_small_eligible, equal_linear
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.randn(1, 24, 4, 4, 4, device=DEV, generator=g, requires_grad=True)
+    w = (torch.randn(10, 24, 3, 3, 3, device=DEV, generator=g) / 25.0).requires_grad_(True)
+    b = torch.randn(10, device=DEV, generator=g, requires_grad=True)
+    up = torch.randn(1, 10, 4, 4, 4, device=DEV, generator=g)
+    y0 = Conv3dSmall.apply(x, w, b)
+    g0 = torch.autograd.grad(y0, (x, w, b), up)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y1 = Conv3dSmall.apply(x, w, b)
+        xs, Ws, bs = torch.randn(2, 32, device=DEV, generator=g, requires_grad=True), torch.randn(64, 32, device=DEV, generator=g, requires_grad=True), torch.zeros(64, device=DEV, requires_grad=True)
+        ye = equal_linear(xs, Ws, bs, 0.5, 1.0)
+    g1 = torch.autograd.grad(y1, (x, w, b), up)
+    assert y1.dtype == torch.float32 and torch.equal(y0, y1) and all(torch.equal(a, c) for a, c in zip(g0, g1))
+    assert ye.dtype == torch.float32
+    ge = torch.autograd.grad(ye.sum(), (xs, Ws, bs))
+    assert all(t_.dtype == torch.float32 and torch.isfinite(t_).all() for t_ in ge)
+    conv = torch.nn.Conv3d(24, 10, 3, padding=1).to(DEV)
+    assert conv3d_small_eligible(x, conv)
+    assert not conv3d_small_eligible(x, torch.nn.Conv3d(24, 10, 3, padding=1, padding_mode="replicate").to(DEV))
+    assert not conv3d_small_eligible(x, torch.nn.Conv3d(24, 10, 3, padding=1).to(DEV).half())
+    assert not conv3d_small_eligible(x, torch.nn.Conv3d(24, 10, 3, padding=1))           # weights still on the host
+
+
 def test_haar_up2_equals_the_three_stage_skip_path_bit_for_bit():
     """hav_haar_up2 (ToRGB's skip path dwt(upsample(iwt(skip))) as one pass, reference model/styleUnet.py:476-480) against the three-stage
     sequence on this library's kernels (each pinned to the reference's upfirdn2d calls elsewhere in this file) and against the plain

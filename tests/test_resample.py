@@ -196,3 +196,35 @@ def test_hip_resample_refuses_what_it_cannot_hold_and_takes_empty_input():
     assert resample_depths(e, e, 16, None).shape == (0, 48)
     with pytest.raises(RuntimeError):
         resample_depths(torch.zeros(4, 64), torch.zeros(4, 64), 16, None)        # CPU tensors: refused like the reference's CHECK_INPUT
+
+
+@pytest.mark.gpu
+def test_hip_resample_writes_every_slot_when_the_inputs_hold_nans():
+    """a diverged step hands NaN weights / depths to the resampling.  The merge is a rank sort; its order is total (NaN last, index
+    as tie-break -- torch.sort's order), so every slot of the merged list is written exactly once: the output (allocated with torch.empty)
+    is a permutation of the even coarse depths and the new samples, finite values ascending, NaNs behind them -- what
+    torch.sort(torch.cat(...)) of the replaced ATen statement returns."""
+    import torch
+    from havatar_amd.native.train_ops import resample_depths
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    n, S_c, S_f = 64, 64, 16
+    z = np.sort(rng.uniform(3.5, 5.5, (n, S_c)).astype(np.float32), axis=-1)
+    w = rng.uniform(0, 1, (n, S_c)).astype(np.float32)
+    w[0, 7] = np.nan              # NaN weight: the pdf, the CDF and every new sample of the ray are NaN
+    z[1, 10] = np.nan             # NaN depths among the even coarse samples (and in two bin centres)
+    z[1, 20] = np.nan
+    w[2, :] = np.nan
+    z[2, ::2] = np.nan            # everything NaN
+    zt, wt = torch.from_numpy(z).to(dev), torch.from_numpy(w).to(dev)
+    for _ in range(3):            # fresh torch.empty outputs over poisoned memory: a slot left unwritten would show the poison
+        poison = torch.full((n, S_c // 2 + S_f), -12345.0, device=dev)
+        del poison
+        z2, zs = resample_depths(zt, wt, S_f, None, return_samples=True)
+        torch.cuda.synchronize()
+        z2, zs = z2.cpu().numpy(), zs.cpu().numpy()
+        assert not (z2 == -12345.0).any()
+        want = np.sort(np.concatenate([z[:, ::2], zs], -1), -1)          # numpy sorts NaN last, like torch.sort
+        assert np.array_equal(z2, want, equal_nan=True)
+        assert np.isnan(z2[0]).sum() == S_f and np.isnan(z2[2]).all() and np.isnan(z2[1]).sum() >= 2
+        assert np.isfinite(z2[3:]).all()

@@ -1,5 +1,9 @@
 #!/usr/bin/env python3
 """Entry script with the reference's name and flags (train_avatar.py); see havatar_amd/harness/train.py."""
+import os
+
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")          # before the first HIP call (havatar_amd/__init__.py)
+
 import numpy as np
 import torch
 
