@@ -1107,6 +1107,10 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a_in, const LaneCtx
                 tp[4 * pl + 2] = texel(cy1, cx0);
                 tp[4 * pl + 3] = texel(cy1, cx1);
             }
+            if constexpr (LAB_GATHER_MODEL != 0 && PREC == 3) {          // lab build only (hav_render_lab.h): timing model, wrong results
+                lab_gather_model(acc1, tp, tw, lane, a.pplanes, (long long)2 * a.p.B * PR * PR * 128);
+                return;
+            }
             // 8 taps x 256 B per lane, two taps (32 x 16 B) in flight.  The empty asm pins each tap's FMAs before the
             // loads that recycle its registers: left alone, the compiler hoists all 128 loads and spills them.
             constexpr int NST = 8 * 16 / GQ;          // pipeline stages: stage g covers float4s [(g*GQ)%16, +GQ) of tap (g*GQ)/16 ...

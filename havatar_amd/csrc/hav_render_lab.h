@@ -24,6 +24,45 @@
 #define LAB_STAGGER(wave_) do { } while (0)
 #endif
 
+// -DHAV_GATHER_MODEL (round 6, with -DHAV_LAB): TIMING MODEL of a tri-plane gather on the matrix cores -- results are WRONG.  The 32 rays of a
+// tile touch ~10 x 2 texels per plane (plane resolution 128 against 512 pixels: neighbouring rays are a quarter texel apart), yet every lane
+// fetches its own 8 taps x 256 B through the texture path: 128 KB per tile for ~12 KB of distinct data.  The model replaces the 128 loads +
+// 256 packed FMAs by what an interpolation-as-matrix-product would cost: out[unit][query] = sum_t P[unit][t] . Wt[t][query] over a 16-column
+// x 2-row footprint per plane (K = 4 chunks of 16), P pre-split into fp16 hi / lo fragments + MX records (read from global memory, coalesced
+// 1-KB rows), Wt = the bilinear weights scattered into the footprint's slots (selects + the hi / lo / tail split + 3 conversions on the VALU),
+// 48 fp16 MFMAs + 12 block-scaled ones per tile through mfma_split2x itself.  tools/ab_march.py compares it with the shipped kernel.
+#ifdef HAV_GATHER_MODEL
+#define LAB_GATHER_MODEL 1
+template <typename ACC>
+__device__ __forceinline__ void lab_gather_model(ACC& acc1, const float4* const (&tp)[8], const float (&tw)[8], int lane, const float* pplanes, long long plane_floats)
+{
+    const int h = lane >> 5;
+    // footprint origin: wave-wide minimum of the lanes' first-tap columns (two DPP reductions + broadcasts, as the real thing would need per plane)
+    long long off4 = (long long)(tp[0] - reinterpret_cast<const float4*>(pplanes));
+    float fo = (float)(int)(off4 & 0xFFFFF), f1 = (float)(int)((tp[4] - reinterpret_cast<const float4*>(pplanes)) & 0xFFFFF);
+    fo = -row16_max(-fo); f1 = -row16_max(-f1);
+    fo = fminf(fminf(read_lane(fo, 0), read_lane(fo, 16)), fminf(read_lane(fo, 32), read_lane(fo, 48)));
+    f1 = fminf(fminf(read_lane(f1, 0), read_lane(f1, 16)), fminf(read_lane(f1, 32), read_lane(f1, 48)));
+    long long base4 = (long long)__builtin_amdgcn_readfirstlane((int)fo) + (off4 & ~0xFFFFFll);
+    base4 = __builtin_amdgcn_readfirstlane((int)(base4 & 0x7FFFFFFF));
+    const long long lim4 = plane_floats / 4 - 16384;          // the model reads 32 KB of fragments + 15 KB of records behind the origin
+    if (base4 > lim4) base4 = lim4;
+    if (base4 < 0) base4 = 0;
+    const uint4* frag = reinterpret_cast<const uint4*>(pplanes) + base4;
+    const unsigned int* rec = reinterpret_cast<const unsigned int*>(pplanes) + 4 * base4 + 8192 + ((int)f1 & 3) * 4;
+    const int dx0 = (int)((off4 >> 2) & 7) + 1, dx1 = (int)(((tp[4] - tp[0]) >> 2) & 7) + 1;          // column of this lane's first tap inside the footprint
+    mfma_split2x<4, false>(acc1, frag, rec, lane, [&](int c, float (&v)[8]) {          // chunk c = (plane c >> 1, tap row c & 1)
+        const int d = (c >> 1) ? dx1 : dx0;
+        const float w0 = tw[4 * (c >> 1) + 2 * (c & 1)], w1 = tw[4 * (c >> 1) + 2 * (c & 1) + 1];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const int col = 8 * h + e; v[e] = (col == d) ? w0 : ((col == d + 1) ? w1 : 0.f); }
+    });
+}
+#else
+#define LAB_GATHER_MODEL 0
+template <typename ACC, typename TP, typename TW> __device__ __forceinline__ void lab_gather_model(ACC&, const TP&, const TW&, int, const float*, long long) {}
+#endif
+
 #ifdef HAV_PROFILE
 #define HAV_NPROF 24      // 0-9 phases | 10 wave lifetime | 11.. free
 __device__ unsigned long long g_prof[HAV_NPROF];
