@@ -748,7 +748,7 @@ class SWGAN_unet(nn.Module, _CondEncoder):
     def forward(self, styles, condition_img, cond=None, return_latents=False, inject_index=None, truncation=1,
                 truncation_latent=None, input_is_latent=False, noise=None, randomize_noise=True):
         if not input_is_latent:
-            styles = [self.style(s if cond is None else torch.cat([s, cond], dim=-1)) for s in styles]
+            styles = [_run_style(self.style, s if cond is None else torch.cat([s, cond], dim=-1)) for s in styles]          # (one launch on the device: hav_style_mlp)
         if noise is None:
             Hc, Wc = condition_img.shape[-2:]
             mid = 2 ** self.middle_log_size
