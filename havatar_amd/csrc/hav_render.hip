@@ -1008,6 +1008,7 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a_in, const LaneCtx
     const float4* sBt = L.sB + sb_off;
     const int PR = a.p.plane_res, VR = a.p.vol_res;
     // ---- pts = o + d z; skinning field (model/Skinning_Field.py:77-95): half-wave h evaluates bone h ---------
+    LAB_PRIO_SITE(HAV_PRIO_A);
     const float px = ox + dx * z, py = oy + dy * z, pz = oz + dz * z;
     const float* iT = a.inv_T + (size_t)b * 12;
     const float tx_ = px + iT[9], ty_ = py + iT[10], tz_ = pz + iT[11];
@@ -1165,6 +1166,7 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a_in, const LaneCtx
         }
         __builtin_amdgcn_sched_barrier(0);
         TICK(3);
+        LAB_PRIO_SITE(HAV_PRIO_D);
 
         if (PREC == 3) {
             if (!ABL(16))
@@ -1255,6 +1257,7 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a_in, const LaneCtx
         relu_tiles<LEAN>(acc2);
         DBG_STAGE(2, acc2);
         TICK(5);
+        LAB_PRIO_SITE(HAV_PRIO_E);
 
         __builtin_amdgcn_sched_barrier(0);
         // ---- head rows rgb(3, folded fc_rgb o fc_rgbFeat) + alpha: 4 dot products over the 128 hidden units.
@@ -1316,8 +1319,16 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a_in, const LaneCtx
     };
     f32x16 acc1[4];
     bias_init(acc1);
+    LAB_PRIO_SITE(HAV_PRIO_B);
     gather(acc1);
+    // Wave priority (round 6): the two waves of a SIMD are mostly in different phases; the one that is past its gather -- positional encoding, the dense
+    // layers, the head rows, the caller's compositing / parking -- goes first at the issue port, the one still collecting taps (its FMAs wait for loads
+    // anyway) yields.  Same instructions, same results bit for bit; -1.2 ... -1.4 % kernel time over six interleaved same-box rounds of 40 launches
+    // (profiles/r06_prio_ab.txt: levels 1 and 3, the dense layers alone or everything behind the gather measure the same; priority on the gather side
+    // measures nothing).  -DHAV_PRIO_C / _F override the two levels in lab builds.
+    LAB_PRIO_SITE(HAV_PRIO_C);
     finish(acc1);
+    LAB_PRIO_SITE(HAV_PRIO_F);
 }
 #undef LDB4
 

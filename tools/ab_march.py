@@ -25,7 +25,7 @@ out = []
 for perturb in (True, False):
     for _ in range(3): rm.render(*args, perturb=perturb, coarse_outputs=CO)
     ts = []
-    for _ in range(12):
+    for _ in range(int(os.environ.get('AB_N', '12'))):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(); rm.render(*args, perturb=perturb, coarse_outputs=CO); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
     out.append("%s %.3f ms (min %.3f)" % ("perturb" if perturb else "det    ", float(np.median(ts)), min(ts)))
@@ -38,7 +38,7 @@ for k in sorted(o, key=str):
 out.append("det sha1 " + hsh.hexdigest()[:12])
 print(" | ".join(out))
 '''
-for rnd in range(2):
+for rnd in range(int(os.environ.get('AB_ROUNDS', '2'))):          # AB_ROUNDS / AB_N: rounds over the libraries / timed launches per round
     for lib in sys.argv[1:]:
         env = dict(os.environ)
         if lib:
