@@ -692,6 +692,7 @@ struct LaneCtx {
     const float4* sB;                           // LDS copy of b1 | b2 (block kernel; the pair kernel reads them through the buffer path)
     __amdgpu_buffer_rsrc_t wrs;
     int lane, h, hoff;
+    int young;                                  // wave-uniform: this wave is in the workgroup's second-dispatched half (lab: static priority experiments)
 };
 
 #define LDB4(off_floats) __builtin_amdgcn_raw_buffer_load_b128(L.wrs, h * 16, (off_floats) * 4, 0)
@@ -1328,7 +1329,7 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a_in, const LaneCtx
     // measures nothing).  -DHAV_PRIO_C / _F override the two levels in lab builds.
     LAB_PRIO_SITE(HAV_PRIO_C);
     finish(acc1);
-    LAB_PRIO_SITE(HAV_PRIO_F);
+    LAB_PRIO_F(L.young);
 }
 #undef LDB4
 
@@ -1385,7 +1386,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
     const int j = lane & 31, h = lane >> 5, col = lane & 15, rowt = (lane >> 4) & 1;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.blob), 0, BLOB_FLOATS * 4, 0x00020000);
     LaneCtx L;
-    L.sW1 = sW1; L.sW2 = sW2; L.sW4 = sW4; L.wrs = wrs; L.lane = lane; L.h = h; L.hoff = h * 16;
+    L.sW1 = sW1; L.sW2 = sW2; L.sW4 = sW4; L.wrs = wrs; L.lane = lane; L.h = h; L.hoff = h * 16; L.young = 0;
 
     const int S_c = a.p.S_c, S_fp = a.S_fp;
     const long long NR = a.NR;
@@ -1718,7 +1719,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
     L.sMX = reinterpret_cast<const unsigned int*>(smem + LDSX_FP16);
     L.sB = reinterpret_cast<const float4*>(smem + WLDS);
     L.wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.blob), 0, BLOB_FLOATS * 4, 0x00020000);
-    L.lane = lane; L.h = h; L.hoff = h * 16;
+    L.lane = lane; L.h = h; L.hoff = h * 16; L.young = wave >= MARCH_WAVES / 2;
 
     const int S_c = a.p.S_c, S_f = a.p.S_f, S_fp = a.S_fp, S_half = (S_c + 1) >> 1;
     const int R = a.p.R;
@@ -1726,6 +1727,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
     const long long nblk = (long long)bpf * a.p.B;
 
     LAB_STAGGER(wave);
+    if (HAV_PRIO_YOUNG >= 0 && wave >= MARCH_WAVES / 2) LAB_PRIO_SITE(HAV_PRIO_YOUNG);
     long long chunk, base, span;
     int lb, nbx;
     if ((gridDim.x & 7) == 0) {

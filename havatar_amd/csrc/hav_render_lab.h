@@ -86,6 +86,15 @@ template <typename ACC, typename TP, typename TW> __device__ __forceinline__ voi
 #ifndef HAV_PRIO_F
 #define HAV_PRIO_F 0          // shipped: see sample_eval
 #endif
+// static priority of the workgroup's second-dispatched half (waves 4-7: the younger wave of every SIMD loses the age arbitration, MI355X_MICROARCH.md
+// "Two waves per SIMD"): HAV_PRIO_YOUNG = its level from the kernel's start, HAV_PRIO_F_YOUNG = its level at site F (instead of HAV_PRIO_F)
+#ifndef HAV_PRIO_YOUNG
+#define HAV_PRIO_YOUNG -1
+#endif
+#ifndef HAV_PRIO_F_YOUNG
+#define HAV_PRIO_F_YOUNG -1
+#endif
+#define LAB_PRIO_F(young) do { if (HAV_PRIO_F_YOUNG >= 0 && (young)) { LAB_PRIO_SITE(HAV_PRIO_F_YOUNG); } else { LAB_PRIO_SITE(HAV_PRIO_F); } } while (0)
 
 #ifdef HAV_PROFILE
 #define HAV_NPROF 24      // 0-9 phases | 10 wave lifetime | 11.. free
