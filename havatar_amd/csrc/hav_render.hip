@@ -100,6 +100,9 @@
 #define LDSX_FLOATS (LDSX_FP16 + MX_GROUPS * MX_G_DWORDS)      // 34560 dwords = 135 KB
 #define BLOB_FLOATS (OFF_MX + MX_GROUPS * MX_G_DWORDS)
 #define HAV_FP16_LIMIT 60000.0f
+#ifndef HAV_PRIO_DENSE
+#define HAV_PRIO_DENSE 3          // issue priority of a wave behind its gather (sample_eval); -DHAV_PRIO_DENSE=0: A/B builds without it
+#endif
 
 extern "C" int64_t hav_mlp_blob_bytes(void) { return (int64_t)BLOB_FLOATS * 4; }
 
@@ -692,7 +695,6 @@ struct LaneCtx {
     const float4* sB;                           // LDS copy of b1 | b2 (block kernel; the pair kernel reads them through the buffer path)
     __amdgpu_buffer_rsrc_t wrs;
     int lane, h, hoff;
-    int young;                                  // wave-uniform: this wave is in the workgroup's second-dispatched half (lab: static priority experiments)
 };
 
 #define LDB4(off_floats) __builtin_amdgcn_raw_buffer_load_b128(L.wrs, h * 16, (off_floats) * 4, 0)
@@ -1009,7 +1011,6 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a_in, const LaneCtx
     const float4* sBt = L.sB + sb_off;
     const int PR = a.p.plane_res, VR = a.p.vol_res;
     // ---- pts = o + d z; skinning field (model/Skinning_Field.py:77-95): half-wave h evaluates bone h ---------
-    LAB_PRIO_SITE(HAV_PRIO_A);
     const float px = ox + dx * z, py = oy + dy * z, pz = oz + dz * z;
     const float* iT = a.inv_T + (size_t)b * 12;
     const float tx_ = px + iT[9], ty_ = py + iT[10], tz_ = pz + iT[11];
@@ -1167,7 +1168,6 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a_in, const LaneCtx
         }
         __builtin_amdgcn_sched_barrier(0);
         TICK(3);
-        LAB_PRIO_SITE(HAV_PRIO_D);
 
         if (PREC == 3) {
             if (!ABL(16))
@@ -1258,7 +1258,6 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a_in, const LaneCtx
         relu_tiles<LEAN>(acc2);
         DBG_STAGE(2, acc2);
         TICK(5);
-        LAB_PRIO_SITE(HAV_PRIO_E);
 
         __builtin_amdgcn_sched_barrier(0);
         // ---- head rows rgb(3, folded fc_rgb o fc_rgbFeat) + alpha: 4 dot products over the 128 hidden units.
@@ -1320,16 +1319,15 @@ __device__ __forceinline__ void sample_eval(const MarchArgs& a_in, const LaneCtx
     };
     f32x16 acc1[4];
     bias_init(acc1);
-    LAB_PRIO_SITE(HAV_PRIO_B);
     gather(acc1);
     // Wave priority (round 6): the two waves of a SIMD are mostly in different phases; the one that is past its gather -- positional encoding, the dense
     // layers, the head rows, the caller's compositing / parking -- goes first at the issue port, the one still collecting taps (its FMAs wait for loads
-    // anyway) yields.  Same instructions, same results bit for bit; -1.2 ... -1.4 % kernel time over six interleaved same-box rounds of 40 launches
-    // (profiles/r06_prio_ab.txt: levels 1 and 3, the dense layers alone or everything behind the gather measure the same; priority on the gather side
-    // measures nothing).  -DHAV_PRIO_C / _F override the two levels in lab builds.
-    LAB_PRIO_SITE(HAV_PRIO_C);
+    // anyway) yields.  Same instructions, same results bit for bit; -1.2 ... -1.8 % kernel time over interleaved same-box rounds of 40 launches
+    // (profiles/r06_prio_ab.txt: levels 1, 2 and 3, the dense layers alone or everything behind the gather measure the same; priority on the gather or
+    // geometry side, and a static level for the second-dispatched half of the workgroup alone, measure nothing).
+    __builtin_amdgcn_s_setprio(HAV_PRIO_DENSE);
     finish(acc1);
-    LAB_PRIO_F(L.young);
+    __builtin_amdgcn_s_setprio(0);
 }
 #undef LDB4
 
@@ -1386,7 +1384,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
     const int j = lane & 31, h = lane >> 5, col = lane & 15, rowt = (lane >> 4) & 1;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.blob), 0, BLOB_FLOATS * 4, 0x00020000);
     LaneCtx L;
-    L.sW1 = sW1; L.sW2 = sW2; L.sW4 = sW4; L.wrs = wrs; L.lane = lane; L.h = h; L.hoff = h * 16; L.young = 0;
+    L.sW1 = sW1; L.sW2 = sW2; L.sW4 = sW4; L.wrs = wrs; L.lane = lane; L.h = h; L.hoff = h * 16;
 
     const int S_c = a.p.S_c, S_fp = a.S_fp;
     const long long NR = a.NR;
@@ -1719,7 +1717,7 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
     L.sMX = reinterpret_cast<const unsigned int*>(smem + LDSX_FP16);
     L.sB = reinterpret_cast<const float4*>(smem + WLDS);
     L.wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.blob), 0, BLOB_FLOATS * 4, 0x00020000);
-    L.lane = lane; L.h = h; L.hoff = h * 16; L.young = wave >= MARCH_WAVES / 2;
+    L.lane = lane; L.h = h; L.hoff = h * 16;
 
     const int S_c = a.p.S_c, S_f = a.p.S_f, S_fp = a.S_fp, S_half = (S_c + 1) >> 1;
     const int R = a.p.R;
@@ -1727,7 +1725,6 @@ __global__ void __launch_bounds__(MARCH_THREADS, MARCH_THREADS / 256) hav_march_
     const long long nblk = (long long)bpf * a.p.B;
 
     LAB_STAGGER(wave);
-    if (HAV_PRIO_YOUNG >= 0 && wave >= MARCH_WAVES / 2) LAB_PRIO_SITE(HAV_PRIO_YOUNG);
     long long chunk, base, span;
     int lb, nbx;
     if ((gridDim.x & 7) == 0) {

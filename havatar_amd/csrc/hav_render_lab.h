@@ -63,39 +63,6 @@ __device__ __forceinline__ void lab_gather_model(ACC& acc1, const float4* const 
 template <typename ACC, typename TP, typename TW> __device__ __forceinline__ void lab_gather_model(ACC&, const TP&, const TW&, int, const float*, long long) {}
 #endif
 
-// -DHAV_PRIO_A=<level> ... -DHAV_PRIO_F=<level> (round 6): s_setprio experiments.  Sites of a tile evaluation: A geometry / skinning taps begin |
-// B tri-plane gather begins | C gather done, positional encoding begins | D layer 1 begins | E head rows begin (both layers done) | F the
-// caller's epilogue is done.  The shipped library sets C = 3 and F = 0 (the wave behind its gather goes first); the other sites emit nothing without a -D.
-// Results are unchanged; only the time moves.
-#define LAB_PRIO_SITE(level) do { if ((level) >= 0) __builtin_amdgcn_s_setprio((level) < 0 ? 0 : (level)); } while (0)
-#ifndef HAV_PRIO_A
-#define HAV_PRIO_A -1
-#endif
-#ifndef HAV_PRIO_B
-#define HAV_PRIO_B -1
-#endif
-#ifndef HAV_PRIO_C
-#define HAV_PRIO_C 3          // shipped: see sample_eval
-#endif
-#ifndef HAV_PRIO_D
-#define HAV_PRIO_D -1
-#endif
-#ifndef HAV_PRIO_E
-#define HAV_PRIO_E -1
-#endif
-#ifndef HAV_PRIO_F
-#define HAV_PRIO_F 0          // shipped: see sample_eval
-#endif
-// static priority of the workgroup's second-dispatched half (waves 4-7: the younger wave of every SIMD loses the age arbitration, MI355X_MICROARCH.md
-// "Two waves per SIMD"): HAV_PRIO_YOUNG = its level from the kernel's start, HAV_PRIO_F_YOUNG = its level at site F (instead of HAV_PRIO_F)
-#ifndef HAV_PRIO_YOUNG
-#define HAV_PRIO_YOUNG -1
-#endif
-#ifndef HAV_PRIO_F_YOUNG
-#define HAV_PRIO_F_YOUNG -1
-#endif
-#define LAB_PRIO_F(young) do { if (HAV_PRIO_F_YOUNG >= 0 && (young)) { LAB_PRIO_SITE(HAV_PRIO_F_YOUNG); } else { LAB_PRIO_SITE(HAV_PRIO_F); } } while (0)
-
 #ifdef HAV_PROFILE
 #define HAV_NPROF 24      // 0-9 phases | 10 wave lifetime | 11.. free
 __device__ unsigned long long g_prof[HAV_NPROF];
