@@ -272,11 +272,21 @@ __global__ void __launch_bounds__(64) style_mlp_kernel(float* __restrict__ out, 
         const int Din = l == 0 ? D0 : D;
         float acc = 0.f;
         const int oc = lane < D ? lane : D - 1;
-        for (int k = 0; k < Din; ++k) {
-            const float xk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), k));
-            acc = fmaf(xk, w[k * D + oc], acc);
+        // the layer's weight column of this lane in ONE round trip (<= 64 loads in flight + the bias), then the products in index order.  (Round 5
+        // read w[k] inside the k loop: 32 dependent L2 round trips per layer -- 55 us for the 32 -> 32 x 4 network at the head of each generator's
+        // chain; same sums, same order.)
+        float wv[64];
+#pragma unroll
+        for (int k = 0; k < 64; ++k) wv[k] = k < Din ? w[k * D + oc] : 0.f;
+        const float bias = w[Din * D + oc];
+#pragma unroll
+        for (int k = 0; k < 64; ++k) {
+            if (k < Din) {          // (wave-uniform)
+                const float xk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), k));
+                acc = fmaf(xk, wv[k], acc);
+            }
         }
-        const float y = acc + w[Din * D + oc];
+        const float y = acc + bias;
         x = lane < D ? (y > 0.f ? y : y * slope) * gain : 0.f;          // fused_leaky_relu (fused_bias_act_kernel.cu:40-63)
         w += (Din + 1) * D;
     }
