@@ -592,9 +592,11 @@ static int conv_ksplit(int B, int Cin, int Cout, int H, int W)
 {
     const bool il = conv_interleaved(Cout) && !conv_narrow(H, W);
     const int64_t tiles = (int64_t)B * (Cout / (il ? 128 : 64)) * ((int64_t)H * W / (CV_ROWS * CV_COLS));
+    // workgroups wanted before the K dimension is split (A/B: HAVATAR_CONV_KSPLIT_CUS, read once; default = the number of compute units)
+    static const int want = [] { const char* e = getenv("HAVATAR_CONV_KSPLIT_CUS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : hav_num_cus(); }();
     int ks = 1;
-    if (il) { while (tiles * ks < hav_num_cus() && ks < 8 && (Cin / 16) / (ks * 2) >= 2) ks *= 2; }
-    else { while (tiles * ks < hav_num_cus() && ks < 4 && (Cin / 16) / (ks * 2) >= 4) ks *= 2; }
+    if (il) { while (tiles * ks < want && ks < 8 && (Cin / 16) / (ks * 2) >= 2) ks *= 2; }
+    else { while (tiles * ks < want && ks < 4 && (Cin / 16) / (ks * 2) >= 4) ks *= 2; }
     return ks;
 }
 extern "C" int64_t hav_conv3x3_scratch_bytes(int B, int Cin, int Cout, int H, int W)
